@@ -1,0 +1,237 @@
+"""Engine: typed Python front end of the C ABI, torch tensors as device buffers."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from ._capi import AdnError, WAVELET, EXT, THR
+
+_ENGINES = {}
+
+
+def get_engine(device=0):
+    """Process-wide engine per device index."""
+    if device not in _ENGINES:
+        _ENGINES[device] = Engine(device)
+    return _ENGINES[device]
+
+
+def _suffix(dtype):
+    if dtype == torch.float32:
+        return "_f32"
+    if dtype == torch.float64:
+        return "_f64"
+    raise TypeError("only float32 / float64 buffers are supported, got %s" % dtype)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Engine:
+    """One adn_ctx bound to cuda:<device>.  Not thread-safe (the context owns a workspace)."""
+
+    def __init__(self, device=0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: the MI355X HIP path has no CPU fallback")
+        self.lib = _capi.load()
+        self.device = int(device)
+        self.torch_device = torch.device("cuda", self.device)
+        h = C.c_void_p()
+        self._check(self.lib.adn_create(C.byref(h), self.device))
+        self._h = h
+        self.use_current_stream()
+
+    # ------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc != 0:
+            raise AdnError(rc, self.lib.adn_last_error().decode("utf-8", "replace"))
+
+    def use_current_stream(self):
+        """Enqueue on torch's current stream of this device."""
+        s = torch.cuda.current_stream(self.torch_device).cuda_stream
+        self._check(self.lib.adn_set_stream(self._h, C.c_void_p(s)))
+
+    def synchronize(self):
+        self._check(self.lib.adn_synchronize(self._h))
+
+    def workspace_bytes(self):
+        return int(self.lib.adn_workspace_bytes(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.adn_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _i64(self, values):
+        return torch.as_tensor(np.asarray(values, dtype=np.int64), device=self.torch_device)
+
+    def _call(self, base, dtype, *args):
+        fn = getattr(self.lib, base + _suffix(dtype))
+        self._check(fn(self._h, *args))
+
+    # ------------------------------------------------------- length helpers
+    def wavelet_out_frames(self, frames):
+        return int(self.lib.adn_wavelet_out_frames(int(frames)))
+
+    def denoise_block_frames(self, rate, frames):
+        return int(self.lib.adn_denoise_block_frames(int(rate), int(frames)))
+
+    def stft_num_frames(self, n, n_fft, hop, padded=True):
+        return int(self.lib.adn_stft_num_frames(int(n), int(n_fft), int(hop), int(bool(padded))))
+
+    def istft_out_samples(self, n, n_fft, hop):
+        return int(self.lib.adn_istft_out_samples(int(n), int(n_fft), int(hop)))
+
+    # --------------------------------------------------------------- phase 2
+    def wavelet_denoise(self, x, in_off, frames, out, out_off, n_ch=1, wavelet="db4", level=2,
+                        thr_mode="soft", want_stats=False, max_frames=None):
+        """Batched VisuShrink block denoise.  x / out: flat device tensors; in_off, frames,
+        out_off: int64 device tensors (element offsets / frame counts per block)."""
+        nb = int(frames.numel())
+        if max_frames is None:
+            max_frames = int(frames.max().item()) if nb else 1
+        sigma = thresh = zeroed = None
+        if want_stats:
+            sigma = torch.empty(nb, dtype=torch.float64, device=self.torch_device)
+            thresh = torch.empty(nb, dtype=torch.float64, device=self.torch_device)
+            zeroed = torch.empty(nb, dtype=torch.int64, device=self.torch_device)
+        self._call("adn_wavelet_denoise", x.dtype, _ptr(x), _ptr(out), nb, _ptr(in_off), _ptr(frames),
+                   _ptr(out_off), int(max_frames), int(n_ch), WAVELET[wavelet], int(level),
+                   THR[thr_mode], _ptr(sigma), _ptr(thresh), _ptr(zeroed))
+        return (sigma, thresh, zeroed) if want_stats else None
+
+    def denoise_signal(self, x, rate, wavelet="db4", level=2, thr_mode="soft", want_stats=False):
+        """AudioDeNoise.deNoise arithmetic on a device tensor of shape (frames,) or
+        (frames, channels): blocks of int(rate * duration * 0.10) frames, each denoised
+        independently.  Returns the concatenated blocks (and per-block stats)."""
+        frames_total = int(x.shape[0])
+        n_ch = 1 if x.dim() == 1 else int(x.shape[1])
+        bs = self.denoise_block_frames(rate, frames_total)
+        if bs <= 0:
+            raise ValueError("input shorter than 10 frames: block size is zero")
+        starts = np.arange(0, frames_total, bs, dtype=np.int64)
+        lens = np.minimum(bs, frames_total - starts)
+        if n_ch == 1:
+            out_lens = 2 * ((lens + 1) // 2)
+        else:
+            out_lens = lens
+        out_starts = np.concatenate([[0], np.cumsum(out_lens)[:-1]])
+        out = torch.empty((int(out_lens.sum()),) if n_ch == 1 else (int(out_lens.sum()), n_ch),
+                          dtype=x.dtype, device=x.device)
+        xc = x.contiguous()
+        stats = self.wavelet_denoise(xc.view(-1), self._i64(starts * n_ch), self._i64(lens), out.view(-1),
+                                     self._i64(out_starts * n_ch), n_ch=n_ch, wavelet=wavelet, level=level,
+                                     thr_mode=thr_mode, want_stats=want_stats, max_frames=int(lens.max()))
+        return (out, stats) if want_stats else out
+
+    def wavedec(self, x, wavelet="db4", level=2, mode="per"):
+        """pywt.wavedec of one 1-D device tensor -> list [cA_L, cD_L, ..., cD_1]."""
+        n = int(x.numel())
+        F = 8 if wavelet == "db4" else 16
+        cap = n + (level + 1) * F + 2 * level + 8 if EXT[mode] else n + 2 * level + 8
+        co = torch.empty(cap, dtype=x.dtype, device=x.device)
+        lens = (C.c_int64 * (level + 1))()
+        self._call("adn_wavedec", x.dtype, _ptr(x.contiguous()), n, WAVELET[wavelet], int(level), EXT[mode],
+                   _ptr(co), cap, lens)
+        out, pos = [], 0
+        for ln in lens:
+            out.append(co[pos:pos + ln].clone())
+            pos += ln
+        return out
+
+    def waverec(self, coeffs, wavelet="db4", mode="per"):
+        level = len(coeffs) - 1
+        flat = torch.cat([c.reshape(-1) for c in coeffs]).contiguous()
+        lens = (C.c_int64 * (level + 1))(*[int(c.numel()) for c in coeffs])
+        cap = 2 * max(int(c.numel()) for c in coeffs) + 4
+        y = torch.empty(cap, dtype=flat.dtype, device=flat.device)
+        n_out = C.c_int64(0)
+        self._call("adn_waverec", flat.dtype, _ptr(flat), lens, WAVELET[wavelet], level, EXT[mode], _ptr(y),
+                   cap, C.byref(n_out))
+        return y[:n_out.value].clone()
+
+    # ------------------------------------------------------------ STFT stages
+    def _signals(self, lens, n_ch, n_fft):
+        lens = np.asarray(lens, dtype=np.int64)
+        if (lens < n_fft).any():
+            # scipy.signal.stft raises this for every such signal
+            raise ValueError("window is longer than input signal")
+        starts = np.concatenate([[0], np.cumsum(lens * n_ch)[:-1]]).astype(np.int64)
+        return starts, lens
+
+    def noise_psd(self, x, lens, n_ch=1, n_fft=2048, hop=512, padded=True, percentile=95.0,
+                  spectral_floor=0.1, freq_bins=5, time_frames=5, offsets=None):
+        """Phase 1 on a batch: x flat device tensor holding the signals back to back
+        (or at `offsets`).  Returns (n_sig, n_fft/2+1) baseline magnitudes."""
+        starts, lens = self._signals(lens, n_ch, n_fft)
+        if offsets is not None:
+            starts = np.asarray(offsets, dtype=np.int64)
+        out = torch.empty((len(lens), n_fft // 2 + 1), dtype=x.dtype, device=x.device)
+        self._call("adn_noise_psd", x.dtype, _ptr(x), len(lens), _ptr(self._i64(starts)), _ptr(self._i64(lens)),
+                   int(lens.max()), int(n_ch), int(n_fft), int(hop), int(bool(padded)), float(percentile),
+                   float(spectral_floor), int(freq_bins), int(time_frames), _ptr(out))
+        return out
+
+    def spectral_subtract(self, x, lens, noise_mag, n_ch=1, n_fft=2048, hop=512, alpha=2.2, beta=0.1,
+                          smooth_time=3, smooth_freq=5, offsets=None, out=None, out_offsets=None):
+        """Phase 2b on a batch.  noise_mag: (F,) shared or (n_sig, F).  Returns (y, out_lens)
+        with the outputs back to back in y (or at `out_offsets` of `out`)."""
+        starts, lens = self._signals(lens, n_ch, n_fft)
+        if offsets is not None:
+            starts = np.asarray(offsets, dtype=np.int64)
+        out_lens = np.array([self.istft_out_samples(n, n_fft, hop) for n in lens], dtype=np.int64)
+        if out_offsets is None:
+            out_offsets = np.concatenate([[0], np.cumsum(out_lens)[:-1]]).astype(np.int64)
+        if out is None:
+            out = torch.empty(int(out_lens.sum()), dtype=x.dtype, device=x.device)
+        noise_mag = noise_mag.to(dtype=x.dtype, device=x.device).contiguous()
+        stride = 0 if noise_mag.dim() == 1 else noise_mag.shape[1]
+        if noise_mag.shape[-1] != n_fft // 2 + 1:
+            raise ValueError("noise profile must hold n_fft/2+1 bins (resize it on the host first)")
+        self._call("adn_spectral_subtract", x.dtype, _ptr(x), len(lens), _ptr(self._i64(starts)),
+                   _ptr(self._i64(lens)), int(lens.max()), int(n_ch), _ptr(noise_mag), int(stride), int(n_fft),
+                   int(hop), float(alpha), float(beta), int(smooth_time), int(smooth_freq), _ptr(out),
+                   _ptr(self._i64(out_offsets)))
+        return out, out_lens
+
+    def wiener(self, x, lens, sample_rate, n_ch=1, n_fft=2048, hop=512, update_ms=20, kernel_bins=5,
+               vad_guided=True, offsets=None, out=None, out_offsets=None, want_gain=False):
+        """Phase 2c on a batch.  Returns (y, out_lens[, gain])."""
+        starts, lens = self._signals(lens, n_ch, n_fft)
+        if offsets is not None:
+            starts = np.asarray(offsets, dtype=np.int64)
+        out_lens = np.array([self.istft_out_samples(n, n_fft, hop) for n in lens], dtype=np.int64)
+        if out_offsets is None:
+            out_offsets = np.concatenate([[0], np.cumsum(out_lens)[:-1]]).astype(np.int64)
+        if out is None:
+            out = torch.empty(int(out_lens.sum()), dtype=x.dtype, device=x.device)
+        gain = torch.empty((len(lens), n_fft // 2 + 1), dtype=x.dtype, device=x.device) if want_gain else None
+        self._call("adn_wiener", x.dtype, _ptr(x), len(lens), _ptr(self._i64(starts)), _ptr(self._i64(lens)),
+                   int(lens.max()), int(n_ch), int(sample_rate), int(n_fft), int(hop), float(update_ms),
+                   int(kernel_bins), int(bool(vad_guided)), _ptr(out), _ptr(self._i64(out_offsets)), _ptr(gain))
+        return (out, out_lens, gain) if want_gain else (out, out_lens)
+
+    # ------------------------------------------------------------------ misc
+    def window_rms(self, x, win):
+        n_rows = int(x.shape[0])
+        n_ch = 1 if x.dim() == 1 else int(x.shape[1])
+        n_win = -(-n_rows // int(win))
+        out = torch.empty(n_win, dtype=torch.float64, device=x.device)
+        self._call("adn_window_rms", x.dtype, _ptr(x.contiguous()), n_rows, n_ch, int(win), _ptr(out))
+        return out
+
+    def synth_noisy_speech(self, n, sample_rate, seed=42, stream=0, sigma=0.05, speech_gain=1.0,
+                           start=0, dtype=torch.float64, out=None):
+        if out is None:
+            out = torch.empty(int(n), dtype=dtype, device=self.torch_device)
+        self._call("adn_synth_noisy_speech", out.dtype, _ptr(out), int(n), int(start), int(sample_rate),
+                   C.c_uint64(seed), C.c_uint64(stream), float(sigma), float(speech_gain))
+        return out

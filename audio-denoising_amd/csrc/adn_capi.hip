@@ -1,0 +1,173 @@
+// extern "C" surface of libadn_hip.so: context management, length helpers and
+// thin typed wrappers around the templated implementations.
+#include <math.h>
+#include <string.h>
+
+#include "adn_kernels.hpp"
+
+namespace adn {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int ws_reserve(Ctx *c, size_t bytes) {
+    if (bytes <= c->ws_bytes) return ADN_OK;
+    // round up generously so that slowly growing batches do not reallocate every call
+    size_t want = bytes + bytes / 8 + (1u << 20);
+    if (c->ws) {
+        ADN_HIP(hipStreamSynchronize(c->stream));
+        ADN_HIP(hipFree(c->ws));
+        c->ws = nullptr;
+        c->ws_bytes = 0;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        set_error("workspace allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+        return ADN_ERR_NOMEM;
+    }
+    c->ws = static_cast<char *>(p);
+    c->ws_bytes = want;
+    return ADN_OK;
+}
+
+}  // namespace adn
+
+using adn::Ctx;
+
+extern "C" {
+
+const char *adn_last_error(void) { return adn::g_err; }
+
+int adn_version(void) { return 100; }
+
+int adn_create(adn_ctx **out, int device) {
+    ADN_REQUIRE(out != nullptr, "ctx output pointer is null");
+    int count = 0;
+    ADN_HIP(hipGetDeviceCount(&count));
+    ADN_REQUIRE(device >= 0 && device < count, "device %d out of range (%d visible)", device, count);
+    adn::DeviceGuard dg(device);
+    hipDeviceProp_t prop;
+    ADN_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        adn::set_error("device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        return ADN_ERR_UNSUPPORTED;
+    }
+    adn_ctx *c = new adn_ctx();
+    c->device = device;
+    c->num_cus = prop.multiProcessorCount;
+    *out = c;
+    return ADN_OK;
+}
+
+int adn_destroy(adn_ctx *c) {
+    if (!c) return ADN_OK;
+    adn::DeviceGuard dg(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->ws) (void)hipFree(c->ws);
+    for (int i = 0; i < c->n_tables; ++i)
+        if (c->tables[i].dev) (void)hipFree(c->tables[i].dev);
+    delete c;
+    return ADN_OK;
+}
+
+int adn_set_stream(adn_ctx *c, void *s) {
+    ADN_REQUIRE(c != nullptr, "ctx is null");
+    c->stream = static_cast<hipStream_t>(s);
+    return ADN_OK;
+}
+
+int adn_synchronize(adn_ctx *c) {
+    ADN_REQUIRE(c != nullptr, "ctx is null");
+    adn::DeviceGuard dg(c->device);
+    ADN_HIP(hipStreamSynchronize(c->stream));
+    return ADN_OK;
+}
+
+int64_t adn_workspace_bytes(adn_ctx *c) { return c ? (int64_t)c->ws_bytes : 0; }
+
+int64_t adn_wavelet_out_frames(int64_t frames) { return 2 * ((frames + 1) / 2); }
+
+int64_t adn_denoise_block_frames(int64_t rate, int64_t frames) {
+    if (rate <= 0) return 0;
+    const double duration = (double)frames / (double)rate;
+    return (int64_t)((double)rate * duration * 0.10);
+}
+
+int64_t adn_stft_num_frames(int64_t n, int n_fft, int hop, int padded) {
+    if (n < n_fft || n_fft <= 0 || hop <= 0) return -1;
+    int64_t nadd = 0;
+    if (padded) {
+        int64_t r = (n - n_fft) % hop;
+        nadd = ((hop - r) % hop) % n_fft;
+    }
+    return 1 + (n + nadd - n_fft) / hop;
+}
+
+int64_t adn_istft_out_samples(int64_t n, int n_fft, int hop) {
+    const int64_t T = adn_stft_num_frames(n, n_fft, hop, 1);
+    return T < 0 ? -1 : (T - 1) * hop;
+}
+
+#define ADN_WRAP_T(SUF, T)                                                                          \
+    int adn_wavelet_denoise_##SUF(adn_ctx *c, const T *d_in, T *d_out, int64_t n_blocks,            \
+                                  const int64_t *d_in_off, const int64_t *d_frames,                 \
+                                  const int64_t *d_out_off, int64_t max_frames, int n_ch,           \
+                                  int wavelet, int level, int thr_mode, double *d_sigma,            \
+                                  double *d_thresh, int64_t *d_zeroed) {                            \
+        return adn::wavelet_denoise<T>(c, d_in, d_out, n_blocks, d_in_off, d_frames, d_out_off,     \
+                                       max_frames, n_ch, wavelet, level, thr_mode, d_sigma,         \
+                                       d_thresh, d_zeroed);                                         \
+    }                                                                                               \
+    int adn_wavedec_##SUF(adn_ctx *c, const T *d_x, int64_t n, int wavelet, int level, int ext,     \
+                          T *d_coeffs, int64_t cap, int64_t *h_band_len) {                          \
+        return adn::wavedec<T>(c, d_x, n, wavelet, level, ext, d_coeffs, cap, h_band_len);          \
+    }                                                                                               \
+    int adn_waverec_##SUF(adn_ctx *c, const T *d_coeffs, const int64_t *h_band_len, int wavelet,    \
+                          int level, int ext, T *d_y, int64_t cap, int64_t *h_n_out) {              \
+        return adn::waverec<T>(c, d_coeffs, h_band_len, wavelet, level, ext, d_y, cap, h_n_out);    \
+    }                                                                                               \
+    int adn_noise_psd_##SUF(adn_ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off,          \
+                            const int64_t *d_len, int64_t max_len, int n_ch, int n_fft, int hop,    \
+                            int padded, double percentile, double spectral_floor, int freq_bins,    \
+                            int time_frames, T *d_baseline) {                                       \
+        return adn::noise_psd<T>(c, d_x, n_sig, d_off, d_len, max_len, n_ch, n_fft, hop, padded,    \
+                                 percentile, spectral_floor, freq_bins, time_frames, d_baseline);   \
+    }                                                                                               \
+    int adn_spectral_subtract_##SUF(adn_ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off,  \
+                                    const int64_t *d_len, int64_t max_len, int n_ch,                \
+                                    const T *d_noise, int64_t noise_stride, int n_fft, int hop,     \
+                                    double alpha, double beta, int smooth_time, int smooth_freq,    \
+                                    T *d_y, const int64_t *d_y_off) {                               \
+        return adn::spectral_subtract<T>(c, d_x, n_sig, d_off, d_len, max_len, n_ch, d_noise,       \
+                                         noise_stride, n_fft, hop, alpha, beta, smooth_time,        \
+                                         smooth_freq, d_y, d_y_off);                                \
+    }                                                                                               \
+    int adn_wiener_##SUF(adn_ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off,             \
+                         const int64_t *d_len, int64_t max_len, int n_ch, int sample_rate,          \
+                         int n_fft, int hop, double update_ms, int kernel_bins, int vad_guided,     \
+                         T *d_y, const int64_t *d_y_off, T *d_gain) {                               \
+        return adn::wiener<T>(c, d_x, n_sig, d_off, d_len, max_len, n_ch, sample_rate, n_fft, hop,  \
+                              update_ms, kernel_bins, vad_guided, d_y, d_y_off, d_gain);            \
+    }                                                                                               \
+    int adn_window_rms_##SUF(adn_ctx *c, const T *d_x, int64_t n_rows, int n_ch, int64_t win,       \
+                             double *d_rms) {                                                       \
+        return adn::window_rms<T>(c, d_x, n_rows, n_ch, win, d_rms);                                \
+    }                                                                                               \
+    int adn_synth_noisy_speech_##SUF(adn_ctx *c, T *d_x, int64_t n, int64_t start, int sample_rate, \
+                                     uint64_t seed, uint64_t stream, double sigma,                  \
+                                     double speech_gain) {                                          \
+        return adn::synth_noisy_speech<T>(c, d_x, n, start, sample_rate, seed, stream, sigma,       \
+                                          speech_gain);                                             \
+    }
+
+ADN_WRAP_T(f32, float)
+ADN_WRAP_T(f64, double)
+
+}  // extern "C"

@@ -1,0 +1,66 @@
+// Internal launch interfaces between the translation units of libadn_hip.so.
+#pragma once
+#include "adn_common.hpp"
+
+namespace adn {
+
+// ------------------------------------------------ segmented order statistics
+enum { SEL_MEDIAN = 0, SEL_PERCENTILE = 1 };
+enum { XF_NONE = 0, XF_ABSDEV = 1 };
+
+struct SelectArgs {
+    int64_t n_seg = 0;
+    const int64_t *d_seg_off = nullptr;   // element offset per segment, or null: seg * seg_stride
+    int64_t seg_stride = 0;
+    const int64_t *d_seg_len = nullptr;   // length per (seg / len_div), or null: uniform_len
+    int64_t len_div = 1;
+    int64_t uniform_len = 0;
+    int64_t max_len = 0;                  // upper bound of any segment length (sizes LDS)
+    int mode = SEL_MEDIAN;
+    double q = 50.0;                      // percentile in [0, 100] for SEL_PERCENTILE
+    int xform = XF_NONE;
+    const double *d_center = nullptr;     // per segment, for XF_ABSDEV
+    double *d_out = nullptr;              // per segment result
+};
+
+// Exact numpy-compatible median / linearly interpolated percentile of every
+// segment (NaN if the segment is empty or holds a NaN).
+template <typename T>
+int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a);
+
+// -------------------------------------------------------------- wavelets
+template <typename T>
+int wavelet_denoise(Ctx *c, const T *d_in, T *d_out, int64_t n_blocks, const int64_t *d_in_off,
+                    const int64_t *d_frames, const int64_t *d_out_off, int64_t max_frames,
+                    int n_ch, int wavelet, int level, int thr_mode, double *d_sigma,
+                    double *d_thresh, int64_t *d_zeroed);
+template <typename T>
+int wavedec(Ctx *c, const T *d_x, int64_t n, int wavelet, int level, int ext_mode, T *d_coeffs,
+            int64_t cap, int64_t *h_band_len);
+template <typename T>
+int waverec(Ctx *c, const T *d_coeffs, const int64_t *h_band_len, int wavelet, int level,
+            int ext_mode, T *d_y, int64_t cap, int64_t *h_n_out);
+
+// ------------------------------------------------------------ STFT stages
+template <typename T>
+int noise_psd(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int64_t *d_len,
+              int64_t max_len, int n_ch, int n_fft, int hop, int padded, double percentile,
+              double spectral_floor, int freq_bins, int time_frames, T *d_baseline);
+template <typename T>
+int spectral_subtract(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off,
+                      const int64_t *d_len, int64_t max_len, int n_ch, const T *d_noise,
+                      int64_t noise_stride, int n_fft, int hop, double alpha, double beta,
+                      int smooth_time, int smooth_freq, T *d_y, const int64_t *d_y_off);
+template <typename T>
+int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int64_t *d_len,
+           int64_t max_len, int n_ch, int sample_rate, int n_fft, int hop, double update_ms,
+           int kernel_bins, int vad_guided, T *d_y, const int64_t *d_y_off, T *d_gain);
+
+// ------------------------------------------------------------------ misc
+template <typename T>
+int window_rms(Ctx *c, const T *d_x, int64_t n_rows, int n_ch, int64_t win, double *d_rms);
+template <typename T>
+int synth_noisy_speech(Ctx *c, T *d_x, int64_t n, int64_t start, int sample_rate, uint64_t seed,
+                       uint64_t stream, double sigma, double speech_gain);
+
+}  // namespace adn

@@ -1,0 +1,104 @@
+// Small kernels: RMS-window energies for the window profiler and the
+// bit-reproducible synthetic test-signal generator.
+#include "adn_kernels.hpp"
+
+namespace adn {
+
+// ------------------------------------------------------------ window RMS
+// One wave per window: sum of squares over every channel of the window's rows
+// (lib/windowBundle.py:67-74), divided by the row count, square root.
+template <typename T>
+__global__ __launch_bounds__(256) void k_window_rms(const T *__restrict__ x, int64_t n_rows,
+                                                    int n_ch, int64_t win, int64_t n_win,
+                                                    double *__restrict__ rms) {
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (w >= n_win) return;
+    const int64_t r0 = w * win, r1 = (r0 + win < n_rows) ? r0 + win : n_rows;
+    const T *p = x + r0 * n_ch;
+    const int64_t cnt = (r1 - r0) * n_ch;
+    double s = 0.0;
+    for (int64_t i = lane; i < cnt; i += 64) {
+        const double v = (double)p[i];
+        s += v * v;
+    }
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    if (lane == 0) rms[w] = sqrt(s / (double)(r1 - r0));
+}
+
+template <typename T>
+int window_rms(Ctx *c, const T *d_x, int64_t n_rows, int n_ch, int64_t win, double *d_rms) {
+    ADN_REQUIRE(c && d_x && d_rms, "null pointer argument");
+    ADN_REQUIRE(n_rows >= 1 && n_ch >= 1 && win >= 1, "n_rows, n_ch and win must be >= 1");
+    DeviceGuard dg(c->device);
+    const int64_t n_win = ceil_div(n_rows, win);
+    hipLaunchKernelGGL((k_window_rms<T>), dim3((unsigned)ceil_div(n_win, 4)), dim3(256), 0,
+                       c->stream, d_x, n_rows, n_ch, win, n_win, d_rms);
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
+
+// ------------------------------------------------------ synthetic signal
+// Every operation below is an exactly rounded IEEE double operation and FP
+// contraction is off, so the host generator (same formulas) produces the same bits.
+#pragma clang fp contract(off)
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z ^= z >> 30;
+    z *= 0xBF58476D1CE4E5B9ull;
+    z ^= z >> 27;
+    z *= 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return z;
+}
+
+__device__ __forceinline__ double psin(double p) {
+#pragma clang fp contract(off)
+    const double q = p - floor(p + 0.5);
+    return q * (8.0 - 16.0 * fabs(q));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_synth(T *__restrict__ x, int64_t n, int64_t start,
+                                               double sr, uint64_t base, double sigma,
+                                               double speech_gain) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t idx = (uint64_t)(start + i);
+    const uint64_t h = splitmix64(idx * 0xA0761D6478BD642Full + base);
+    const double s4 = (double)((h & 0xFFFF) + ((h >> 16) & 0xFFFF) + ((h >> 32) & 0xFFFF) + ((h >> 48) & 0xFFFF));
+    const double noise = (s4 - 131070.0) * (1.7320508075688772 / 65536.0);
+    const double t = (double)idx / sr;
+    const double phase = 140.0 * t + (20.0 / 3.0) * psin(0.5 * t) * 0.5;
+    double r = 3.0 * t;
+    r = r - floor(r);
+    const double ramp = fmin(r, 0.5 - r) / 0.03;
+    const double env = fmin(fmax(ramp, 0.0), 1.0);
+    const double s = 0.25 * psin(phase) + 0.12 * psin(2.0 * phase) + 0.06 * psin(3.0 * phase);
+    const double sp = env * s;
+    const double v = speech_gain * sp + sigma * noise;
+    x[i] = (T)v;
+}
+
+template <typename T>
+int synth_noisy_speech(Ctx *c, T *d_x, int64_t n, int64_t start, int sample_rate, uint64_t seed,
+                       uint64_t stream, double sigma, double speech_gain) {
+    ADN_REQUIRE(c && d_x, "null pointer argument");
+    ADN_REQUIRE(n >= 0 && start >= 0 && sample_rate > 0, "n, start must be >= 0 and sample_rate > 0");
+    if (n == 0) return ADN_OK;
+    DeviceGuard dg(c->device);
+    const uint64_t base = seed * 0x9E3779B97F4A7C15ull + stream * 0xD1B54A32D192ED03ull;
+    hipLaunchKernelGGL((k_synth<T>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, c->stream, d_x,
+                       n, start, (double)sample_rate, base, sigma, speech_gain);
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
+
+template int window_rms<float>(Ctx *, const float *, int64_t, int, int64_t, double *);
+template int window_rms<double>(Ctx *, const double *, int64_t, int, int64_t, double *);
+template int synth_noisy_speech<float>(Ctx *, float *, int64_t, int64_t, int, uint64_t, uint64_t, double, double);
+template int synth_noisy_speech<double>(Ctx *, double *, int64_t, int64_t, int, uint64_t, uint64_t, double, double);
+
+}  // namespace adn

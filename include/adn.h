@@ -1,0 +1,204 @@
+/*
+ * adn.h - C ABI of the MI355X-native audio denoising hot path (libadn_hip.so).
+ *
+ * The reference (nobbydoo80/Audio-Denoising) is pure Python and has no FFI of
+ * its own: its hot path sits behind the class API in denoise.py and the four
+ * stage scripts under src/.  This header is the boundary a ctypes binding in
+ * those files would call instead of pywt / scipy / numpy.  Every entry point
+ * names the reference lines whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - All functions return ADN_OK (0) or a negative ADN_ERR_* code; the message
+ *    for the last failure on the calling thread is adn_last_error().
+ *  - Pointers prefixed d_ are DEVICE pointers (hipMalloc / torch-ROCm tensors),
+ *    pointers prefixed h_ are host pointers.  The caller owns every buffer.
+ *  - Work is enqueued on the context's stream (adn_set_stream; default: the
+ *    null stream) and is asynchronous with respect to the host; no entry point
+ *    synchronises unless its comment says so.
+ *  - A context owns a device workspace that grows on demand (hipMalloc only on
+ *    growth) and is re-used by later calls, so a context must not be used from
+ *    two host threads at once.  Calls on one context are ordered by its stream.
+ *  - _f32 entry points compute in IEEE binary32, _f64 in binary64 (the
+ *    reference's own precision).  Order statistics are exact in either mode.
+ */
+#ifndef ADN_H
+#define ADN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct adn_ctx adn_ctx;
+
+enum {
+    ADN_OK = 0,
+    ADN_ERR_ARG = -1,          /* bad argument (null pointer, size, enum) */
+    ADN_ERR_HIP = -2,          /* a HIP runtime call failed */
+    ADN_ERR_UNSUPPORTED = -3,  /* valid in the reference but not implemented here */
+    ADN_ERR_NOMEM = -4,        /* workspace allocation failed */
+    ADN_ERR_SHORT = -5         /* signal shorter than the STFT window (scipy raises ValueError) */
+};
+
+enum { ADN_WAVELET_DB4 = 0, ADN_WAVELET_DB8 = 1 };
+enum { ADN_EXT_PERIODIZATION = 0, ADN_EXT_SYMMETRIC = 1 };
+enum { ADN_THR_SOFT = 0, ADN_THR_HARD = 1 };
+
+/* ---------------------------------------------------------------- context */
+const char *adn_last_error(void);
+int adn_version(void);
+int adn_create(adn_ctx **ctx, int device);
+int adn_destroy(adn_ctx *ctx);
+/* hip_stream is a hipStream_t (0 = null stream). */
+int adn_set_stream(adn_ctx *ctx, void *hip_stream);
+/* Blocks the host until everything enqueued on the context's stream is done. */
+int adn_synchronize(adn_ctx *ctx);
+/* Bytes of device workspace currently held by the context. */
+int64_t adn_workspace_bytes(adn_ctx *ctx);
+
+/* ------------------------------------------------------- length helpers */
+/* Frames pywt.waverec(mode='per') returns for a block of `frames` frames when
+ * the transform runs along time (mono): 2*ceil(frames/2).  denoise.py:77,89. */
+int64_t adn_wavelet_out_frames(int64_t frames);
+/* Frames per block of AudioDeNoise.deNoise: int(rate * (frames/rate) * 0.10),
+ * evaluated in IEEE double like the reference.  denoise.py:76. */
+int64_t adn_denoise_block_frames(int64_t rate, int64_t frames);
+/* scipy.signal.stft(boundary=None, padded=True) frame count for n samples, or
+ * -1 when n < n_fft.  src/spectral_subtract.py:82. */
+int64_t adn_stft_num_frames(int64_t n, int n_fft, int hop, int padded);
+/* Samples scipy.signal.istft (boundary=True) returns: (T-1)*hop.
+ * src/spectral_subtract.py:108. */
+int64_t adn_istft_out_samples(int64_t n, int n_fft, int hop);
+
+/* ------------------------------------------------ phase 2: wavelet blocks
+ * Replaces, per block, pywt.wavedec(block, w, mode='per', level=L) ->
+ * sigma = mad(cD1) -> thresh = sigma*sqrt(2*ln(frames)) -> pywt.threshold on
+ * every detail band -> pywt.waverec  (denoise.py:16-23, 77-89).
+ *
+ * Blocks are independent.  Block b reads frames[b] frames of n_ch interleaved
+ * samples starting at element d_in[d_in_off[b]] and writes to
+ * d_out[d_out_off[b]] (element offsets).
+ *   n_ch == 1 : the transform runs along time; the block comes back with
+ *               adn_wavelet_out_frames(frames[b]) samples.
+ *   n_ch >= 2 : like the reference (pywt default axis=-1 on a (frames, n_ch)
+ *               block) the transform runs ACROSS THE CHANNEL AXIS of every
+ *               frame; n_ch must be even and <= 8; output is frames[b]*n_ch.
+ * d_in_off / d_frames / d_out_off: device arrays of n_blocks int64.
+ * max_frames: an upper bound of frames[b] (sizes grids and workspace).
+ * d_sigma / d_thresh (n_blocks doubles) and d_zeroed (n_blocks int64: detail
+ * coefficients whose magnitude was below the threshold) may be NULL.
+ */
+int adn_wavelet_denoise_f32(adn_ctx *ctx, const float *d_in, float *d_out, int64_t n_blocks,
+                            const int64_t *d_in_off, const int64_t *d_frames,
+                            const int64_t *d_out_off, int64_t max_frames, int n_ch, int wavelet,
+                            int level, int thr_mode, double *d_sigma, double *d_thresh,
+                            int64_t *d_zeroed);
+int adn_wavelet_denoise_f64(adn_ctx *ctx, const double *d_in, double *d_out, int64_t n_blocks,
+                            const int64_t *d_in_off, const int64_t *d_frames,
+                            const int64_t *d_out_off, int64_t max_frames, int n_ch, int wavelet,
+                            int level, int thr_mode, double *d_sigma, double *d_thresh,
+                            int64_t *d_zeroed);
+
+/* Multi-level analysis / synthesis of ONE signal (pywt.wavedec / pywt.waverec,
+ * and the single-level steps pywt.WaveletPacket is built from:
+ * lib/windowBundle.py:33-34).  d_coeffs receives the bands concatenated as
+ * [cA_L, cD_L, ..., cD_1]; h_band_len (level+1 int64, host) receives their
+ * lengths.  ext_mode: ADN_EXT_PERIODIZATION or ADN_EXT_SYMMETRIC.
+ * These two calls synchronise the stream before returning. */
+int adn_wavedec_f64(adn_ctx *ctx, const double *d_x, int64_t n, int wavelet, int level,
+                    int ext_mode, double *d_coeffs, int64_t coeffs_capacity,
+                    int64_t *h_band_len);
+int adn_waverec_f64(adn_ctx *ctx, const double *d_coeffs, const int64_t *h_band_len, int wavelet,
+                    int level, int ext_mode, double *d_y, int64_t y_capacity, int64_t *h_n_out);
+int adn_wavedec_f32(adn_ctx *ctx, const float *d_x, int64_t n, int wavelet, int level,
+                    int ext_mode, float *d_coeffs, int64_t coeffs_capacity, int64_t *h_band_len);
+int adn_waverec_f32(adn_ctx *ctx, const float *d_coeffs, const int64_t *h_band_len, int wavelet,
+                    int level, int ext_mode, float *d_y, int64_t y_capacity, int64_t *h_n_out);
+
+/* --------------------------------------------------- STFT stages (batched)
+ * Signals are independent.  Signal s has len[s] frames of n_ch interleaved
+ * samples at d_x[d_off[s]]; multi-channel input is folded to mono with
+ * mean(axis=1) like the reference (src/noise_profile.py:45,
+ * src/spectral_subtract.py:76, src/wiener_filter.py:67).  d_off / d_len are
+ * device arrays of n_sig int64; max_len bounds len[s].  Every signal must have
+ * len >= n_fft (else ADN_ERR_SHORT is reported by the host wrapper, which knows
+ * the lengths; the kernels clamp).  n_fft must be a power of two in [64, 4096].
+ */
+
+/* Phase 1 (src/noise_profile.py:11-14, 57-63): |STFT| with a periodic Hann
+ * window of n_fft samples, P-th percentile over time per bin (linear
+ * interpolation), clamp to spectral_floor * max|Z|, box filter of freq_bins
+ * along frequency with edge replication.  d_baseline receives n_sig rows of
+ * n_fft/2+1 values: column 0 of the reference's time-constant baseline_mag.
+ * padded = the config's `center` flag, which the reference hands to scipy as
+ * `padded`. */
+int adn_noise_psd_f32(adn_ctx *ctx, const float *d_x, int64_t n_sig, const int64_t *d_off,
+                      const int64_t *d_len, int64_t max_len, int n_ch, int n_fft, int hop,
+                      int padded, double percentile, double spectral_floor, int freq_bins,
+                      int time_frames, float *d_baseline);
+int adn_noise_psd_f64(adn_ctx *ctx, const double *d_x, int64_t n_sig, const int64_t *d_off,
+                      const int64_t *d_len, int64_t max_len, int n_ch, int n_fft, int hop,
+                      int padded, double percentile, double spectral_floor, int freq_bins,
+                      int time_frames, double *d_baseline);
+
+/* Phase 2b (src/spectral_subtract.py:29-46, 79-109): STFT -> max(|Z|-alpha*n,
+ * beta*|Z|) -> box filter (smooth_freq x smooth_time, edge replicated) -> keep
+ * the phase -> ISTFT (drops n_fft/2 at both ends) -> clip to [-1, 1].
+ * d_noise: noise magnitude per bin, n_fft/2+1 values per signal at
+ * d_noise[s*noise_stride] (noise_stride = 0 shares one profile).
+ * Signal s writes adn_istft_out_samples(len[s]) samples at d_y[d_y_off[s]]. */
+int adn_spectral_subtract_f32(adn_ctx *ctx, const float *d_x, int64_t n_sig, const int64_t *d_off,
+                              const int64_t *d_len, int64_t max_len, int n_ch,
+                              const float *d_noise, int64_t noise_stride, int n_fft, int hop,
+                              double alpha, double beta, int smooth_time, int smooth_freq,
+                              float *d_y, const int64_t *d_y_off);
+int adn_spectral_subtract_f64(adn_ctx *ctx, const double *d_x, int64_t n_sig,
+                              const int64_t *d_off, const int64_t *d_len, int64_t max_len,
+                              int n_ch, const double *d_noise, int64_t noise_stride, int n_fft,
+                              int hop, double alpha, double beta, int smooth_time,
+                              int smooth_freq, double *d_y, const int64_t *d_y_off);
+
+/* Phase 2c (src/wiener_filter.py:12-39, 72-129): |Z|^2, 10th percentile over
+ * time per bin -> medfilt -> floor 1e-12; energy VAD (frame = int(sr*update_ms/
+ * 1000) samples, -40 dB, hangover 5) mapped onto STFT frames; VAD-masked mean
+ * (or the median when vad_guided == 0) -> medfilt -> max(., noise); gain =
+ * medfilt(clip(snr/(1+snr), 0, 1)); Z*gain -> ISTFT -> clip.  The reference's
+ * attack/release loop never executes, so the gain is constant in time.
+ * d_gain (n_sig rows of n_fft/2+1, may be NULL) receives the per-bin gain. */
+int adn_wiener_f32(adn_ctx *ctx, const float *d_x, int64_t n_sig, const int64_t *d_off,
+                   const int64_t *d_len, int64_t max_len, int n_ch, int sample_rate, int n_fft,
+                   int hop, double update_ms, int kernel_bins, int vad_guided, float *d_y,
+                   const int64_t *d_y_off, float *d_gain);
+int adn_wiener_f64(adn_ctx *ctx, const double *d_x, int64_t n_sig, const int64_t *d_off,
+                   const int64_t *d_len, int64_t max_len, int n_ch, int sample_rate, int n_fft,
+                   int hop, double update_ms, int kernel_bins, int vad_guided, double *d_y,
+                   const int64_t *d_y_off, double *d_gain);
+
+/* ------------------------------------------------- RMS-window profiler
+ * Per-window sum of squares over all channels divided by the window's row
+ * count, then sqrt (lib/windowBundle.py:67-74 as used by
+ * lib/noiseProfiler.py:151-162,191-206).  Window w covers rows
+ * [w*win, min((w+1)*win, n_rows)).  d_rms receives ceil(n_rows/win) doubles. */
+int adn_window_rms_f32(adn_ctx *ctx, const float *d_x, int64_t n_rows, int n_ch, int64_t win,
+                       double *d_rms);
+int adn_window_rms_f64(adn_ctx *ctx, const double *d_x, int64_t n_rows, int n_ch, int64_t win,
+                       double *d_rms);
+
+/* ------------------------------------------------ synthetic test signal
+ * Fills d_x with n samples of the bit-reproducible "noisy speech" generator
+ * used by the benchmark and the tests (splitmix64 hash -> Irwin-Hall noise +
+ * parabolic-sine harmonics; only exactly rounded IEEE operations, so the host
+ * generator produces the same bits).  No counterpart in the reference, which
+ * ships no test signal.  Sample i of the call is generator index start+i. */
+int adn_synth_noisy_speech_f64(adn_ctx *ctx, double *d_x, int64_t n, int64_t start,
+                               int sample_rate, uint64_t seed, uint64_t stream, double sigma,
+                               double speech_gain);
+int adn_synth_noisy_speech_f32(adn_ctx *ctx, float *d_x, int64_t n, int64_t start,
+                               int sample_rate, uint64_t seed, uint64_t stream, double sigma,
+                               double speech_gain);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ADN_H */
