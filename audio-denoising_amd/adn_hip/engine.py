@@ -175,7 +175,8 @@ class Engine:
         if offsets is not None:
             starts = np.asarray(offsets, dtype=np.int64)
         out = torch.empty((len(lens), n_fft // 2 + 1), dtype=x.dtype, device=x.device)
-        self._call("adn_noise_psd", x.dtype, _ptr(x), len(lens), _ptr(self._i64(starts)), _ptr(self._i64(lens)),
+        d_off, d_len = self._i64(starts), self._i64(lens)     # keep alive across the call
+        self._call("adn_noise_psd", x.dtype, _ptr(x), len(lens), _ptr(d_off), _ptr(d_len),
                    int(lens.max()), int(n_ch), int(n_fft), int(hop), int(bool(padded)), float(percentile),
                    float(spectral_floor), int(freq_bins), int(time_frames), _ptr(out))
         return out
@@ -196,10 +197,11 @@ class Engine:
         stride = 0 if noise_mag.dim() == 1 else noise_mag.shape[1]
         if noise_mag.shape[-1] != n_fft // 2 + 1:
             raise ValueError("noise profile must hold n_fft/2+1 bins (resize it on the host first)")
-        self._call("adn_spectral_subtract", x.dtype, _ptr(x), len(lens), _ptr(self._i64(starts)),
-                   _ptr(self._i64(lens)), int(lens.max()), int(n_ch), _ptr(noise_mag), int(stride), int(n_fft),
+        d_off, d_len, d_yoff = self._i64(starts), self._i64(lens), self._i64(out_offsets)
+        self._call("adn_spectral_subtract", x.dtype, _ptr(x), len(lens), _ptr(d_off),
+                   _ptr(d_len), int(lens.max()), int(n_ch), _ptr(noise_mag), int(stride), int(n_fft),
                    int(hop), float(alpha), float(beta), int(smooth_time), int(smooth_freq), _ptr(out),
-                   _ptr(self._i64(out_offsets)))
+                   _ptr(d_yoff))
         return out, out_lens
 
     def wiener(self, x, lens, sample_rate, n_ch=1, n_fft=2048, hop=512, update_ms=20, kernel_bins=5,
@@ -214,9 +216,10 @@ class Engine:
         if out is None:
             out = torch.empty(int(out_lens.sum()), dtype=x.dtype, device=x.device)
         gain = torch.empty((len(lens), n_fft // 2 + 1), dtype=x.dtype, device=x.device) if want_gain else None
-        self._call("adn_wiener", x.dtype, _ptr(x), len(lens), _ptr(self._i64(starts)), _ptr(self._i64(lens)),
+        d_off, d_len, d_yoff = self._i64(starts), self._i64(lens), self._i64(out_offsets)
+        self._call("adn_wiener", x.dtype, _ptr(x), len(lens), _ptr(d_off), _ptr(d_len),
                    int(lens.max()), int(n_ch), int(sample_rate), int(n_fft), int(hop), float(update_ms),
-                   int(kernel_bins), int(bool(vad_guided)), _ptr(out), _ptr(self._i64(out_offsets)), _ptr(gain))
+                   int(kernel_bins), int(bool(vad_guided)), _ptr(out), _ptr(d_yoff), _ptr(gain))
         return (out, out_lens, gain) if want_gain else (out, out_lens)
 
     # ------------------------------------------------------------------ misc

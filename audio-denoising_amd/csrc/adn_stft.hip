@@ -1,14 +1,910 @@
+// STFT stages: noise-PSD profile (phase 1), spectral subtraction (phase 2b) and
+// Wiener filtering (phase 2c), batched over independent signals.
+//
+// Reference behaviour restated here (not its code): scipy.signal.stft/istft as
+// called from src/noise_profile.py:11-14, src/spectral_subtract.py:82,108 and
+// src/wiener_filter.py:72,128 (periodic Hann window, boundary=None, padded=True on
+// the way in, boundary=True on the way out), and the per-bin arithmetic of those
+// three files.
+//
+// Execution model: ONE WAVEFRONT PER FRAME.  A frame of n_fft real samples is packed
+// into n_fft/2 complex points in the wave's private LDS buffer and transformed there
+// (radix-2^2 decimation in frequency, bit-reversed spectrum; the inverse is the
+// matching decimation-in-time network, so no reordering pass exists).  Waves of a
+// workgroup exchange only what the stage needs across frames: a row of clean
+// magnitudes per frame for the time smoothing, and the overlap-add accumulators.
+// A workgroup slides along one segment of one signal, so each sample is loaded once
+// per overlapping frame from L1/L2 and every spectrum stays on chip:
+// HBM sees the input once and the output once.
+#include <math.h>
+
+#include <vector>
+
 #include "adn_kernels.hpp"
+
 namespace adn {
-template <typename T>
-int noise_psd(Ctx *, const T *, int64_t, const int64_t *, const int64_t *, int64_t, int, int, int, int, double, double, int, int, T *) { set_error("not built yet"); return ADN_ERR_UNSUPPORTED; }
-template <typename T>
-int spectral_subtract(Ctx *, const T *, int64_t, const int64_t *, const int64_t *, int64_t, int, const T *, int64_t, int, int, double, double, int, int, T *, const int64_t *) { set_error("not built yet"); return ADN_ERR_UNSUPPORTED; }
-template <typename T>
-int wiener(Ctx *, const T *, int64_t, const int64_t *, const int64_t *, int64_t, int, int, int, int, double, int, int, T *, const int64_t *, T *) { set_error("not built yet"); return ADN_ERR_UNSUPPORTED; }
-#define I(T) \
-template int noise_psd<T>(Ctx *, const T *, int64_t, const int64_t *, const int64_t *, int64_t, int, int, int, int, double, double, int, int, T *); \
-template int spectral_subtract<T>(Ctx *, const T *, int64_t, const int64_t *, const int64_t *, int64_t, int, const T *, int64_t, int, int, double, double, int, int, T *, const int64_t *); \
-template int wiener<T>(Ctx *, const T *, int64_t, const int64_t *, const int64_t *, int64_t, int, int, int, int, double, int, int, T *, const int64_t *, T *);
-I(float) I(double)
+
+template <typename T> struct Vec2;
+template <> struct Vec2<float> { using type = float2; };
+template <> struct Vec2<double> { using type = double2; };
+
+template <typename V> __device__ __forceinline__ V cadd(V a, V b) { return V{a.x + b.x, a.y + b.y}; }
+template <typename V> __device__ __forceinline__ V csub(V a, V b) { return V{a.x - b.x, a.y - b.y}; }
+template <typename V> __device__ __forceinline__ V cmul(V a, V b) {
+    return V{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
 }
+template <typename V> __device__ __forceinline__ V cmulc(V a, V b) {   // a * conj(b)
+    return V{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y};
+}
+template <typename V> __device__ __forceinline__ V conj(V a) { return V{a.x, -a.y}; }
+
+// Orders LDS traffic between lanes of one wave (the hardware issues a wave's LDS
+// instructions in order; this only stops the compiler from moving them).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int brev(int k, int logn) { return (int)(__brev((unsigned)k) >> (32 - logn)); }
+
+// ---------------------------------------------------------------- tables
+// Device layout of one table set: window[N] | tw[Nc/2] | rtw[Nc/2+1]
+//   window[k] = 0.5 - 0.5 cos(2 pi k / N)            (scipy get_window('hann', N))
+//   tw[k]     = exp(-2 pi i k / Nc)                  (complex FFT of length Nc = N/2)
+//   rtw[k]    = exp(-2 pi i k / N)                   (real-FFT split / merge)
+template <typename T>
+struct Tables {
+    const T *window;
+    const typename Vec2<T>::type *tw;
+    const typename Vec2<T>::type *rtw;
+    double wsum;
+    int n_fft, logc;   // logc = log2(N/2)
+};
+
+template <typename T>
+static int get_tables(Ctx *c, int n_fft, Tables<T> *out) {
+    using V = typename Vec2<T>::type;
+    const int Nc = n_fft / 2;
+    int logc = 0;
+    while ((1 << logc) < Nc) ++logc;
+    StftTable *e = nullptr;
+    for (int i = 0; i < c->n_tables; ++i)
+        if (c->tables[i].n_fft == n_fft && c->tables[i].elem == (int)sizeof(T)) e = &c->tables[i];
+    if (!e) {
+        ADN_REQUIRE(c->n_tables < 16, "too many distinct (n_fft, precision) pairs on one context");
+        const size_t count = (size_t)n_fft + 2 * (Nc / 2) + 2 * (Nc / 2 + 1);
+        std::vector<T> h(count);
+        double wsum = 0.0;
+        for (int k = 0; k < n_fft; ++k) {
+            const double w = 0.5 - 0.5 * cos(2.0 * M_PI * (double)k / (double)n_fft);
+            wsum += w;
+            h[k] = (T)w;
+        }
+        T *tw = h.data() + n_fft;
+        for (int k = 0; k < Nc / 2; ++k) {
+            const double a = -2.0 * M_PI * (double)k / (double)Nc;
+            tw[2 * k] = (T)cos(a);
+            tw[2 * k + 1] = (T)sin(a);
+        }
+        T *rtw = tw + 2 * (Nc / 2);
+        for (int k = 0; k <= Nc / 2; ++k) {
+            const double a = -2.0 * M_PI * (double)k / (double)n_fft;
+            rtw[2 * k] = (T)cos(a);
+            rtw[2 * k + 1] = (T)sin(a);
+        }
+        void *dev = nullptr;
+        ADN_HIP(hipMalloc(&dev, count * sizeof(T)));
+        ADN_HIP(hipMemcpy(dev, h.data(), count * sizeof(T), hipMemcpyHostToDevice));
+        e = &c->tables[c->n_tables++];
+        e->n_fft = n_fft;
+        e->elem = (int)sizeof(T);
+        e->dev = dev;
+        e->wsum = wsum;
+    }
+    const T *base = static_cast<const T *>(e->dev);
+    out->window = base;
+    out->tw = reinterpret_cast<const V *>(base + n_fft);
+    out->rtw = reinterpret_cast<const V *>(base + n_fft + 2 * (Nc / 2));
+    out->wsum = e->wsum;
+    out->n_fft = n_fft;
+    out->logc = logc;
+    return ADN_OK;
+}
+
+// ------------------------------------------------------- wave-level FFTs
+// In-place complex FFT of Nc = 2^logn points in LDS, natural order in, bit-reversed
+// order out (decimation in frequency, two radix-2 stages fused per sweep).
+template <typename V>
+__device__ void fft_dif(V *buf, const V *__restrict__ tw, int logn, int lane) {
+    const int Nc = 1 << logn;
+    int s = logn;
+    while (s >= 2) {
+        const int m = 1 << (s - 1), hm = m >> 1, twstep = Nc >> s;
+        for (int q = lane; q < Nc / 4; q += 64) {
+            const int j = q & (hm - 1);
+            const int i0 = ((q >> (s - 2)) << s) + j;
+            const V a0 = buf[i0], a1 = buf[i0 + hm], a2 = buf[i0 + m], a3 = buf[i0 + m + hm];
+            const V w1 = tw[j * twstep], w2 = tw[2 * j * twstep];
+            const V b0 = cadd(a0, a2), b2 = cmul(csub(a0, a2), w1);
+            const V b1 = cadd(a1, a3), d = csub(a1, a3);
+            const V b3 = cmul(V{d.y, -d.x}, w1);                 // (a1 - a3) * (-i) * w1
+            buf[i0] = cadd(b0, b1);
+            buf[i0 + hm] = cmul(csub(b0, b1), w2);
+            buf[i0 + m] = cadd(b2, b3);
+            buf[i0 + m + hm] = cmul(csub(b2, b3), w2);
+        }
+        wave_sync();
+        s -= 2;
+    }
+    if (s == 1) {
+        for (int q = lane; q < Nc / 2; q += 64) {
+            const V a = buf[2 * q], b = buf[2 * q + 1];
+            buf[2 * q] = cadd(a, b);
+            buf[2 * q + 1] = csub(a, b);
+        }
+        wave_sync();
+    }
+}
+
+// Inverse network: bit-reversed order in, natural order out, conjugate twiddles, no scaling.
+template <typename V>
+__device__ void fft_dit_inv(V *buf, const V *__restrict__ tw, int logn, int lane) {
+    const int Nc = 1 << logn;
+    int s = 1;
+    if (logn & 1) {
+        for (int q = lane; q < Nc / 2; q += 64) {
+            const V a = buf[2 * q], b = buf[2 * q + 1];
+            buf[2 * q] = cadd(a, b);
+            buf[2 * q + 1] = csub(a, b);
+        }
+        wave_sync();
+        s = 2;
+    }
+    while (s + 1 <= logn) {
+        const int m = 1 << (s - 1);
+        for (int q = lane; q < Nc / 4; q += 64) {
+            const int j = q & (m - 1);
+            const int i0 = ((q >> (s - 1)) << (s + 1)) + j;
+            const V a0 = buf[i0], a1 = buf[i0 + m], a2 = buf[i0 + 2 * m], a3 = buf[i0 + 3 * m];
+            const V w1 = tw[j * (Nc >> s)], w2 = tw[j * (Nc >> (s + 1))];
+            const V t1 = cmulc(a1, w1), t3 = cmulc(a3, w1);
+            const V b0 = cadd(a0, t1), b1 = csub(a0, t1), b2 = cadd(a2, t3), b3 = csub(a2, t3);
+            const V u2 = cmulc(b2, w2), v3 = cmulc(b3, w2);
+            const V u3 = V{-v3.y, v3.x};                          // * (+i)
+            buf[i0] = cadd(b0, u2);
+            buf[i0 + 2 * m] = csub(b0, u2);
+            buf[i0 + m] = cadd(b1, u3);
+            buf[i0 + 3 * m] = csub(b1, u3);
+        }
+        wave_sync();
+        s += 2;
+    }
+}
+
+// ---------------------------------------------------------- signal access
+struct Signals {
+    const int64_t *off;
+    const int64_t *len;
+    int n_ch;
+    int n_fft, hop, padded;
+};
+
+__host__ __device__ inline int64_t stft_frames(int64_t n, int n_fft, int hop, int padded) {
+    if (n < n_fft) return 0;
+    int64_t nadd = 0;
+    if (padded) {
+        const int64_t r = (n - n_fft) % hop;
+        nadd = ((hop - r) % hop) % n_fft;
+    }
+    return 1 + (n + nadd - n_fft) / hop;
+}
+
+// Sample p of the zero-padded, mono-folded signal (mean over channels like np.mean(axis=1)).
+template <typename T>
+__device__ __forceinline__ T fold_sample(const T *__restrict__ x, int64_t p, int64_t n, int n_ch) {
+    if (p >= n) return (T)0;
+    if (n_ch == 1) return x[p];
+    T s = 0;
+    for (int c = 0; c < n_ch; ++c) s += x[p * n_ch + c];
+    return s / (T)n_ch;
+}
+
+// Load frame t (windowed) into the wave's buffer as Nc packed complex points and
+// transform it; on return buf holds X[k] * scale at brev(k) for k < Nc and X[Nc] at buf[Nc].
+template <typename T, typename V>
+__device__ void wave_rfft_frame(V *buf, const T *__restrict__ x, int64_t n, int n_ch, int64_t t,
+                                const Tables<T> &tb, int hop, T scale, int lane) {
+    const int Nc = tb.n_fft / 2, logc = tb.logc;
+    const int64_t p0 = t * hop;
+    if (n_ch == 1 && p0 + tb.n_fft <= n && (reinterpret_cast<uintptr_t>(x + p0) % sizeof(V)) == 0) {
+        const V *xv = reinterpret_cast<const V *>(x + p0);
+        const V *wv = reinterpret_cast<const V *>(tb.window);
+        for (int i = lane; i < Nc; i += 64) {
+            const V a = xv[i], w = wv[i];
+            buf[i] = V{a.x * w.x, a.y * w.y};
+        }
+    } else {
+        for (int i = lane; i < Nc; i += 64) {
+            const T a = fold_sample(x, p0 + 2 * i, n, n_ch), b = fold_sample(x, p0 + 2 * i + 1, n, n_ch);
+            buf[i] = V{a * tb.window[2 * i], b * tb.window[2 * i + 1]};
+        }
+    }
+    wave_sync();
+    fft_dif(buf, tb.tw, logc, lane);
+    // split the packed transform into the real-signal spectrum, in place (pairs k <-> Nc-k)
+    for (int k = lane; k <= Nc / 2; k += 64) {
+        if (k == 0) {
+            const V z = buf[0];
+            buf[0] = V{(z.x + z.y) * scale, (T)0};
+            buf[Nc] = V{(z.x - z.y) * scale, (T)0};
+        } else if (k == Nc / 2) {
+            const int pk = brev(k, logc);
+            const V z = buf[pk];
+            buf[pk] = V{z.x * scale, -z.y * scale};
+        } else {
+            const int pk = brev(k, logc), pm = brev(Nc - k, logc);
+            const V zk = buf[pk], zm = buf[pm], w = tb.rtw[k];
+            const V e = V{(zk.x + zm.x) * (T)0.5, (zk.y - zm.y) * (T)0.5};
+            const V o = V{(zk.y + zm.y) * (T)0.5, (zm.x - zk.x) * (T)0.5};   // -i/2 (zk - conj zm)
+            const V wo = cmul(w, o);
+            buf[pk] = V{(e.x + wo.x) * scale, (e.y + wo.y) * scale};
+            buf[pm] = V{(e.x - wo.x) * scale, -(e.y - wo.y) * scale};
+        }
+    }
+    wave_sync();
+}
+
+// Inverse of the split + inverse FFT: buf holds X'[k] as laid out above; on return the
+// buffer, read as 2*Nc reals, holds Nc * irfft(X') (natural order, unscaled).
+template <typename T, typename V>
+__device__ void wave_irfft_frame(V *buf, const Tables<T> &tb, int lane) {
+    const int Nc = tb.n_fft / 2, logc = tb.logc;
+    for (int k = lane; k <= Nc / 2; k += 64) {
+        if (k == 0) {
+            const T a = buf[0].x, b = buf[Nc].x;          // imaginary parts are ignored (irfft)
+            buf[0] = V{(a + b) * (T)0.5, (a - b) * (T)0.5};
+        } else if (k == Nc / 2) {
+            const int pk = brev(k, logc);
+            const V z = buf[pk];
+            buf[pk] = V{z.x, -z.y};
+        } else {
+            const int pk = brev(k, logc), pm = brev(Nc - k, logc);
+            const V xk = buf[pk], xm = buf[pm], w = tb.rtw[k];
+            const V e = V{(xk.x + xm.x) * (T)0.5, (xk.y - xm.y) * (T)0.5};
+            const V d = V{(xk.x - xm.x) * (T)0.5, (xk.y + xm.y) * (T)0.5};   // (xk - conj xm)/2
+            const V o = cmulc(d, w);                                       // conj(w) * d
+            buf[pk] = V{e.x - o.y, e.y + o.x};                             // e + i o
+            buf[pm] = V{e.x + o.y, -(e.y - o.x)};                          // conj(e - i o)
+        }
+    }
+    wave_sync();
+    fft_dit_inv(buf, tb.tw, logc, lane);
+}
+
+// ------------------------------------------- spectra rows (|X| or |X|^2), transposed
+// Workgroup: W waves, FT frames of one signal (FT a multiple of W).
+// Output S[(sig*F + k)*Tmax + t].
+
+template <typename T, int W>
+__global__ __launch_bounds__(W * 64) void k_stft_rows(const T *__restrict__ x, Signals sg,
+                                                      Tables<T> tb, int64_t groups_per_sig,
+                                                      int ROW_FT, int64_t Tmax, int power,
+                                                      T *__restrict__ S,
+                                                      unsigned long long *__restrict__ sig_max) {
+    using V = typename Vec2<T>::type;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int Nc = tb.n_fft / 2, F = Nc + 1, logc = tb.logc;
+    const int bstride = Nc + 2;
+    V *bufs = reinterpret_cast<V *>(smem);
+    T *tile = reinterpret_cast<T *>(bufs + (size_t)W * bstride);       // [F][ROW_FT + 1]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t sig = blockIdx.x / groups_per_sig, grp = blockIdx.x % groups_per_sig;
+    const int64_t n = sg.len[sig];
+    const int64_t Tn = stft_frames(n, tb.n_fft, sg.hop, sg.padded);
+    const int64_t t0 = grp * ROW_FT;
+    if (t0 >= Tn) return;
+    const T *xs = x + sg.off[sig];
+    V *buf = bufs + (size_t)wave * bstride;
+    const T scale = (T)(1.0 / tb.wsum);
+    T vmax = 0;
+    for (int it = 0; it < ROW_FT / W; ++it) {
+        const int ft = it * W + wave;
+        const int64_t t = t0 + ft;
+        if (t < Tn) {
+            wave_rfft_frame<T, V>(buf, xs, n, sg.n_ch, t, tb, sg.hop, scale, lane);
+            for (int k = lane; k <= Nc; k += 64) {
+                const V z = buf[k == Nc ? Nc : brev(k, logc)];
+                const T p2 = z.x * z.x + z.y * z.y;
+                const T v = power ? p2 : sqrt(p2);
+                tile[k * (ROW_FT + 1) + ft] = v;
+                vmax = v > vmax ? v : vmax;
+            }
+        }
+        wave_sync();
+    }
+    __syncthreads();
+    const int nft = (int)((Tn - t0) < ROW_FT ? (Tn - t0) : ROW_FT);
+    for (int idx = threadIdx.x; idx < F * ROW_FT; idx += W * 64) {
+        const int k = idx / ROW_FT, ft = idx % ROW_FT;
+        if (ft < nft) S[((size_t)sig * F + k) * Tmax + t0 + ft] = tile[k * (ROW_FT + 1) + ft];
+    }
+    if (sig_max != nullptr) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            const T o = __shfl_xor(vmax, d);
+            vmax = o > vmax ? o : vmax;
+        }
+        // non-negative IEEE values order like their bit patterns
+        if (lane == 0) atomicMax(&sig_max[sig], (unsigned long long)key_of((double)vmax));
+    }
+}
+
+// Per-signal frame counts as int64 (segment lengths for the row statistics).
+__global__ void k_frame_counts(Signals sg, int64_t n_sig, int64_t *Tn) {
+    const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (s < n_sig) Tn[s] = stft_frames(sg.len[s], sg.n_fft, sg.hop, sg.padded);
+}
+
+// ------------------------------------------------------ phase 1 epilogue
+// B[k] = max(P[k], floor * max|Z|) -> box mean over freq_bins (edge replicated) ->
+// box mean over time_frames of a time-constant row.
+template <typename T>
+__global__ __launch_bounds__(256) void k_profile_finish(const double *__restrict__ P,
+                                                        const unsigned long long *__restrict__ sig_max,
+                                                        int F, double floor_frac, int freq_bins,
+                                                        int time_frames, T *__restrict__ out) {
+    const int64_t sig = blockIdx.x;
+    const T mx = (T)val_of((uint64_t)sig_max[sig]);
+    const T lim = (T)floor_frac * mx;
+    const int left = freq_bins / 2, right = freq_bins - left - 1;
+    for (int k = threadIdx.x; k < F; k += 256) {
+        T acc = 0;
+        for (int o = -left; o <= right; ++o) {
+            int kk = k + o;
+            kk = kk < 0 ? 0 : (kk > F - 1 ? F - 1 : kk);
+            const T p = (T)P[sig * F + kk];
+            acc += p > lim ? p : lim;
+        }
+        const T v = acc / (T)freq_bins;
+        T tsum = 0;
+        for (int i = 0; i < time_frames; ++i) tsum += v;
+        out[sig * F + k] = time_frames > 0 ? tsum / (T)time_frames : v;
+    }
+}
+
+// -------------------------------------------------------------- VAD (2c)
+// speech[i] = 20 log10(sqrt(mean(frame^2) + 1e-12) + 1e-12) > -40   (src/wiener_filter.py:17-26)
+template <typename T>
+__global__ __launch_bounds__(256) void k_vad_energy(const T *__restrict__ x, Signals sg,
+                                                    int64_t n_sig, int64_t frame_len,
+                                                    int64_t nv_max,
+                                                    unsigned char *__restrict__ speech) {
+    const int64_t gid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int64_t sig = gid / nv_max, i = gid % nv_max;
+    if (sig >= n_sig) return;
+    const int64_t n = sg.len[sig];
+    int64_t nv = (n + frame_len - 1) / frame_len;
+    nv = nv < 1 ? 1 : nv;
+    if (i >= nv) return;
+    const T *xs = x + sg.off[sig];
+    const int64_t s = i * frame_len, e = (s + frame_len < n) ? s + frame_len : n;
+    double acc = 0.0;
+    for (int64_t p = s + lane; p < e; p += 64) {
+        const double v = (double)fold_sample(xs, p, n, sg.n_ch);
+        acc += v * v;
+    }
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane == 0) {
+        unsigned char f = 0;
+        if (e > s) {
+            const double rms = sqrt(acc / (double)(e - s) + 1e-12);
+            f = 20.0 * log10(rms + 1e-12) > -40.0;
+        }
+        speech[sig * nv_max + i] = f;
+    }
+}
+
+// Hangover (a frame is speech if any of frames i-5..i fired) and the map from STFT
+// frames to VAD frames: idx = min(int(t*hop/frame_len), n_vad-1)  (src/wiener_filter.py:27-33, 92-98).
+__global__ void k_vad_map(Signals sg, int64_t n_sig, int64_t frame_len, int64_t nv_max, int64_t Tmax,
+                          const unsigned char *__restrict__ speech, unsigned char *__restrict__ vad,
+                          int *__restrict__ count) {
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (gid >= n_sig * Tmax) return;
+    const int64_t sig = gid / Tmax, t = gid % Tmax;
+    const int64_t n = sg.len[sig];
+    const int64_t Tn = stft_frames(n, sg.n_fft, sg.hop, sg.padded);
+    if (t >= Tn) return;
+    int64_t nv = (n + frame_len - 1) / frame_len;
+    nv = nv < 1 ? 1 : nv;
+    int64_t idx = (t * sg.hop) / frame_len;
+    idx = idx > nv - 1 ? nv - 1 : idx;
+    unsigned char v = 0;
+    for (int64_t j = idx > 5 ? idx - 5 : 0; j <= idx; ++j) v |= speech[sig * nv_max + j];
+    vad[gid] = v;
+    if (v) atomicAdd(&count[sig], 1);
+}
+
+// speech_raw[row] = sum over VAD frames of S[row][t] / max(count, 1)  (src/wiener_filter.py:99-102)
+template <typename T>
+__global__ __launch_bounds__(256) void k_masked_mean(const T *__restrict__ S, int F, int64_t Tmax,
+                                                     int64_t n_rows, const int64_t *__restrict__ Tn,
+                                                     const unsigned char *__restrict__ vad,
+                                                     const int *__restrict__ count,
+                                                     double *__restrict__ out) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n_rows) return;
+    const int64_t sig = row / F;
+    const int64_t T_ = Tn[sig];
+    const T *r = S + row * Tmax;
+    const unsigned char *m = vad + sig * Tmax;
+    T acc = 0;
+    for (int64_t t = lane; t < T_; t += 64) acc += m[t] ? r[t] : (T)0;
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane == 0) {
+        const int c = count[sig];
+        out[row] = (double)(acc / (T)(c > 1 ? c : 1));
+    }
+}
+
+// gain[k] of the reference Wiener stage from the per-bin statistics (src/wiener_filter.py:84-86,
+// 108-115, 35-39): three zero-padded running medians around the SNR arithmetic.
+__device__ inline double medfilt_at(const double *v, int F, int k, int ksz) {
+    double w[31];
+    const int h = ksz / 2;
+    for (int i = 0; i < ksz; ++i) {
+        const int kk = k - h + i;
+        w[i] = (kk < 0 || kk >= F) ? 0.0 : v[kk];
+    }
+    for (int i = 1; i < ksz; ++i) {       // insertion sort (ksz <= 31)
+        const double key = w[i];
+        int j = i - 1;
+        while (j >= 0 && w[j] > key) {
+            w[j + 1] = w[j];
+            --j;
+        }
+        w[j + 1] = key;
+    }
+    return w[h];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_wiener_gain(const double *__restrict__ p10,
+                                                     const double *__restrict__ speech_raw, int F,
+                                                     int ksz, T *__restrict__ gain) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    double *a = reinterpret_cast<double *>(smem), *b = a + F, *g = b + F;
+    const int64_t sig = blockIdx.x;
+    for (int k = threadIdx.x; k < F; k += 256) {
+        a[k] = (double)(T)p10[sig * F + k];
+        b[k] = (double)(T)speech_raw[sig * F + k];
+    }
+    __syncthreads();
+    double nz[9], sp[9];
+    int cnt = 0;
+    for (int k = threadIdx.x; k < F; k += 256, ++cnt) {
+        nz[cnt] = (double)(T)fmax(medfilt_at(a, F, k, ksz), 1e-12);
+        sp[cnt] = medfilt_at(b, F, k, ksz);
+    }
+    __syncthreads();
+    cnt = 0;
+    for (int k = threadIdx.x; k < F; k += 256, ++cnt) {
+        const T noise = (T)nz[cnt];
+        T speech = (T)sp[cnt];
+        speech = speech > noise ? speech : noise;
+        const T snr = speech / (noise + (T)1e-12);
+        T gv = snr / ((T)1 + snr);
+        gv = gv < (T)0 ? (T)0 : (gv > (T)1 ? (T)1 : gv);
+        g[k] = (double)gv;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < F; k += 256) gain[sig * F + k] = (T)medfilt_at(g, F, k, ksz);
+}
+
+// ---------------------------------------- fused STFT -> modify -> ISTFT overlap-add
+enum { APPLY_SUBTRACT = 0, APPLY_GAIN = 1 };
+
+template <typename T>
+struct ApplyArgs {
+    const T *x;
+    T *y;
+    const int64_t *y_off;
+    Signals sg;
+    Tables<T> tb;
+    const T *row;        // noise magnitude (SUBTRACT) or gain (GAIN), F per signal
+    int64_t row_stride;  // elements between signals (0 = shared)
+    T alpha, beta;
+    int st, sf;          // box sizes along time / frequency
+    int64_t segs_per_sig;
+    int seg_hops;        // output hops per workgroup
+};
+
+template <typename T, int W, int MODE>
+__global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
+    using V = typename Vec2<T>::type;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const Tables<T> &tb = a.tb;
+    const int N = tb.n_fft, Nc = N / 2, F = Nc + 1, logc = tb.logc;
+    const int H = a.sg.hop, R = N / H;
+    const int RING = W + R;
+    const int bstride = Nc + 2, mstride = F + 1;
+    V *bufs = reinterpret_cast<V *>(smem);
+    T *mags = reinterpret_cast<T *>(bufs + (size_t)W * bstride);          // [W][mstride]
+    T *acc = mags + (MODE == APPLY_SUBTRACT ? (size_t)W * mstride : 0);   // [RING][H]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
+    const int64_t sig = blockIdx.x / a.segs_per_sig, seg = blockIdx.x % a.segs_per_sig;
+    const int64_t n = a.sg.len[sig];
+    const int64_t Tn = stft_frames(n, N, H, 1);
+    const int64_t out_hops = Tn - 1;                       // output length (Tn-1)*H
+    const int64_t g0 = seg * a.seg_hops;
+    if (Tn < 1 || g0 >= out_hops) return;
+    const int64_t g1 = (g0 + a.seg_hops < out_hops) ? g0 + a.seg_hops : out_hops;
+    // padded-coordinate hops [ph0, ph1) are produced by this workgroup
+    const int64_t ph0 = g0 + R / 2, ph1 = g1 + R / 2;
+    int64_t next_u = ph0 - R + 1;
+    next_u = next_u < 0 ? 0 : next_u;
+    const int64_t last_u = (ph1 - 1 < Tn - 1) ? ph1 - 1 : Tn - 1;
+    const int h = MODE == APPLY_SUBTRACT ? a.st / 2 : 0;
+    const int hr = MODE == APPLY_SUBTRACT ? a.st - h - 1 : 0;
+    const T *xs = a.x + a.sg.off[sig];
+    T *ys = a.y + a.y_off[sig];
+    const T *row = a.row + sig * a.row_stride;
+    const T fscale = (T)(1.0 / tb.wsum);
+    const T iscale = (T)(tb.wsum / (double)Nc);
+    V *buf = bufs + (size_t)wave * bstride;
+
+    for (int i = tid; i < RING * H; i += W * 64) acc[i] = 0;
+    __syncthreads();
+
+    while (next_u <= last_u) {
+        int64_t base = next_u - h;
+        base = base < 0 ? 0 : base;
+        const int64_t t = base + wave;
+        int64_t a_last = last_u + hr;
+        a_last = a_last > Tn - 1 ? Tn - 1 : a_last;
+        // ---- stage A: spectrum of frame t (and its clean magnitudes)
+        if (t <= a_last) {
+            wave_rfft_frame<T, V>(buf, xs, n, a.sg.n_ch, t, tb, H, fscale, lane);
+            if (MODE == APPLY_SUBTRACT) {
+                T *mrow = mags + (size_t)wave * mstride;
+                for (int k = lane; k <= Nc; k += 64) {
+                    const V z = buf[k == Nc ? Nc : brev(k, logc)];
+                    const T mag = sqrt(z.x * z.x + z.y * z.y);
+                    const T c1 = mag - a.alpha * row[k], c2 = a.beta * mag;
+                    mrow[k] = c1 > c2 ? c1 : c2;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- frames [ub, ue] of this group can be finalised
+        const int64_t ub = next_u;
+        int64_t ue = base + W - 1 - hr;
+        if (base + W - 1 >= Tn - 1) ue = Tn - 1;           // the right neighbours are clamped at Tn-1
+        ue = ue > last_u ? last_u : ue;
+        // ---- stage B: modify the spectrum, inverse transform
+        if (t >= ub && t <= ue) {
+            if (MODE == APPLY_SUBTRACT) {
+                const T inv_sf = (T)1 / (T)a.sf, inv_st = (T)1 / (T)a.st;
+                const int fl = a.sf / 2, fr = a.sf - fl - 1;
+                for (int k = lane; k <= Nc; k += 64) {
+                    T tsum = 0;
+                    for (int dt = -h; dt <= hr; ++dt) {
+                        int64_t tt = t + dt;
+                        tt = tt < 0 ? 0 : (tt > Tn - 1 ? Tn - 1 : tt);
+                        const T *mrow = mags + (size_t)(tt - base) * mstride;
+                        T fs = 0;
+                        for (int df = -fl; df <= fr; ++df) {
+                            int kk = k + df;
+                            kk = kk < 0 ? 0 : (kk > Nc ? Nc : kk);
+                            fs += mrow[kk];
+                        }
+                        tsum += fs * inv_sf;
+                    }
+                    const T sm = tsum * inv_st;
+                    const int pk = k == Nc ? Nc : brev(k, logc);
+                    const V z = buf[pk];
+                    const T mag = sqrt(z.x * z.x + z.y * z.y);
+                    // clean * exp(i*angle(Z)); angle(0) = 0
+                    buf[pk] = mag > (T)0 ? V{sm * (z.x / mag), sm * (z.y / mag)} : V{sm, (T)0};
+                }
+            } else {
+                for (int k = lane; k <= Nc; k += 64) {
+                    const int pk = k == Nc ? Nc : brev(k, logc);
+                    const V z = buf[pk];
+                    const T gk = row[k];
+                    buf[pk] = V{z.x * gk, z.y * gk};
+                }
+            }
+            wave_sync();
+            wave_irfft_frame<T, V>(buf, tb, lane);
+        }
+        __syncthreads();
+        // ---- overlap-add of frames [ub, ue] into padded hops [ub, ue + R - 1]
+        if (ue >= ub) {
+            const bool final_group = (ue == Tn - 1);
+            const int64_t nj = ue - ub + R;
+            for (int64_t idx = tid; idx < nj * H; idx += W * 64) {
+                const int64_t j = ub + idx / H;
+                const int i = (int)(idx % H);
+                T *slot = acc + (size_t)(j % RING) * H + i;
+                T v = *slot;
+                int64_t u_lo = j - R + 1;
+                u_lo = u_lo < ub ? ub : u_lo;
+                const int64_t u_hi = j < ue ? j : ue;
+                for (int64_t u = u_lo; u <= u_hi; ++u) {
+                    const int pos = (int)(j - u) * H + i;
+                    const T *fr = reinterpret_cast<const T *>(bufs + (size_t)(u - base) * bstride);
+                    v += fr[pos] * iscale * tb.window[pos];
+                }
+                if (j <= ue || final_group) {
+                    if (j >= ph0 && j < ph1) {
+                        T norm = 0;
+                        int64_t t_lo = j - R + 1;
+                        t_lo = t_lo < 0 ? 0 : t_lo;
+                        const int64_t t_hi = j < Tn - 1 ? j : Tn - 1;
+                        for (int64_t tt = t_lo; tt <= t_hi; ++tt) {
+                            const T w = tb.window[(int)(j - tt) * H + i];
+                            norm += w * w;
+                        }
+                        T o = v / (norm > (T)1e-10 ? norm : (T)1);
+                        o = o < (T)-1 ? (T)-1 : (o > (T)1 ? (T)1 : o);      // np.clip keeps NaN
+                        ys[(j - R / 2) * H + i] = o;
+                    }
+                    *slot = 0;
+                } else {
+                    *slot = v;
+                }
+            }
+        }
+        __syncthreads();
+        next_u = ue + 1;
+    }
+}
+
+// ---------------------------------------------------------- host drivers
+static int check_stft_args(int n_fft, int hop, int n_ch) {
+    ADN_REQUIRE(n_fft >= 64 && n_fft <= 4096 && (n_fft & (n_fft - 1)) == 0,
+                "n_fft must be a power of two in [64, 4096], got %d", n_fft);
+    ADN_REQUIRE(hop >= 1 && hop <= n_fft && n_fft % hop == 0, "hop must divide n_fft, got %d", hop);
+    ADN_REQUIRE(n_ch >= 1, "n_ch must be >= 1");
+    return ADN_OK;
+}
+
+template <typename T, int W>
+static int launch_rows(Ctx *c, const T *d_x, const Signals &sg, const Tables<T> &tb, int64_t n_sig,
+                       int ROW_FT, int64_t Tmax, int power, T *S, unsigned long long *sig_max) {
+    using V = typename Vec2<T>::type;
+    const int Nc = tb.n_fft / 2;
+    const size_t lds = (size_t)W * (Nc + 2) * sizeof(V) + (size_t)(Nc + 1) * (ROW_FT + 1) * sizeof(T);
+    const int64_t groups = ceil_div(Tmax, ROW_FT);
+    auto kern = k_stft_rows<T, W>;
+    ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(groups * n_sig)), dim3(W * 64), lds, c->stream, d_x, sg,
+                       tb, groups, ROW_FT, Tmax, power, S, sig_max);
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
+
+template <typename T>
+static int rows_dispatch(Ctx *c, const T *d_x, const Signals &sg, const Tables<T> &tb, int64_t n_sig,
+                         int64_t Tmax, int power, T *S, unsigned long long *sig_max) {
+    using V = typename Vec2<T>::type;
+    const int Nc = tb.n_fft / 2;
+    const size_t per_wave = (size_t)(Nc + 2) * sizeof(V);
+    // widest transposed tile (frames per workgroup) and most waves that fit the CU's LDS
+    for (int ft = 16; ft >= 2; ft >>= 1) {
+        const size_t tile = (size_t)(Nc + 1) * (ft + 1) * sizeof(T);
+        const size_t budget = 150 * 1024;
+        if (ft >= 8 && 8 * per_wave + tile <= budget) return launch_rows<T, 8>(c, d_x, sg, tb, n_sig, ft, Tmax, power, S, sig_max);
+        if (ft >= 4 && 4 * per_wave + tile <= budget) return launch_rows<T, 4>(c, d_x, sg, tb, n_sig, ft, Tmax, power, S, sig_max);
+        if (2 * per_wave + tile <= budget) return launch_rows<T, 2>(c, d_x, sg, tb, n_sig, ft, Tmax, power, S, sig_max);
+    }
+    set_error("n_fft=%d does not fit the 160 KB LDS of a CU", tb.n_fft);
+    return ADN_ERR_UNSUPPORTED;
+}
+
+template <typename T, int W, int MODE>
+static int launch_apply(Ctx *c, ApplyArgs<T> a, int64_t n_sig, int64_t Tmax) {
+    using V = typename Vec2<T>::type;
+    const int N = a.tb.n_fft, Nc = N / 2, R = N / a.sg.hop;
+    const size_t lds = (size_t)W * (Nc + 2) * sizeof(V) +
+                       (MODE == APPLY_SUBTRACT ? (size_t)W * (Nc + 2) * sizeof(T) : 0) +
+                       (size_t)(W + R) * a.sg.hop * sizeof(T);
+    const int64_t out_hops = Tmax - 1;
+    if (out_hops <= 0) return ADN_OK;
+    // enough workgroups to fill the chip several times, but long enough segments to
+    // amortise the (R - 1 + smoothing halo) warm-up frames of every segment
+    int64_t seg = ceil_div(n_sig * out_hops, (int64_t)c->num_cus * 8);
+    seg = seg < 16 ? 16 : (seg > 128 ? 128 : seg);
+    a.seg_hops = (int)seg;
+    a.segs_per_sig = ceil_div(out_hops, seg);
+    auto kern = k_stft_apply<T, W, MODE>;
+    ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.segs_per_sig * n_sig)), dim3(W * 64), lds, c->stream, a);
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
+
+template <typename T, int MODE>
+static int apply_dispatch(Ctx *c, const ApplyArgs<T> &a, int64_t n_sig, int64_t Tmax) {
+    using V = typename Vec2<T>::type;
+    const int N = a.tb.n_fft, Nc = N / 2, R = N / a.sg.hop;
+    auto need = [&](int W) {
+        return (size_t)W * (Nc + 2) * sizeof(V) + (MODE == APPLY_SUBTRACT ? (size_t)W * (Nc + 2) * sizeof(T) : 0) +
+               (size_t)(W + R) * a.sg.hop * sizeof(T);
+    };
+    const int min_w = MODE == APPLY_SUBTRACT ? a.st : 1;
+    if (need(8) <= 156 * 1024) return launch_apply<T, 8, MODE>(c, a, n_sig, Tmax);
+    if (need(4) <= 156 * 1024 && min_w <= 4) return launch_apply<T, 4, MODE>(c, a, n_sig, Tmax);
+    if (need(2) <= 156 * 1024 && min_w <= 2) return launch_apply<T, 2, MODE>(c, a, n_sig, Tmax);
+    set_error("n_fft=%d hop=%d smoothing=%d does not fit the 160 KB LDS of a CU", N, a.sg.hop, a.st);
+    return ADN_ERR_UNSUPPORTED;
+}
+
+template <typename T>
+int noise_psd(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int64_t *d_len,
+              int64_t max_len, int n_ch, int n_fft, int hop, int padded, double percentile,
+              double spectral_floor, int freq_bins, int time_frames, T *d_baseline) {
+    ADN_REQUIRE(c && d_x && d_off && d_len && d_baseline, "null pointer argument");
+    ADN_TRY(check_stft_args(n_fft, hop, n_ch));
+    ADN_REQUIRE(percentile >= 0.0 && percentile <= 100.0, "percentile must be in [0, 100]");
+    ADN_REQUIRE(freq_bins >= 1 && time_frames >= 1, "smoothing sizes must be >= 1");
+    if (n_sig <= 0) return ADN_OK;
+    if (max_len < n_fft) {
+        set_error("window is longer than input signal (n_fft=%d, longest signal=%lld)", n_fft, (long long)max_len);
+        return ADN_ERR_SHORT;
+    }
+    DeviceGuard dg(c->device);
+    ws_reset(c);
+    Tables<T> tb;
+    ADN_TRY(get_tables<T>(c, n_fft, &tb));
+    const int F = n_fft / 2 + 1;
+    const int64_t Tmax = stft_frames(max_len, n_fft, hop, padded);
+    const size_t nS = (size_t)n_sig * F * Tmax;
+    ADN_TRY(ws_reserve(c, ws_need(nS, sizeof(T)) + ws_need(n_sig, 8) * 2 + ws_need((size_t)n_sig * F, 8)));
+    T *S = ws_take<T>(c, nS);
+    int64_t *Tn = ws_take<int64_t>(c, n_sig);
+    unsigned long long *sig_max = ws_take<unsigned long long>(c, n_sig);
+    double *P = ws_take<double>(c, (size_t)n_sig * F);
+    Signals sg{d_off, d_len, n_ch, n_fft, hop, padded};
+    ADN_HIP(hipMemsetAsync(sig_max, 0, sizeof(unsigned long long) * n_sig, c->stream));
+    hipLaunchKernelGGL(k_frame_counts, dim3((unsigned)ceil_div(n_sig, 256)), dim3(256), 0, c->stream, sg, n_sig, Tn);
+    ADN_TRY(rows_dispatch<T>(c, d_x, sg, tb, n_sig, Tmax, 0, S, sig_max));
+    SelectArgs sa;
+    sa.n_seg = n_sig * F;
+    sa.seg_stride = Tmax;
+    sa.d_seg_len = Tn;
+    sa.len_div = F;
+    sa.max_len = Tmax;
+    sa.mode = SEL_PERCENTILE;
+    sa.q = percentile;
+    sa.d_out = P;
+    ADN_TRY(launch_select<T>(c, S, sa));
+    hipLaunchKernelGGL((k_profile_finish<T>), dim3((unsigned)n_sig), dim3(256), 0, c->stream, P, sig_max, F,
+                       spectral_floor, freq_bins, time_frames, d_baseline);
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
+
+template <typename T>
+int spectral_subtract(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off,
+                      const int64_t *d_len, int64_t max_len, int n_ch, const T *d_noise,
+                      int64_t noise_stride, int n_fft, int hop, double alpha, double beta,
+                      int smooth_time, int smooth_freq, T *d_y, const int64_t *d_y_off) {
+    ADN_REQUIRE(c && d_x && d_off && d_len && d_noise && d_y && d_y_off, "null pointer argument");
+    ADN_TRY(check_stft_args(n_fft, hop, n_ch));
+    ADN_REQUIRE(smooth_time >= 1 && smooth_time <= 7 && smooth_freq >= 1, "smoothing sizes out of range");
+    if (n_sig <= 0) return ADN_OK;
+    if (max_len < n_fft) {
+        set_error("window is longer than input signal (n_fft=%d, longest signal=%lld)", n_fft, (long long)max_len);
+        return ADN_ERR_SHORT;
+    }
+    DeviceGuard dg(c->device);
+    ws_reset(c);
+    Tables<T> tb;
+    ADN_TRY(get_tables<T>(c, n_fft, &tb));
+    ApplyArgs<T> a{};
+    a.x = d_x;
+    a.y = d_y;
+    a.y_off = d_y_off;
+    a.sg = Signals{d_off, d_len, n_ch, n_fft, hop, 1};
+    a.tb = tb;
+    a.row = d_noise;
+    a.row_stride = noise_stride;
+    a.alpha = (T)alpha;
+    a.beta = (T)beta;
+    a.st = smooth_time;
+    a.sf = smooth_freq;
+    return apply_dispatch<T, APPLY_SUBTRACT>(c, a, n_sig, stft_frames(max_len, n_fft, hop, 1));
+}
+
+template <typename T>
+int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int64_t *d_len,
+           int64_t max_len, int n_ch, int sample_rate, int n_fft, int hop, double update_ms,
+           int kernel_bins, int vad_guided, T *d_y, const int64_t *d_y_off, T *d_gain) {
+    ADN_REQUIRE(c && d_x && d_off && d_len && d_y && d_y_off, "null pointer argument");
+    ADN_TRY(check_stft_args(n_fft, hop, n_ch));
+    ADN_REQUIRE(kernel_bins >= 1 && kernel_bins <= 31 && (kernel_bins & 1), "median kernel must be odd and <= 31");
+    ADN_REQUIRE(n_fft / 2 + 1 <= 9 * 256, "n_fft too large for the gain kernel");
+    const int64_t frame_len = (int64_t)((double)sample_rate * update_ms / 1000.0);
+    ADN_REQUIRE(!vad_guided || frame_len >= 1, "VAD frame of %lld samples (sample_rate*update_ms/1000)", (long long)frame_len);
+    if (n_sig <= 0) return ADN_OK;
+    if (max_len < n_fft) {
+        set_error("window is longer than input signal (n_fft=%d, longest signal=%lld)", n_fft, (long long)max_len);
+        return ADN_ERR_SHORT;
+    }
+    DeviceGuard dg(c->device);
+    ws_reset(c);
+    Tables<T> tb;
+    ADN_TRY(get_tables<T>(c, n_fft, &tb));
+    const int F = n_fft / 2 + 1;
+    const int64_t Tmax = stft_frames(max_len, n_fft, hop, 1);
+    const int64_t nv_max = vad_guided ? (ceil_div(max_len, frame_len) < 1 ? 1 : ceil_div(max_len, frame_len)) : 1;
+    const size_t nS = (size_t)n_sig * F * Tmax, nR = (size_t)n_sig * F;
+    ADN_TRY(ws_reserve(c, ws_need(nS, sizeof(T)) + ws_need(n_sig, 8) + 2 * ws_need(nR, 8) + ws_need(nR, sizeof(T)) +
+                              ws_need((size_t)n_sig * nv_max, 1) + ws_need((size_t)n_sig * Tmax, 1) + ws_need(n_sig, 4)));
+    T *S = ws_take<T>(c, nS);
+    int64_t *Tn = ws_take<int64_t>(c, n_sig);
+    double *p10 = ws_take<double>(c, nR), *sraw = ws_take<double>(c, nR);
+    T *gain = d_gain ? d_gain : ws_take<T>(c, nR);
+    unsigned char *speech = ws_take<unsigned char>(c, (size_t)n_sig * nv_max);
+    unsigned char *vad = ws_take<unsigned char>(c, (size_t)n_sig * Tmax);
+    int *count = ws_take<int>(c, n_sig);
+    Signals sg{d_off, d_len, n_ch, n_fft, hop, 1};
+    hipLaunchKernelGGL(k_frame_counts, dim3((unsigned)ceil_div(n_sig, 256)), dim3(256), 0, c->stream, sg, n_sig, Tn);
+    ADN_TRY(rows_dispatch<T>(c, d_x, sg, tb, n_sig, Tmax, 1, S, nullptr));
+    SelectArgs sa;
+    sa.n_seg = n_sig * F;
+    sa.seg_stride = Tmax;
+    sa.d_seg_len = Tn;
+    sa.len_div = F;
+    sa.max_len = Tmax;
+    sa.mode = SEL_PERCENTILE;
+    sa.q = 10.0;
+    sa.d_out = p10;
+    ADN_TRY(launch_select<T>(c, S, sa));
+    if (vad_guided) {
+        ADN_HIP(hipMemsetAsync(count, 0, sizeof(int) * n_sig, c->stream));
+        hipLaunchKernelGGL((k_vad_energy<T>), dim3((unsigned)ceil_div(n_sig * nv_max, 4)), dim3(256), 0, c->stream,
+                           d_x, sg, n_sig, frame_len, nv_max, speech);
+        hipLaunchKernelGGL(k_vad_map, dim3((unsigned)ceil_div(n_sig * Tmax, 256)), dim3(256), 0, c->stream, sg, n_sig,
+                           frame_len, nv_max, Tmax, speech, vad, count);
+        hipLaunchKernelGGL((k_masked_mean<T>), dim3((unsigned)ceil_div(n_sig * F, 4)), dim3(256), 0, c->stream, S, F,
+                           Tmax, n_sig * F, Tn, vad, count, sraw);
+    } else {
+        sa.mode = SEL_MEDIAN;
+        sa.d_out = sraw;
+        ADN_TRY(launch_select<T>(c, S, sa));
+    }
+    hipLaunchKernelGGL((k_wiener_gain<T>), dim3((unsigned)n_sig), dim3(256), 3 * F * sizeof(double), c->stream, p10,
+                       sraw, F, kernel_bins, gain);
+    ADN_HIP(hipGetLastError());
+    ApplyArgs<T> a{};
+    a.x = d_x;
+    a.y = d_y;
+    a.y_off = d_y_off;
+    a.sg = sg;
+    a.tb = tb;
+    a.row = gain;
+    a.row_stride = F;
+    a.st = 1;
+    a.sf = 1;
+    return apply_dispatch<T, APPLY_GAIN>(c, a, n_sig, Tmax);
+}
+
+#define ADN_INST(T)                                                                                    \
+    template int noise_psd<T>(Ctx *, const T *, int64_t, const int64_t *, const int64_t *, int64_t,   \
+                              int, int, int, int, double, double, int, int, T *);                     \
+    template int spectral_subtract<T>(Ctx *, const T *, int64_t, const int64_t *, const int64_t *,    \
+                                      int64_t, int, const T *, int64_t, int, int, double, double,     \
+                                      int, int, T *, const int64_t *);                                \
+    template int wiener<T>(Ctx *, const T *, int64_t, const int64_t *, const int64_t *, int64_t, int, \
+                           int, int, int, double, int, int, T *, const int64_t *, T *);
+ADN_INST(float)
+ADN_INST(double)
+
+}  // namespace adn

@@ -1,0 +1,170 @@
+"""GPU parity of the STFT stages (phases 1, 2b, 2c) through the C ABI: HIP kernels vs the
+CPU oracle and vs golden vectors produced by running the reference stage scripts.
+fp64: 1e-9 max-abs; fp32: 1e-4 max-abs and >= 90 dB SNR of the difference."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import adn_oracle as orc
+import synth
+from gpu_util import engine, dev, host, check64, check32
+
+pytestmark = pytest.mark.gpu
+SR = 48000
+
+
+def _noise_mag(golden):
+    return golden("stages")["p1_baseline_col0"].astype(np.float64)
+
+
+def test_noise_profile_fp64_and_fp32(golden):
+    g = golden("stages")
+    e = engine()
+    noise = synth.white_noise(240000, 42, 1000)
+    base_or, T = orc.noise_profile(noise)
+    b64 = host(e.noise_psd(dev(noise), [noise.size]))[0]
+    check64(b64, base_or, 1e-12)
+    ref32 = g["p1_baseline_col0"]
+    assert np.max(np.abs(b64.astype(np.float32) - ref32) / ref32) <= 1.2e-7
+    b32 = host(e.noise_psd(dev(noise, torch.float32), [noise.size]))[0]
+    assert np.max(np.abs(b32 - base_or) / base_or) <= 2e-5
+    # a profile learnt with another window length (reference passes win_length as nperseg)
+    b1024 = host(e.noise_psd(dev(noise), [noise.size], n_fft=1024, hop=256))[0]
+    check64(b1024, orc.noise_profile(noise, n_fft=1024, hop=256, win_length=1024)[0], 1e-12)
+    assert np.max(np.abs(b1024.astype(np.float32) - g["p1_1024_baseline_col0"]) / g["p1_1024_baseline_col0"]) <= 1.2e-7
+    # stereo noise sample is folded to mono; unpadded variant (center: false)
+    st = np.stack([noise[:50000], synth.white_noise(50000, 42, 1002)], axis=1)
+    check64(host(e.noise_psd(dev(st).view(-1), [50000], n_ch=2))[0], orc.noise_profile(st)[0], 1e-12)
+    check64(host(e.noise_psd(dev(noise[:50000]), [50000], padded=False))[0],
+            orc.noise_profile(noise[:50000], padded=False)[0], 1e-12)
+
+
+def test_spectral_subtract_fp64_vs_reference(golden):
+    g = golden("stages")
+    e = engine()
+    nm = _noise_mag(golden)
+    x = synth.noisy_speech(60000, SR, 42, 20)
+    y, lens = e.spectral_subtract(dev(x), [x.size], dev(nm))
+    assert list(lens) == [g["p2b_y"].size]
+    check64(host(y), g["p2b_y"])
+    check64(host(y), orc.spectral_subtract(x, nm))
+
+
+def test_spectral_subtract_fp32(golden):
+    g = golden("stages")
+    e = engine()
+    nm = _noise_mag(golden)
+    x32 = synth.noisy_speech(60000, SR, 42, 20).astype(np.float32)
+    y, _ = e.spectral_subtract(dev(x32), [x32.size], dev(nm.astype(np.float32)))
+    want = orc.spectral_subtract(x32.astype(np.float64), nm)
+    print("2b fp32 (max-abs, SNR dB):", check32(host(y), want))
+    check32(host(y), g["p2b_y"])
+
+
+def test_spectral_subtract_edges_and_batch(golden):
+    g = golden("stages")
+    e = engine()
+    nm = _noise_mag(golden)
+    xs = [synth.noisy_speech(n, SR, 42, 22) for n in (2048, 2100, 5000)]
+    xs.append(synth.noisy_speech(60000, SR, 42, 20))
+    flat = np.concatenate(xs)
+    y, lens = e.spectral_subtract(dev(flat), [x.size for x in xs], dev(nm))
+    y = host(y)
+    assert list(lens) == [0, 512, 3072, g["p2b_y"].size]
+    pos = 0
+    for tag, ln in zip(("n2048", "n2100", "n5000"), lens[:3]):
+        check64(y[pos:pos + ln], g["p2b_%s_y" % tag])
+        pos += ln
+    check64(y[pos:], g["p2b_y"])
+    # stereo input is folded to mono
+    xst = synth.stereo_noisy_speech(30000, SR, 42, 23)
+    ys, _ = e.spectral_subtract(dev(xst).view(-1), [30000], dev(nm), n_ch=2)
+    check64(host(ys), g["p2b_stereo_y"])
+    # profile with another bin count: the host resizes it with np.interp like the reference
+    nm_r = orc.resize_noise(g["p1_1024_baseline_col0"].astype(np.float64), 1025)
+    yr, _ = e.spectral_subtract(dev(xs[2]), [5000], dev(nm_r))
+    check64(host(yr), g["p2b_resize_y"])
+    with pytest.raises(ValueError, match="window is longer than input signal"):
+        e.spectral_subtract(dev(xs[0][:1000]), [1000], dev(nm))
+    # other transform sizes against the oracle
+    for n_fft, hop in ((1024, 256), (512, 128), (2048, 1024), (256, 256), (64, 16)):
+        nmo = np.abs(np.sin(np.arange(n_fft // 2 + 1) * 0.01)) * 0.002 + 0.001
+        x = synth.noisy_speech(20000, SR, 42, 25)
+        yo, _ = e.spectral_subtract(dev(x), [x.size], dev(nmo), n_fft=n_fft, hop=hop)
+        check64(host(yo), orc.spectral_subtract(x, nmo, n_fft=n_fft, hop=hop))
+        yw, _ = e.wiener(dev(x), [x.size], SR, n_fft=n_fft, hop=hop)
+        check64(host(yw), orc.wiener(x, SR, n_fft=n_fft, hop=hop)[0])
+    # n_fft = 4096 exceeds the LDS budget in fp64 with time smoothing; fp32 covers it
+    nmo = np.abs(np.sin(np.arange(2049) * 0.01)) * 0.002 + 0.001
+    x32 = synth.noisy_speech(40000, SR, 42, 25).astype(np.float32)
+    yo, _ = e.spectral_subtract(dev(x32), [x32.size], dev(nmo.astype(np.float32)), n_fft=4096, hop=1024)
+    check32(host(yo), orc.spectral_subtract(x32.astype(np.float64), nmo, n_fft=4096, hop=1024))
+    from adn_hip import AdnError
+    with pytest.raises(AdnError, match="does not fit"):
+        e.spectral_subtract(dev(x32.astype(np.float64)), [x32.size], dev(nmo), n_fft=4096, hop=1024)
+
+
+def test_wiener_fp64_vs_reference(golden):
+    g = golden("stages")
+    e = engine()
+    x = synth.noisy_speech(60000, SR, 42, 20)
+    y2b = g["p2b_y"]
+    y, lens, gain = e.wiener(dev(y2b), [y2b.size], SR, want_gain=True)
+    check64(host(y), g["p2c_y"])
+    y_or, gain_or = orc.wiener(y2b, SR)
+    check64(host(gain)[0], gain_or, 1e-12)
+    check64(host(e.wiener(dev(x), [x.size], SR, vad_guided=False)[0]), g["p2c_novad_y"])
+    check64(host(e.wiener(dev(x), [x.size], SR, vad_guided=True)[0]), g["p2c_vad_x_y"])
+    xq = 1e-4 * synth.noisy_speech(30000, SR, 42, 21)
+    check64(host(e.wiener(dev(xq), [xq.size], SR)[0]), g["p2c_quiet_y"])
+
+
+def test_wiener_fp32(golden):
+    g = golden("stages")
+    e = engine()
+    x32 = synth.noisy_speech(60000, SR, 42, 20).astype(np.float32)
+    y, _ = e.wiener(dev(x32), [x32.size], SR)
+    want, _ = orc.wiener(x32.astype(np.float64), SR)
+    print("2c fp32 (max-abs, SNR dB):", check32(host(y), want))
+    check32(host(y), g["p2c_vad_x_y"])
+
+
+def test_core_chain_stereo_fp64(golden):
+    """phases 1 / 2 / 2b / 2c chained on device against the reference's core_pipeline run."""
+    g = golden("pipeline")
+    e = engine()
+    x = synth.stereo_noisy_speech(40000, SR, 42, 30)
+    noise = synth.white_noise(48000, 42, 1001)
+    base = e.noise_psd(dev(noise), [noise.size])
+    b32 = host(base)[0].astype(np.float32)
+    assert np.max(np.abs(b32 - g["baseline_col0"]) / g["baseline_col0"]) <= 1.2e-7
+    y2 = e.denoise_signal(dev(x), SR)
+    check64(host(y2), g["wavelet_y"])
+    # the stage file holds float32 baseline_mag; 2b reads it back as float32 values
+    y2b, l2b = e.spectral_subtract(y2.view(-1), [y2.shape[0]], dev(b32.astype(np.float64)), n_ch=2)
+    check64(host(y2b), g["ss_y"])
+    y2c, _ = e.wiener(y2b, [int(l2b[0])], SR)
+    check64(host(y2c), g["wiener_y"])
+
+
+def test_large_batch_properties():
+    """BASELINE-sized signals (60 s at 48 kHz): size-independent properties.  With a zero
+    noise profile and beta = 1 the 2b stage is the identity up to the box filter, so with
+    smoothing 1x1 the output equals the input shifted by n_fft/2 (scipy's istft trim); the
+    Wiener stage with unit gain is the same identity."""
+    e = engine()
+    n = 60 * SR
+    x = e.synth_noisy_speech(2 * n, SR, stream=50).view(2, n)
+    zero = torch.zeros(1025, dtype=torch.float64, device="cuda:0")
+    y, lens = e.spectral_subtract(x.reshape(-1), [n, n], zero, alpha=0.0, beta=1.0, smooth_time=1, smooth_freq=1)
+    L = int(lens[0])
+    assert L == (e.stft_num_frames(n, 2048, 512) - 1) * 512
+    for s in range(2):
+        ref = torch.clamp(x[s, 1024:1024 + L], -1.0, 1.0)
+        m = min(L, n - 1024)
+        assert float((y[s * L:s * L + m] - ref[:m]).abs().max()) <= 1e-12
+    # batch result == single-signal result, bit for bit (independent signals)
+    y1, _ = e.spectral_subtract(x[1].contiguous(), [n], zero, alpha=0.0, beta=1.0, smooth_time=1, smooth_freq=1)
+    assert torch.equal(y1, y[L:2 * L])
