@@ -41,6 +41,7 @@ class Engine:
         h = C.c_void_p()
         self._check(self.lib.adn_create(C.byref(h), self.device))
         self._h = h
+        self._desc_cache = {}
         self.use_current_stream()
 
     # ------------------------------------------------------------ plumbing
@@ -71,7 +72,17 @@ class Engine:
             pass
 
     def _i64(self, values):
-        return torch.as_tensor(np.asarray(values, dtype=np.int64), device=self.torch_device)
+        """int64 descriptor array on the device.  Descriptors repeat from call to call (same
+        batch layout), so uploads are cached: steady-state calls do no host-to-device copy."""
+        arr = np.ascontiguousarray(values, dtype=np.int64)
+        key = arr.tobytes()
+        t = self._desc_cache.get(key)
+        if t is None:
+            if len(self._desc_cache) >= 256:
+                self._desc_cache.clear()
+            t = torch.as_tensor(arr, device=self.torch_device)
+            self._desc_cache[key] = t
+        return t
 
     def _call(self, base, dtype, *args):
         fn = getattr(self.lib, base + _suffix(dtype))

@@ -667,7 +667,11 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
 static int check_stft_args(int n_fft, int hop, int n_ch) {
     ADN_REQUIRE(n_fft >= 64 && n_fft <= 4096 && (n_fft & (n_fft - 1)) == 0,
                 "n_fft must be a power of two in [64, 4096], got %d", n_fft);
-    ADN_REQUIRE(hop >= 1 && hop <= n_fft && n_fft % hop == 0, "hop must divide n_fft, got %d", hop);
+    // the overlap-add tiles assume that the n_fft/2 samples istft trims are whole hops
+    if (hop < 1 || hop > n_fft / 2 || (n_fft / 2) % hop != 0) {
+        set_error("hop must divide n_fft/2 (got n_fft=%d hop=%d)", n_fft, hop);
+        return ADN_ERR_UNSUPPORTED;
+    }
     ADN_REQUIRE(n_ch >= 1, "n_ch must be >= 1");
     return ADN_OK;
 }

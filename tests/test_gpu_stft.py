@@ -89,7 +89,7 @@ def test_spectral_subtract_edges_and_batch(golden):
     with pytest.raises(ValueError, match="window is longer than input signal"):
         e.spectral_subtract(dev(xs[0][:1000]), [1000], dev(nm))
     # other transform sizes against the oracle
-    for n_fft, hop in ((1024, 256), (512, 128), (2048, 1024), (256, 256), (64, 16)):
+    for n_fft, hop in ((1024, 256), (512, 128), (2048, 1024), (256, 32), (64, 16)):
         nmo = np.abs(np.sin(np.arange(n_fft // 2 + 1) * 0.01)) * 0.002 + 0.001
         x = synth.noisy_speech(20000, SR, 42, 25)
         yo, _ = e.spectral_subtract(dev(x), [x.size], dev(nmo), n_fft=n_fft, hop=hop)
@@ -104,6 +104,8 @@ def test_spectral_subtract_edges_and_batch(golden):
     from adn_hip import AdnError
     with pytest.raises(AdnError, match="does not fit"):
         e.spectral_subtract(dev(x32.astype(np.float64)), [x32.size], dev(nmo), n_fft=4096, hop=1024)
+    with pytest.raises(AdnError, match="hop must divide n_fft/2"):
+        e.spectral_subtract(dev(x32), [x32.size], dev(nmo[:129].astype(np.float32)), n_fft=256, hop=256)
 
 
 def test_wiener_fp64_vs_reference(golden):
