@@ -24,6 +24,7 @@ _PLAIN = {
     "adn_destroy": (_i, [_vp]),
     "adn_set_stream": (_i, [_vp, _vp]),
     "adn_synchronize": (_i, [_vp]),
+    "adn_set_option": (_i, [_vp, _i, _i]),
     "adn_workspace_bytes": (_i64, [_vp]),
     "adn_wavelet_out_frames": (_i64, [_i64]),
     "adn_denoise_block_frames": (_i64, [_i64, _i64]),

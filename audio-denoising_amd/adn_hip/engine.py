@@ -54,6 +54,10 @@ class Engine:
         s = torch.cuda.current_stream(self.torch_device).cuda_stream
         self._check(self.lib.adn_set_stream(self._h, C.c_void_p(s)))
 
+    def force_generic(self, on=True):
+        """Test hook: run the shape-generic kernels instead of the specialised ones."""
+        self._check(self.lib.adn_set_option(self._h, 1, int(bool(on))))
+
     def synchronize(self):
         self._check(self.lib.adn_synchronize(self._h))
 

@@ -83,6 +83,13 @@ int adn_set_stream(adn_ctx *c, void *s) {
     return ADN_OK;
 }
 
+int adn_set_option(adn_ctx *c, int option, int value) {
+    ADN_REQUIRE(c != nullptr, "ctx is null");
+    ADN_REQUIRE(option == ADN_OPT_FORCE_GENERIC, "unknown option %d", option);
+    c->force_generic = value != 0;
+    return ADN_OK;
+}
+
 int adn_synchronize(adn_ctx *c) {
     ADN_REQUIRE(c != nullptr, "ctx is null");
     adn::DeviceGuard dg(c->device);

@@ -54,6 +54,7 @@ struct Ctx {
     size_t ws_bytes = 0;
     size_t ws_used = 0;        // bump pointer, reset per call
     int num_cus = 256;
+    bool force_generic = false;   // test hook: skip the specialised kernels
 };
 
 // Ensure the workspace holds at least `bytes`; growing synchronises the stream

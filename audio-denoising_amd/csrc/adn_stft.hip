@@ -20,48 +20,18 @@
 
 #include <vector>
 
+#include <type_traits>
+
 #include "adn_kernels.hpp"
+#include "adn_stft_shared.hpp"
 
 namespace adn {
-
-template <typename T> struct Vec2;
-template <> struct Vec2<float> { using type = float2; };
-template <> struct Vec2<double> { using type = double2; };
-
-template <typename V> __device__ __forceinline__ V cadd(V a, V b) { return V{a.x + b.x, a.y + b.y}; }
-template <typename V> __device__ __forceinline__ V csub(V a, V b) { return V{a.x - b.x, a.y - b.y}; }
-template <typename V> __device__ __forceinline__ V cmul(V a, V b) {
-    return V{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
-}
-template <typename V> __device__ __forceinline__ V cmulc(V a, V b) {   // a * conj(b)
-    return V{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y};
-}
-template <typename V> __device__ __forceinline__ V conj(V a) { return V{a.x, -a.y}; }
-
-// Orders LDS traffic between lanes of one wave (the hardware issues a wave's LDS
-// instructions in order; this only stops the compiler from moving them).
-__device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ int brev(int k, int logn) { return (int)(__brev((unsigned)k) >> (32 - logn)); }
 
 // ---------------------------------------------------------------- tables
 // Device layout of one table set: window[N] | tw[Nc/2] | rtw[Nc/2+1]
 //   window[k] = 0.5 - 0.5 cos(2 pi k / N)            (scipy get_window('hann', N))
 //   tw[k]     = exp(-2 pi i k / Nc)                  (complex FFT of length Nc = N/2)
 //   rtw[k]    = exp(-2 pi i k / N)                   (real-FFT split / merge)
-template <typename T>
-struct Tables {
-    const T *window;
-    const typename Vec2<T>::type *tw;
-    const typename Vec2<T>::type *rtw;
-    double wsum;
-    int n_fft, logc;   // logc = log2(N/2)
-};
-
 template <typename T>
 static int get_tables(Ctx *c, int n_fft, Tables<T> *out) {
     using V = typename Vec2<T>::type;
@@ -180,34 +150,6 @@ __device__ void fft_dit_inv(V *buf, const V *__restrict__ tw, int logn, int lane
         wave_sync();
         s += 2;
     }
-}
-
-// ---------------------------------------------------------- signal access
-struct Signals {
-    const int64_t *off;
-    const int64_t *len;
-    int n_ch;
-    int n_fft, hop, padded;
-};
-
-__host__ __device__ inline int64_t stft_frames(int64_t n, int n_fft, int hop, int padded) {
-    if (n < n_fft) return 0;
-    int64_t nadd = 0;
-    if (padded) {
-        const int64_t r = (n - n_fft) % hop;
-        nadd = ((hop - r) % hop) % n_fft;
-    }
-    return 1 + (n + nadd - n_fft) / hop;
-}
-
-// Sample p of the zero-padded, mono-folded signal (mean over channels like np.mean(axis=1)).
-template <typename T>
-__device__ __forceinline__ T fold_sample(const T *__restrict__ x, int64_t p, int64_t n, int n_ch) {
-    if (p >= n) return (T)0;
-    if (n_ch == 1) return x[p];
-    T s = 0;
-    for (int c = 0; c < n_ch; ++c) s += x[p * n_ch + c];
-    return s / (T)n_ch;
 }
 
 // Load frame t (windowed) into the wave's buffer as Nc packed complex points and
@@ -408,8 +350,7 @@ __global__ __launch_bounds__(256) void k_vad_energy(const T *__restrict__ x, Sig
 // Hangover (a frame is speech if any of frames i-5..i fired) and the map from STFT
 // frames to VAD frames: idx = min(int(t*hop/frame_len), n_vad-1)  (src/wiener_filter.py:27-33, 92-98).
 __global__ void k_vad_map(Signals sg, int64_t n_sig, int64_t frame_len, int64_t nv_max, int64_t Tmax,
-                          const unsigned char *__restrict__ speech, unsigned char *__restrict__ vad,
-                          int *__restrict__ count) {
+                          const unsigned char *__restrict__ speech, unsigned char *__restrict__ vad) {
     const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (gid >= n_sig * Tmax) return;
     const int64_t sig = gid / Tmax, t = gid % Tmax;
@@ -423,7 +364,6 @@ __global__ void k_vad_map(Signals sg, int64_t n_sig, int64_t frame_len, int64_t 
     unsigned char v = 0;
     for (int64_t j = idx > 5 ? idx - 5 : 0; j <= idx; ++j) v |= speech[sig * nv_max + j];
     vad[gid] = v;
-    if (v) atomicAdd(&count[sig], 1);
 }
 
 // speech_raw[row] = sum over VAD frames of S[row][t] / max(count, 1)  (src/wiener_filter.py:99-102)
@@ -431,7 +371,6 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_masked_mean(const T *__restrict__ S, int F, int64_t Tmax,
                                                      int64_t n_rows, const int64_t *__restrict__ Tn,
                                                      const unsigned char *__restrict__ vad,
-                                                     const int *__restrict__ count,
                                                      double *__restrict__ out) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -441,12 +380,17 @@ __global__ __launch_bounds__(256) void k_masked_mean(const T *__restrict__ S, in
     const T *r = S + row * Tmax;
     const unsigned char *m = vad + sig * Tmax;
     T acc = 0;
-    for (int64_t t = lane; t < T_; t += 64) acc += m[t] ? r[t] : (T)0;
-    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-    if (lane == 0) {
-        const int c = count[sig];
-        out[row] = (double)(acc / (T)(c > 1 ? c : 1));
+    int c = 0;                     // frames flagged as speech (every row recounts: no atomics)
+    for (int64_t t = lane; t < T_; t += 64) {
+        const bool on = m[t] != 0;
+        acc += on ? r[t] : (T)0;
+        c += on;
     }
+    for (int d = 32; d >= 1; d >>= 1) {
+        acc += __shfl_xor(acc, d);
+        c += __shfl_xor(c, d);
+    }
+    if (lane == 0) out[row] = (double)(acc / (T)(c > 1 ? c : 1));
 }
 
 // gain[k] of the reference Wiener stage from the per-bin statistics (src/wiener_filter.py:84-86,
@@ -504,23 +448,6 @@ __global__ __launch_bounds__(256) void k_wiener_gain(const double *__restrict__ 
 }
 
 // ---------------------------------------- fused STFT -> modify -> ISTFT overlap-add
-enum { APPLY_SUBTRACT = 0, APPLY_GAIN = 1 };
-
-template <typename T>
-struct ApplyArgs {
-    const T *x;
-    T *y;
-    const int64_t *y_off;
-    Signals sg;
-    Tables<T> tb;
-    const T *row;        // noise magnitude (SUBTRACT) or gain (GAIN), F per signal
-    int64_t row_stride;  // elements between signals (0 = shared)
-    T alpha, beta;
-    int st, sf;          // box sizes along time / frequency
-    int64_t segs_per_sig;
-    int seg_hops;        // output hops per workgroup
-};
-
 template <typename T, int W, int MODE>
 __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
     using V = typename Vec2<T>::type;
@@ -697,6 +624,9 @@ static int rows_dispatch(Ctx *c, const T *d_x, const Signals &sg, const Tables<T
                          int64_t Tmax, int power, T *S, unsigned long long *sig_max) {
     using V = typename Vec2<T>::type;
     const int Nc = tb.n_fft / 2;
+    if constexpr (std::is_same<T, float>::value) {
+        if (tb.n_fft == 2048 && !c->force_generic) return rows_fast(c, d_x, sg, tb, n_sig, Tmax, power, S, sig_max);
+    }
     const size_t per_wave = (size_t)(Nc + 2) * sizeof(V);
     // widest transposed tile (frames per workgroup) and most waves that fit the CU's LDS
     for (int ft = 16; ft >= 2; ft >>= 1) {
@@ -742,6 +672,9 @@ static int apply_dispatch(Ctx *c, const ApplyArgs<T> &a, int64_t n_sig, int64_t 
                (size_t)(W + R) * a.sg.hop * sizeof(T);
     };
     const int min_w = MODE == APPLY_SUBTRACT ? a.st : 1;
+    if constexpr (std::is_same<T, float>::value) {
+        if (!c->force_generic && apply_fast_ok(N, a.sg.hop, a.st)) return apply_fast<MODE>(c, a, n_sig, Tmax);
+    }
     if (need(8) <= 156 * 1024) return launch_apply<T, 8, MODE>(c, a, n_sig, Tmax);
     if (need(4) <= 156 * 1024 && min_w <= 4) return launch_apply<T, 4, MODE>(c, a, n_sig, Tmax);
     if (need(2) <= 156 * 1024 && min_w <= 2) return launch_apply<T, 2, MODE>(c, a, n_sig, Tmax);
@@ -857,7 +790,6 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     T *gain = d_gain ? d_gain : ws_take<T>(c, nR);
     unsigned char *speech = ws_take<unsigned char>(c, (size_t)n_sig * nv_max);
     unsigned char *vad = ws_take<unsigned char>(c, (size_t)n_sig * Tmax);
-    int *count = ws_take<int>(c, n_sig);
     Signals sg{d_off, d_len, n_ch, n_fft, hop, 1};
     hipLaunchKernelGGL(k_frame_counts, dim3((unsigned)ceil_div(n_sig, 256)), dim3(256), 0, c->stream, sg, n_sig, Tn);
     ADN_TRY(rows_dispatch<T>(c, d_x, sg, tb, n_sig, Tmax, 1, S, nullptr));
@@ -872,13 +804,12 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     sa.d_out = p10;
     ADN_TRY(launch_select<T>(c, S, sa));
     if (vad_guided) {
-        ADN_HIP(hipMemsetAsync(count, 0, sizeof(int) * n_sig, c->stream));
         hipLaunchKernelGGL((k_vad_energy<T>), dim3((unsigned)ceil_div(n_sig * nv_max, 4)), dim3(256), 0, c->stream,
                            d_x, sg, n_sig, frame_len, nv_max, speech);
         hipLaunchKernelGGL(k_vad_map, dim3((unsigned)ceil_div(n_sig * Tmax, 256)), dim3(256), 0, c->stream, sg, n_sig,
-                           frame_len, nv_max, Tmax, speech, vad, count);
+                           frame_len, nv_max, Tmax, speech, vad);
         hipLaunchKernelGGL((k_masked_mean<T>), dim3((unsigned)ceil_div(n_sig * F, 4)), dim3(256), 0, c->stream, S, F,
-                           Tmax, n_sig * F, Tn, vad, count, sraw);
+                           Tmax, n_sig * F, Tn, vad, sraw);
     } else {
         sa.mode = SEL_MEDIAN;
         sa.d_out = sraw;

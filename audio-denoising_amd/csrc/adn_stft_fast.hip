@@ -1,0 +1,579 @@
+// Register-resident STFT kernels for the headline shape: binary32, n_fft = 2048.
+//
+// One wavefront owns one frame.  The 2048 real samples are packed into 1024 complex
+// points, 16 per lane, and transformed as 16 x 16 x 4:
+//   pass 1  16-point DFT in registers over the stride-64 samples of a lane,
+//           twiddle by W1024^(lane*k1), transpose through LDS (padded rows: conflict free);
+//   pass 2  16-point DFT in registers, twiddle by W64^(b*c);
+//   pass 3  radix-4 across the four lanes of a quad with DPP moves (no LDS).
+// The inverse transform is the same network with conjugated twiddles.  Spectra are
+// exchanged between lanes only through a natural-order LDS image with 8 entries of
+// padding per 256 (all accesses of a wave hit distinct banks), twiddles and the
+// real-FFT split factors live in registers for the lifetime of the workgroup.
+#include "adn_kernels.hpp"
+#include "adn_stft_shared.hpp"
+
+namespace adn {
+namespace fast {
+
+typedef float2 c2;
+static constexpr int NC = 1024;     // complex points per frame
+static constexpr int RS = 68;       // exchange row stride (float2): 64 + 4 keeps quads on distinct banks
+static constexpr int WBUF = 1088;   // float2 per wave buffer: 16 * RS >= padded natural image + 1
+static constexpr int MROW = 1032;   // floats per magnitude row (1025 used)
+
+__device__ __forceinline__ int nat(int k) { return k + ((k >> 8) << 3); }        // float2 index
+__device__ __forceinline__ int natf(int s) { return s + ((s >> 9) << 4); }       // float index of sample s
+
+__device__ __forceinline__ c2 operator+(c2 a, c2 b) { return c2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ c2 operator-(c2 a, c2 b) { return c2{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ c2 mul(c2 a, c2 b) { return c2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ c2 mulc(c2 a, c2 b) { return c2{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }
+
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ c2 dpp2(c2 v) { return c2{dpp<CTRL>(v.x), dpp<CTRL>(v.y)}; }
+
+// v * W16^M (forward) or its conjugate (inverse)
+template <int M, bool INV>
+__device__ __forceinline__ c2 mul_w16(c2 v) {
+    constexpr float C1 = 0.9238795325112867f, S1 = 0.3826834323650898f, R = 0.7071067811865476f;
+    if (M == 0) return v;
+    if (M == 4) return INV ? c2{-v.y, v.x} : c2{v.y, -v.x};
+    if (M == 2) return INV ? c2{(v.x - v.y) * R, (v.x + v.y) * R} : c2{(v.x + v.y) * R, (v.y - v.x) * R};
+    if (M == 6) return INV ? c2{-(v.x + v.y) * R, (v.x - v.y) * R} : c2{(v.y - v.x) * R, -(v.x + v.y) * R};
+    // generic: W = (c, -s) forward
+    constexpr float c = M == 1 ? C1 : (M == 3 ? S1 : -C1);     // M in {1, 3, 9}
+    constexpr float s = M == 1 ? S1 : (M == 3 ? C1 : -S1);
+    return INV ? c2{v.x * c - v.y * s, v.y * c + v.x * s} : c2{v.x * c + v.y * s, v.y * c - v.x * s};
+}
+
+template <bool INV>
+__device__ __forceinline__ void bfly4(c2 &a0, c2 &a1, c2 &a2, c2 &a3) {
+    const c2 s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+    const c2 id = INV ? c2{-d13.y, d13.x} : c2{d13.y, -d13.x};
+    a0 = s02 + s13;
+    a1 = d02 + id;
+    a2 = s02 - s13;
+    a3 = d02 - id;
+}
+
+// 16-point DFT in registers.  Input r[n]; output X[k] at r[P16(k)].
+__host__ __device__ constexpr int P16(int k) { return 4 * (k & 3) + (k >> 2); }
+
+template <bool INV>
+__device__ __forceinline__ void dft16(c2 (&r)[16]) {
+    bfly4<INV>(r[0], r[4], r[8], r[12]);
+    bfly4<INV>(r[1], r[5], r[9], r[13]);
+    bfly4<INV>(r[2], r[6], r[10], r[14]);
+    bfly4<INV>(r[3], r[7], r[11], r[15]);
+    // position 4*k1 + n2 holds y[n2][k1]; twiddle by W16^(n2*k1)
+    r[5] = mul_w16<1, INV>(r[5]);
+    r[6] = mul_w16<2, INV>(r[6]);
+    r[7] = mul_w16<3, INV>(r[7]);
+    r[9] = mul_w16<2, INV>(r[9]);
+    r[10] = mul_w16<4, INV>(r[10]);
+    r[11] = mul_w16<6, INV>(r[11]);
+    r[13] = mul_w16<3, INV>(r[13]);
+    r[14] = mul_w16<6, INV>(r[14]);
+    r[15] = mul_w16<9, INV>(r[15]);
+    bfly4<INV>(r[0], r[1], r[2], r[3]);
+    bfly4<INV>(r[4], r[5], r[6], r[7]);
+    bfly4<INV>(r[8], r[9], r[10], r[11]);
+    bfly4<INV>(r[12], r[13], r[14], r[15]);
+}
+
+// Twiddles of the two inter-pass multiplications, one copy per workgroup in LDS:
+//   t1[(k1-1)*64 + lane] = W1024^(lane*k1),  t2[(c-1)*4 + b] = W64^(b*c),  k1, c = 1..15
+static constexpr int TWTAB = 15 * 64 + 15 * 4;     // float2 entries
+struct LaneTw {
+    const c2 *t1;   // + lane
+    const c2 *t2;   // + (lane & 3)
+};
+
+// tw holds exp(-2 pi i k / 1024) for k < 512
+__device__ __forceinline__ c2 w1024(const c2 *__restrict__ tw, int k) {
+    k &= 1023;
+    const c2 v = tw[k & 511];
+    return (k & 512) ? c2{-v.x, -v.y} : v;
+}
+
+// Cooperative fill by the whole workgroup; the caller synchronises before first use.
+__device__ __forceinline__ void fill_tw_table(c2 *tab, const c2 *__restrict__ tw, int tid, int nthreads) {
+    for (int i = tid; i < 15 * 64; i += nthreads) tab[i] = w1024(tw, (i & 63) * ((i >> 6) + 1));
+    for (int i = tid; i < 15 * 4; i += nthreads) tab[15 * 64 + i] = w1024(tw, 16 * (i & 3) * ((i >> 2) + 1));
+}
+
+__device__ __forceinline__ LaneTw lane_tw(const c2 *tab, int lane) {
+    return LaneTw{tab + lane, tab + 15 * 64 + (lane & 3)};
+}
+
+// In: lane l, r[j] = x[l + 64 j].  Out: lane l = 4*k1 + b, r[c] = X[k1 + 16 c + 256 * brev2(b)].
+template <bool INV>
+__device__ __forceinline__ void wave_fft1024(c2 (&r)[16], c2 *E, const LaneTw &t, int lane) {
+    dft16<INV>(r);
+#pragma unroll
+    for (int k1 = 0; k1 < 16; ++k1) {
+        c2 v = r[P16(k1)];
+        if (k1) v = INV ? mulc(v, t.t1[(k1 - 1) * 64]) : mul(v, t.t1[(k1 - 1) * 64]);
+        E[k1 * RS + lane] = v;
+    }
+    wave_sync();
+    const int row = (lane >> 2) * RS + (lane & 3);
+#pragma unroll
+    for (int a = 0; a < 16; ++a) r[a] = E[row + 4 * a];
+    wave_sync();
+    dft16<INV>(r);
+    const int b = lane & 3;
+    c2 u[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        c2 v = r[P16(c)];
+        if (c) v = INV ? mulc(v, t.t2[(c - 1) * 4]) : mul(v, t.t2[(c - 1) * 4]);
+        // radix-4 across the quad, step 1 (partner = lane ^ 2)
+        const c2 p = dpp2<0x4E>(v);
+        c2 s = (b < 2) ? v + p : p - v;
+        if (b == 3) s = INV ? c2{-s.y, s.x} : c2{s.y, -s.x};
+        u[c] = s;
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const c2 p = dpp2<0xB1>(u[c]);                 // partner = lane ^ 1
+        r[c] = (b & 1) ? p - u[c] : u[c] + p;
+    }
+}
+
+// Natural-order (padded) store of the layout produced by wave_fft1024.
+__device__ __forceinline__ void store_natural(const c2 (&r)[16], c2 *buf, int lane) {
+    const int b = lane & 3, d = ((b >> 1) | ((b & 1) << 1));
+    const int base = (lane >> 2) + 264 * d;           // k1 + nat(256 d)
+#pragma unroll
+    for (int c = 0; c < 16; ++c) buf[base + 16 * c] = r[c];
+}
+
+// Frame at padded sample p0 of a signal -> layout-A registers (windowed, packed):
+// r[j] = z[lane + 64 j].  Frames that are wholly inside the signal and suitably aligned
+// are loaded straight into registers; any other frame (zero-padded tail, odd alignment,
+// more than two channels) is staged through the wave's LDS buffer by a rolled loop.
+__device__ __noinline__ void stage_frame_generic(c2 *buf, const float *__restrict__ xs, int64_t n, int n_ch,
+                                                 int64_t p0, const float *__restrict__ window, int lane) {
+#pragma unroll 1
+    for (int i = lane; i < NC; i += 64) {
+        const float a = fold_sample(xs, p0 + 2 * i, n, n_ch), b = fold_sample(xs, p0 + 2 * i + 1, n, n_ch);
+        buf[nat(i)] = c2{a * window[2 * i], b * window[2 * i + 1]};
+    }
+}
+
+__device__ __forceinline__ void load_frame(c2 (&r)[16], c2 *buf, const float *__restrict__ xs, int64_t n,
+                                           int n_ch, int64_t p0, const float *__restrict__ window, int lane) {
+    const c2 *wv = reinterpret_cast<const c2 *>(window);
+    if (p0 + 2048 <= n && n_ch == 1 && (reinterpret_cast<uintptr_t>(xs + p0) & 7) == 0) {
+        const c2 *xv = reinterpret_cast<const c2 *>(xs + p0) + lane;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const c2 a = xv[64 * j], w = wv[lane + 64 * j];
+            r[j] = c2{a.x * w.x, a.y * w.y};
+        }
+    } else if (p0 + 2048 <= n && n_ch == 2 && (reinterpret_cast<uintptr_t>(xs + 2 * p0) & 15) == 0) {
+        const float4 *xv = reinterpret_cast<const float4 *>(xs + 2 * p0) + lane;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const float4 a = xv[64 * j];
+            const c2 w = wv[lane + 64 * j];
+            r[j] = c2{(a.x + a.y) / 2.0f * w.x, (a.z + a.w) / 2.0f * w.y};
+        }
+    } else {
+        stage_frame_generic(buf, xs, n, n_ch, p0, window, lane);
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) r[j] = buf[nat(lane + 64 * j)];
+        wave_sync();
+    }
+}
+
+// Real-signal spectrum of the packed transform held in buf (natural, padded).
+// lo[j] = X[k], hi[j] = X[1024-k] for k = lane + 64 j (lane 0, j 0: X[0] and X[1024]); mid = X[512].
+struct Spec {
+    c2 lo[8], hi[8], mid;
+};
+
+__device__ __forceinline__ void split_spectrum(Spec &s, const c2 *buf, const c2 (&rtw)[8], float scale, int lane) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = lane + 64 * j;
+        const c2 zk = buf[nat(k)];
+        const c2 zm = buf[nat((1024 - k) & 1023)];
+        const c2 e = c2{(zk.x + zm.x) * 0.5f, (zk.y - zm.y) * 0.5f};
+        const c2 o = c2{(zk.y + zm.y) * 0.5f, (zm.x - zk.x) * 0.5f};
+        const c2 wo = mul(rtw[j], o);
+        s.lo[j] = c2{(e.x + wo.x) * scale, (e.y + wo.y) * scale};
+        s.hi[j] = c2{(e.x - wo.x) * scale, -(e.y - wo.y) * scale};
+        if (j == 0 && lane == 0) {
+            s.lo[0] = c2{(zk.x + zk.y) * scale, 0.0f};
+            s.hi[0] = c2{(zk.x - zk.y) * scale, 0.0f};
+        }
+    }
+    const c2 z = buf[nat(512)];
+    s.mid = c2{z.x * scale, -z.y * scale};
+}
+
+// Inverse of split_spectrum: writes the packed spectrum Z' (natural, padded) into buf.
+__device__ __forceinline__ void merge_spectrum(const Spec &s, c2 *buf, const c2 (&rtw)[8], int lane) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = lane + 64 * j;
+        const c2 xk = s.lo[j], xm = s.hi[j];
+        if (j == 0 && lane == 0) {
+            buf[0] = c2{(xk.x + xm.x) * 0.5f, (xk.x - xm.x) * 0.5f};
+        } else {
+            const c2 e = c2{(xk.x + xm.x) * 0.5f, (xk.y - xm.y) * 0.5f};
+            const c2 d = c2{(xk.x - xm.x) * 0.5f, (xk.y + xm.y) * 0.5f};
+            const c2 o = mulc(d, rtw[j]);
+            buf[nat(k)] = c2{e.x - o.y, e.y + o.x};
+            buf[nat(1024 - k)] = c2{e.x + o.y, -(e.y - o.x)};
+        }
+    }
+    if (lane == 0) buf[nat(512)] = c2{s.mid.x, -s.mid.y};
+}
+
+__device__ __forceinline__ void load_rtw(c2 (&rtw)[8], const c2 *__restrict__ tab, int lane) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rtw[j] = tab[lane + 64 * j];
+}
+
+// --------------------------------------------------- transposed power / magnitude rows
+template <int W>
+__global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ x, Signals sg,
+                                                      Tables<float> tb, int64_t groups_per_sig,
+                                                      int FT, int64_t Tmax, int power,
+                                                      float *__restrict__ S,
+                                                      unsigned long long *__restrict__ sig_max) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    c2 *bufs = reinterpret_cast<c2 *>(smem);
+    float *tile = reinterpret_cast<float *>(bufs + (size_t)W * WBUF);      // [1025][FT + 1]
+    c2 *twtab = reinterpret_cast<c2 *>(tile + 1025 * (FT + 1) + ((1025 * (FT + 1)) & 1));
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t sig = blockIdx.x / groups_per_sig, grp = blockIdx.x % groups_per_sig;
+    const int64_t n = sg.len[sig];
+    const int64_t Tn = stft_frames(n, 2048, sg.hop, sg.padded);
+    const int64_t t0 = grp * FT;
+    if (t0 >= Tn) return;
+    const float *xs = x + sg.off[sig];
+    c2 *buf = bufs + (size_t)wave * WBUF;
+    fill_tw_table(twtab, tb.tw, threadIdx.x, W * 64);
+    __syncthreads();
+    const LaneTw tw = lane_tw(twtab, lane);
+    c2 rtw[8];
+    load_rtw(rtw, tb.rtw, lane);
+    const float scale = (float)(1.0 / tb.wsum);
+    const int ts = FT + 1;
+    float vmax = 0.0f;
+    for (int it = 0; it < FT / W; ++it) {
+        const int ft = it * W + wave;
+        const int64_t t = t0 + ft;
+        if (t < Tn) {
+            c2 r[16];
+            load_frame(r, buf, xs, n, sg.n_ch, t * sg.hop, tb.window, lane);
+            wave_fft1024<false>(r, buf, tw, lane);
+            store_natural(r, buf, lane);
+            wave_sync();
+            Spec s;
+            split_spectrum(s, buf, rtw, scale, lane);
+            wave_sync();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = lane + 64 * j;
+                float p0 = s.lo[j].x * s.lo[j].x + s.lo[j].y * s.lo[j].y;
+                float p1 = s.hi[j].x * s.hi[j].x + s.hi[j].y * s.hi[j].y;
+                if (!power) {
+                    p0 = sqrtf(p0);
+                    p1 = sqrtf(p1);
+                }
+                tile[k * ts + ft] = p0;
+                tile[(1024 - k) * ts + ft] = p1;
+                vmax = fmaxf(vmax, fmaxf(p0, p1));
+            }
+            if (lane == 0) {
+                float pm = s.mid.x * s.mid.x + s.mid.y * s.mid.y;
+                if (!power) pm = sqrtf(pm);
+                tile[512 * ts + ft] = pm;
+                vmax = fmaxf(vmax, pm);
+            }
+        }
+    }
+    __syncthreads();
+    const int nft = (int)((Tn - t0) < FT ? (Tn - t0) : FT);
+    for (int idx = threadIdx.x; idx < 1025 * FT; idx += W * 64) {
+        const int k = idx / FT, ft = idx % FT;
+        if (ft < nft) S[((size_t)sig * 1025 + k) * Tmax + t0 + ft] = tile[k * ts + ft];
+    }
+    if (sig_max != nullptr) {
+        for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
+        if (lane == 0) atomicMax(&sig_max[sig], (unsigned long long)key_of((double)vmax));
+    }
+}
+
+// ------------------------------------ fused STFT -> modify -> ISTFT overlap-add
+// Workgroup = W waves sliding along one segment of one signal.  Per iteration the waves
+// transform W consecutive frames (stage A), the frames whose time-smoothing neighbours are
+// all present are modified and inverse-transformed (stage B), and all threads overlap-add
+// the finished frames into a ring of hop accumulators, emitting the hops that are complete.
+template <int W, int MODE>
+__global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const Tables<float> &tb = a.tb;
+    const int H = a.sg.hop, R = 2048 / H, LOGH = 31 - __clz(H);
+    const int RING = W + R;
+    c2 *bufs = reinterpret_cast<c2 *>(smem);
+    float *mags = reinterpret_cast<float *>(bufs + (size_t)W * WBUF);                 // [W][MROW]
+    float *acc = mags + (MODE == APPLY_SUBTRACT ? (size_t)W * MROW : 0);              // [RING][H]
+    float *wsq = acc + (size_t)RING * H;                                              // [H] full-overlap norm
+    c2 *twtab = reinterpret_cast<c2 *>(wsq + H);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
+    const int64_t sig = blockIdx.x / a.segs_per_sig, seg = blockIdx.x % a.segs_per_sig;
+    const int64_t n = a.sg.len[sig];
+    const int64_t Tn64 = stft_frames(n, 2048, H, 1);
+    const int64_t g0 = seg * a.seg_hops;
+    if (Tn64 < 1 || g0 >= Tn64 - 1) return;
+    // frame / hop indices of one signal fit 32 bits (the host checks max_len)
+    const int Tn = (int)Tn64;
+    const int out_hops = Tn - 1;
+    const int g1 = ((int)g0 + a.seg_hops < out_hops) ? (int)g0 + a.seg_hops : out_hops;
+    const int ph0 = (int)g0 + R / 2, ph1 = g1 + R / 2;
+    int next_u = ph0 - R + 1;
+    next_u = next_u < 0 ? 0 : next_u;
+    const int last_u = (ph1 - 1 < Tn - 1) ? ph1 - 1 : Tn - 1;
+    const int h = MODE == APPLY_SUBTRACT ? a.st / 2 : 0;
+    const int hr = MODE == APPLY_SUBTRACT ? a.st - h - 1 : 0;
+    const float *xs = a.x + a.sg.off[sig];
+    float *ys = a.y + a.y_off[sig];
+    const float *row = a.row + sig * a.row_stride;
+    const float fscale = (float)(1.0 / tb.wsum);
+    const float iscale = (float)(tb.wsum / 1024.0);
+    c2 *buf = bufs + wave * WBUF;
+    float *bufr = reinterpret_cast<float *>(buf);
+
+    fill_tw_table(twtab, tb.tw, tid, W * 64);
+    const LaneTw tw = lane_tw(twtab, lane);
+    c2 rtw[8];
+    load_rtw(rtw, tb.rtw, lane);
+
+    for (int i = tid; i < RING * H; i += W * 64) acc[i] = 0.0f;
+    for (int i = tid; i < H; i += W * 64) {
+        float s = 0.0f;
+        for (int r = 0; r < R; ++r) {
+            const float w = tb.window[i + r * H];
+            s += w * w;
+        }
+        wsq[i] = s;
+    }
+    __syncthreads();
+
+#pragma unroll 1
+    while (next_u <= last_u) {
+        int base = next_u - h;
+        base = base < 0 ? 0 : base;
+        const int t = base + wave;
+        int a_last = last_u + hr;
+        a_last = a_last > Tn - 1 ? Tn - 1 : a_last;
+        Spec s;
+        // ---- stage A: spectrum of frame t
+        if (t <= a_last) {
+            c2 r[16];
+            load_frame(r, buf, xs, n, a.sg.n_ch, (int64_t)t * H, tb.window, lane);
+            wave_fft1024<false>(r, buf, tw, lane);
+            store_natural(r, buf, lane);
+            wave_sync();
+            split_spectrum(s, buf, rtw, fscale, lane);
+            wave_sync();
+            if (MODE == APPLY_SUBTRACT) {
+                // clean magnitudes of the lane's bins -> raw row in the wave's own buffer
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = lane + 64 * j;
+                    const float m0 = sqrtf(s.lo[j].x * s.lo[j].x + s.lo[j].y * s.lo[j].y);
+                    const float m1 = sqrtf(s.hi[j].x * s.hi[j].x + s.hi[j].y * s.hi[j].y);
+                    bufr[k] = fmaxf(m0 - a.alpha * row[k], a.beta * m0);
+                    bufr[1024 - k] = fmaxf(m1 - a.alpha * row[1024 - k], a.beta * m1);
+                }
+                if (lane == 0) {
+                    const float mm = sqrtf(s.mid.x * s.mid.x + s.mid.y * s.mid.y);
+                    bufr[512] = fmaxf(mm - a.alpha * row[512], a.beta * mm);
+                }
+                wave_sync();
+                // box mean along frequency (edge replicated) -> shared row of this frame
+                float *mrow = mags + wave * MROW;
+                const int fl = a.sf / 2, fr = a.sf - fl - 1;
+                const float inv_sf = 1.0f / (float)a.sf;
+#pragma unroll 1
+                for (int k = lane; k <= 1024; k += 64) {
+                    float fs = 0.0f;
+                    for (int df = -fl; df <= fr; ++df) {
+                        int kk = k + df;
+                        kk = kk < 0 ? 0 : (kk > 1024 ? 1024 : kk);
+                        fs += bufr[kk];
+                    }
+                    mrow[k] = fs * inv_sf;
+                }
+            }
+        }
+        if (MODE == APPLY_SUBTRACT) __syncthreads();
+        const int ub = next_u;
+        int ue = base + W - 1 - hr;
+        if (base + W - 1 >= Tn - 1) ue = Tn - 1;
+        ue = ue > last_u ? last_u : ue;
+        // ---- stage B: modify, inverse transform, window
+        if (t >= ub && t <= ue) {
+            if (MODE == APPLY_SUBTRACT) {
+                const float inv_st = 1.0f / (float)a.st;
+                // rows of the time neighbours (clamped at the signal's first / last frame)
+                int r_lo = t - h, r_hi = t + hr;
+                auto smooth = [&](int k) {
+                    float ts = 0.0f;
+                    for (int tt = r_lo; tt <= r_hi; ++tt) {
+                        const int tc = tt < 0 ? 0 : (tt > Tn - 1 ? Tn - 1 : tt);
+                        ts += mags[(tc - base) * MROW + k];
+                    }
+                    return ts * inv_st;
+                };
+                auto rephase = [&](c2 z, float sm) {
+                    const float mag = sqrtf(z.x * z.x + z.y * z.y);
+                    return mag > 0.0f ? c2{sm * (z.x / mag), sm * (z.y / mag)} : c2{sm, 0.0f};
+                };
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = lane + 64 * j;
+                    s.lo[j] = rephase(s.lo[j], smooth(k));
+                    s.hi[j] = rephase(s.hi[j], smooth(1024 - k));
+                }
+                s.mid = rephase(s.mid, smooth(512));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = lane + 64 * j;
+                    const float g0v = row[k], g1v = row[1024 - k];
+                    s.lo[j] = c2{s.lo[j].x * g0v, s.lo[j].y * g0v};
+                    s.hi[j] = c2{s.hi[j].x * g1v, s.hi[j].y * g1v};
+                }
+                const float gm = row[512];
+                s.mid = c2{s.mid.x * gm, s.mid.y * gm};
+            }
+            merge_spectrum(s, buf, rtw, lane);
+            wave_sync();
+            c2 r[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) r[j] = buf[nat(lane + 64 * j)];
+            wave_sync();
+            wave_fft1024<true>(r, buf, tw, lane);
+            // time samples of this lane: n = k1 + 16 c + 256 d; apply the synthesis window
+            const int b = lane & 3, d = ((b >> 1) | ((b & 1) << 1));
+            const c2 *wv = reinterpret_cast<const c2 *>(tb.window) + (lane >> 2) + 256 * d;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const c2 w = wv[16 * c];
+                r[c] = c2{r[c].x * iscale * w.x, r[c].y * iscale * w.y};
+            }
+            store_natural(r, buf, lane);
+        }
+        __syncthreads();
+        // ---- overlap-add of frames [ub, ue] into padded hops [ub, ue + R - 1]
+        if (ue >= ub) {
+            const bool final_group = (ue == Tn - 1);
+            const int nj = ue - ub + R;                     // hops touched
+            const int i = tid & (H - 1);                    // sample inside the hop: fixed per thread
+            const int jstep = (W * 64) >> LOGH;             // hops advanced per sweep of the block
+            const float *fbase = reinterpret_cast<const float *>(bufs);
+#pragma unroll 1
+            for (int jj = tid >> LOGH; jj < nj; jj += jstep) {
+                const int j = ub + jj;
+                int slot_i = j % RING;
+                float *slot = acc + slot_i * H + i;
+                float v = *slot;
+                int u_lo = j - R + 1;
+                u_lo = u_lo < ub ? ub : u_lo;
+                const int u_hi = j < ue ? j : ue;
+                for (int u = u_lo; u <= u_hi; ++u)
+                    v += fbase[(u - base) * (2 * WBUF) + natf(((j - u) << LOGH) + i)];
+                if (j <= ue || final_group) {
+                    if (j >= ph0 && j < ph1) {
+                        float norm;
+                        if (j - R + 1 >= 0 && j <= Tn - 1) {
+                            norm = wsq[i];
+                        } else {
+                            norm = 0.0f;
+                            int t_lo = j - R + 1;
+                            t_lo = t_lo < 0 ? 0 : t_lo;
+                            const int t_hi = j < Tn - 1 ? j : Tn - 1;
+                            for (int tt = t_lo; tt <= t_hi; ++tt) {
+                                const float w = tb.window[((j - tt) << LOGH) + i];
+                                norm += w * w;
+                            }
+                        }
+                        float o = v / (norm > 1e-10f ? norm : 1.0f);
+                        o = o < -1.0f ? -1.0f : (o > 1.0f ? 1.0f : o);
+                        ys[(int64_t)(j - R / 2) * H + i] = o;
+                    }
+                    *slot = 0.0f;
+                } else {
+                    *slot = v;
+                }
+            }
+        }
+        __syncthreads();
+        next_u = ue + 1;
+    }
+}
+
+static size_t apply_lds(int W, int mode, int hop) {
+    const int R = 2048 / hop;
+    return (size_t)W * WBUF * sizeof(c2) + (mode == APPLY_SUBTRACT ? (size_t)W * MROW * sizeof(float) : 0) +
+           (size_t)(W + R) * hop * sizeof(float) + (size_t)hop * sizeof(float) + (size_t)TWTAB * sizeof(c2);
+}
+
+}  // namespace fast
+
+template <int MODE>
+int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
+    constexpr int W = 8;
+    const int64_t out_hops = Tmax - 1;
+    if (out_hops <= 0) return ADN_OK;
+    const size_t lds = fast::apply_lds(W, MODE, a.sg.hop);
+    int64_t seg = ceil_div(n_sig * out_hops, (int64_t)c->num_cus * 8);
+    seg = seg < 24 ? 24 : (seg > 96 ? 96 : seg);
+    a.seg_hops = (int)seg;
+    a.segs_per_sig = ceil_div(out_hops, seg);
+    auto kern = fast::k_apply_fast<W, MODE>;
+    ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.segs_per_sig * n_sig)), dim3(W * 64), lds, c->stream, a);
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
+
+bool apply_fast_ok(int n_fft, int hop, int st) {
+    if (n_fft != 2048 || hop < 64 || st > 7) return false;
+    return fast::apply_lds(8, APPLY_SUBTRACT, hop) <= 156 * 1024;
+}
+
+int rows_fast(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &tb, int64_t n_sig,
+              int64_t Tmax, int power, float *S, unsigned long long *sig_max) {
+    constexpr int W = 8, FT = 16;
+    const size_t lds = (size_t)W * fast::WBUF * sizeof(float2) + (size_t)(1025 * (FT + 1) + 1) * sizeof(float) +
+                       (size_t)fast::TWTAB * sizeof(float2);
+    const int64_t groups = ceil_div(Tmax, FT);
+    auto kern = fast::k_rows_fast<W>;
+    ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)(groups * n_sig)), dim3(W * 64), lds, c->stream, d_x, sg, tb,
+                       groups, FT, Tmax, power, S, sig_max);
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
+
+template int apply_fast<APPLY_SUBTRACT>(Ctx *, ApplyArgs<float>, int64_t, int64_t);
+template int apply_fast<APPLY_GAIN>(Ctx *, ApplyArgs<float>, int64_t, int64_t);
+
+}  // namespace adn

@@ -1,0 +1,94 @@
+// Declarations shared by the generic (adn_stft.hip) and register-resident
+// (adn_stft_fast.hip) STFT kernels.
+#pragma once
+#include "adn_kernels.hpp"
+
+namespace adn {
+
+template <typename T> struct Vec2;
+template <> struct Vec2<float> { using type = float2; };
+template <> struct Vec2<double> { using type = double2; };
+
+template <typename V> __device__ __forceinline__ V cadd(V a, V b) { return V{a.x + b.x, a.y + b.y}; }
+template <typename V> __device__ __forceinline__ V csub(V a, V b) { return V{a.x - b.x, a.y - b.y}; }
+template <typename V> __device__ __forceinline__ V cmul(V a, V b) {
+    return V{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x};
+}
+template <typename V> __device__ __forceinline__ V cmulc(V a, V b) {   // a * conj(b)
+    return V{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y};
+}
+template <typename V> __device__ __forceinline__ V conj(V a) { return V{a.x, -a.y}; }
+
+// Orders LDS traffic between lanes of one wave (the hardware issues a wave's LDS
+// instructions in order; this only stops the compiler from moving them).
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int brev(int k, int logn) { return (int)(__brev((unsigned)k) >> (32 - logn)); }
+
+template <typename T>
+struct Tables {
+    const T *window;
+    const typename Vec2<T>::type *tw;
+    const typename Vec2<T>::type *rtw;
+    double wsum;
+    int n_fft, logc;   // logc = log2(N/2)
+};
+
+// ---------------------------------------------------------- signal access
+struct Signals {
+    const int64_t *off;
+    const int64_t *len;
+    int n_ch;
+    int n_fft, hop, padded;
+};
+
+__host__ __device__ inline int64_t stft_frames(int64_t n, int n_fft, int hop, int padded) {
+    if (n < n_fft) return 0;
+    int64_t nadd = 0;
+    if (padded) {
+        const int64_t r = (n - n_fft) % hop;
+        nadd = ((hop - r) % hop) % n_fft;
+    }
+    return 1 + (n + nadd - n_fft) / hop;
+}
+
+// Sample p of the zero-padded, mono-folded signal (mean over channels like np.mean(axis=1)).
+template <typename T>
+__device__ __forceinline__ T fold_sample(const T *__restrict__ x, int64_t p, int64_t n, int n_ch) {
+    if (p >= n) return (T)0;
+    if (n_ch == 1) return x[p];
+    T s = 0;
+    for (int c = 0; c < n_ch; ++c) s += x[p * n_ch + c];
+    return s / (T)n_ch;
+}
+
+enum { APPLY_SUBTRACT = 0, APPLY_GAIN = 1 };
+
+template <typename T>
+struct ApplyArgs {
+    const T *x;
+    T *y;
+    const int64_t *y_off;
+    Signals sg;
+    Tables<T> tb;
+    const T *row;        // noise magnitude (SUBTRACT) or gain (GAIN), F per signal
+    int64_t row_stride;  // elements between signals (0 = shared)
+    T alpha, beta;
+    int st, sf;          // box sizes along time / frequency
+    int64_t segs_per_sig;
+    int seg_hops;        // output hops per workgroup
+};
+
+
+// register-resident path (binary32, n_fft = 2048)
+bool apply_fast_ok(int n_fft, int hop, int st);
+template <int MODE>
+int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax);
+int rows_fast(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &tb, int64_t n_sig,
+              int64_t Tmax, int power, float *S, unsigned long long *sig_max);
+
+}  // namespace adn

@@ -54,6 +54,11 @@ int adn_destroy(adn_ctx *ctx);
 int adn_set_stream(adn_ctx *ctx, void *hip_stream);
 /* Blocks the host until everything enqueued on the context's stream is done. */
 int adn_synchronize(adn_ctx *ctx);
+/* Tuning / test knobs.  ADN_OPT_FORCE_GENERIC (value != 0): run the shape-generic
+ * kernels even where a specialised one exists (binary32, n_fft = 2048; fused wavelet
+ * tiles), so that tests can cover both. */
+enum { ADN_OPT_FORCE_GENERIC = 1 };
+int adn_set_option(adn_ctx *ctx, int option, int value);
 /* Bytes of device workspace currently held by the context. */
 int64_t adn_workspace_bytes(adn_ctx *ctx);
 

@@ -170,3 +170,26 @@ def test_large_batch_properties():
     # batch result == single-signal result, bit for bit (independent signals)
     y1, _ = e.spectral_subtract(x[1].contiguous(), [n], zero, alpha=0.0, beta=1.0, smooth_time=1, smooth_freq=1)
     assert torch.equal(y1, y[L:2 * L])
+
+
+def test_generic_fp32_kernels_match_specialised(golden):
+    """binary32 / n_fft 2048 normally runs the register-resident kernels; the shape-generic
+    LDS kernels must agree with them (and with the oracle) on the same input."""
+    e = engine()
+    nm = _noise_mag(golden).astype(np.float32)
+    x32 = synth.noisy_speech(60000, SR, 42, 20).astype(np.float32)
+    want_b = orc.spectral_subtract(x32.astype(np.float64), nm.astype(np.float64))
+    want_c, _ = orc.wiener(x32.astype(np.float64), SR)
+    outs = {}
+    for generic in (False, True):
+        e.force_generic(generic)
+        try:
+            yb, _ = e.spectral_subtract(dev(x32), [x32.size], dev(nm))
+            yc, _ = e.wiener(dev(x32), [x32.size], SR)
+            outs[generic] = (host(yb), host(yc))
+        finally:
+            e.force_generic(False)
+        check32(outs[generic][0], want_b)
+        check32(outs[generic][1], want_c)
+    assert np.max(np.abs(outs[True][0] - outs[False][0])) <= 2e-6
+    assert np.max(np.abs(outs[True][1] - outs[False][1])) <= 2e-6
