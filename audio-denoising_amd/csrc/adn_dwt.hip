@@ -440,8 +440,9 @@ static int mad_threshold(Ctx *c, const T *D, const BlockGeom &g, int F, int ext,
     return ADN_OK;
 }
 
-static size_t mad_ws_bytes(int64_t n_blocks) {
-    return 2 * ws_need(n_blocks, sizeof(int64_t)) + 3 * ws_need(n_blocks, sizeof(double));
+static size_t mad_ws_bytes(int64_t n_blocks, int64_t max_seg) {
+    return 2 * ws_need(n_blocks, sizeof(int64_t)) + 3 * ws_need(n_blocks, sizeof(double)) +
+           2 * select_ws_bytes(n_blocks, max_seg);
 }
 
 template <typename T, int NCH>
@@ -449,7 +450,8 @@ static int channel_denoise(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t
                            const ChannelMap<T> &m, int thr_mode, double *d_sigma,
                            double *d_thresh, int64_t *d_zeroed) {
     g.d_stride = max_frames * m.n_d1;
-    ADN_TRY(ws_reserve(c, ws_need((size_t)g.n_blocks * g.d_stride, sizeof(T)) + mad_ws_bytes(g.n_blocks)));
+    ADN_TRY(ws_reserve(c, ws_need((size_t)g.n_blocks * g.d_stride, sizeof(T)) +
+                          mad_ws_bytes(g.n_blocks, max_frames * m.n_d1)));
     T *D = ws_take<T>(c, (size_t)g.n_blocks * g.d_stride);
     const int64_t tiles = ceil_div(max_frames, 256);
     dim3 grid((unsigned)(tiles * g.n_blocks)), block(256);
@@ -472,7 +474,8 @@ static int general_denoise(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t
     g.a_stride = (max_frames + 1) / 2 + 1;
     g.d_stride = max_frames + level + 1;
     const size_t nA = (size_t)g.n_blocks * g.a_stride, nD = (size_t)g.n_blocks * g.d_stride;
-    ADN_TRY(ws_reserve(c, 2 * ws_need(nA, sizeof(T)) + ws_need(nD, sizeof(T)) + mad_ws_bytes(g.n_blocks)));
+    ADN_TRY(ws_reserve(c, 2 * ws_need(nA, sizeof(T)) + ws_need(nD, sizeof(T)) +
+                          mad_ws_bytes(g.n_blocks, (max_frames + 1) / 2)));
     T *A0 = ws_take<T>(c, nA), *A1 = ws_take<T>(c, nA), *D = ws_take<T>(c, nD);
     for (int l = 1; l <= level; ++l) {
         const int64_t tiles = ceil_div(band_len(max_frames, l, F, ext), 256);

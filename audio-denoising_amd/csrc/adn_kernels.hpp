@@ -27,6 +27,9 @@ struct SelectArgs {
 // segment (NaN if the segment is empty or holds a NaN).
 template <typename T>
 int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a);
+// Workspace (bytes) a launch_select call carves out of the context's reserved workspace;
+// callers add it to their ws_reserve request, once per launch_select call they make.
+size_t select_ws_bytes(int64_t n_seg, int64_t max_len);
 
 // -------------------------------------------------------------- wavelets
 template <typename T>

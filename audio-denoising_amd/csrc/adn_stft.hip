@@ -702,7 +702,8 @@ int noise_psd(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const i
     const int F = n_fft / 2 + 1;
     const int64_t Tmax = stft_frames(max_len, n_fft, hop, padded);
     const size_t nS = (size_t)n_sig * F * Tmax;
-    ADN_TRY(ws_reserve(c, ws_need(nS, sizeof(T)) + ws_need(n_sig, 8) * 2 + ws_need((size_t)n_sig * F, 8)));
+    ADN_TRY(ws_reserve(c, ws_need(nS, sizeof(T)) + ws_need(n_sig, 8) * 2 + ws_need((size_t)n_sig * F, 8) +
+                              select_ws_bytes(n_sig * F, Tmax)));
     T *S = ws_take<T>(c, nS);
     int64_t *Tn = ws_take<int64_t>(c, n_sig);
     unsigned long long *sig_max = ws_take<unsigned long long>(c, n_sig);
@@ -783,7 +784,8 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     const int64_t nv_max = vad_guided ? (ceil_div(max_len, frame_len) < 1 ? 1 : ceil_div(max_len, frame_len)) : 1;
     const size_t nS = (size_t)n_sig * F * Tmax, nR = (size_t)n_sig * F;
     ADN_TRY(ws_reserve(c, ws_need(nS, sizeof(T)) + ws_need(n_sig, 8) + 2 * ws_need(nR, 8) + ws_need(nR, sizeof(T)) +
-                              ws_need((size_t)n_sig * nv_max, 1) + ws_need((size_t)n_sig * Tmax, 1) + ws_need(n_sig, 4)));
+                              ws_need((size_t)n_sig * nv_max, 1) + ws_need((size_t)n_sig * Tmax, 1) + ws_need(n_sig, 4) +
+                              2 * select_ws_bytes(n_sig * F, Tmax)));
     T *S = ws_take<T>(c, nS);
     int64_t *Tn = ws_take<int64_t>(c, n_sig);
     double *p10 = ws_take<double>(c, nR), *sraw = ws_take<double>(c, nR);
