@@ -34,6 +34,7 @@ _PLAIN = {
 # per-precision symbols (suffix _f32 / _f64); every data pointer is passed as void*
 _TYPED = {
     "adn_wavelet_denoise": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp],
+    "adn_mad": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp],
     "adn_wavedec": [_vp, _vp, _i64, _i, _i, _i, _vp, _i64, C.POINTER(_i64)],
     "adn_waverec": [_vp, _vp, C.POINTER(_i64), _i, _i, _i, _vp, _i64, C.POINTER(_i64)],
     "adn_noise_psd": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _d, _d, _i, _i, _vp],

@@ -237,6 +237,17 @@ class Engine:
                    int(kernel_bins), int(bool(vad_guided)), _ptr(out), _ptr(d_yoff), _ptr(gain))
         return (out, out_lens, gain) if want_gain else (out, out_lens)
 
+    def mad(self, x, lens=None):
+        """median(|x - median(x)|) per segment of a flat device tensor (one segment when
+        `lens` is None).  Returns a float64 device tensor of one value per segment."""
+        lens = np.asarray([x.numel()] if lens is None else lens, dtype=np.int64)
+        offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+        out = torch.empty(len(lens), dtype=torch.float64, device=x.device)
+        d_off, d_len = self._i64(offs), self._i64(lens)
+        self._call("adn_mad", x.dtype, _ptr(x.contiguous()), len(lens), _ptr(d_off), _ptr(d_len),
+                   int(lens.max()), _ptr(None), _ptr(out))
+        return out if len(lens) > 1 else out[0]
+
     # ------------------------------------------------------------------ misc
     def window_rms(self, x, win):
         n_rows = int(x.shape[0])

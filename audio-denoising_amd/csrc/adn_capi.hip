@@ -39,6 +39,30 @@ int ws_reserve(Ctx *c, size_t bytes) {
 
 }  // namespace adn
 
+template <typename T>
+static int mad_impl(adn_ctx *c, const T *d_x, int64_t n_seg, const int64_t *d_off, const int64_t *d_len,
+                    int64_t max_len, double *d_median, double *d_mad) {
+    ADN_REQUIRE(c && d_x && d_off && d_len && d_mad, "null pointer argument");
+    ADN_REQUIRE(n_seg >= 0 && max_len >= 1, "n_seg must be >= 0 and max_len >= 1");
+    if (n_seg == 0) return ADN_OK;
+    adn::DeviceGuard dg(c->device);
+    adn::ws_reset(c);
+    ADN_TRY(adn::ws_reserve(c, adn::ws_need(n_seg, 8) + 2 * adn::select_ws_bytes(n_seg, max_len)));
+    double *med = d_median ? d_median : adn::ws_take<double>(c, n_seg);
+    adn::SelectArgs a;
+    a.n_seg = n_seg;
+    a.d_seg_off = d_off;
+    a.d_seg_len = d_len;
+    a.max_len = max_len;
+    a.mode = adn::SEL_MEDIAN;
+    a.d_out = med;
+    ADN_TRY(adn::launch_select<T>(c, d_x, a));
+    a.xform = adn::XF_ABSDEV;
+    a.d_center = med;
+    a.d_out = d_mad;
+    return adn::launch_select<T>(c, d_x, a);
+}
+
 using adn::Ctx;
 
 extern "C" {
@@ -85,8 +109,9 @@ int adn_set_stream(adn_ctx *c, void *s) {
 
 int adn_set_option(adn_ctx *c, int option, int value) {
     ADN_REQUIRE(c != nullptr, "ctx is null");
-    ADN_REQUIRE(option == ADN_OPT_FORCE_GENERIC, "unknown option %d", option);
-    c->force_generic = value != 0;
+    ADN_REQUIRE(option == ADN_OPT_FORCE_GENERIC || option == ADN_OPT_ABLATE, "unknown option %d", option);
+    if (option == ADN_OPT_FORCE_GENERIC) c->force_generic = value != 0;
+    if (option == ADN_OPT_ABLATE) c->ablate = value;
     return ADN_OK;
 }
 
@@ -131,6 +156,10 @@ int64_t adn_istft_out_samples(int64_t n, int n_fft, int hop) {
         return adn::wavelet_denoise<T>(c, d_in, d_out, n_blocks, d_in_off, d_frames, d_out_off,     \
                                        max_frames, n_ch, wavelet, level, thr_mode, d_sigma,         \
                                        d_thresh, d_zeroed);                                         \
+    }                                                                                               \
+    int adn_mad_##SUF(adn_ctx *c, const T *d_x, int64_t n_seg, const int64_t *d_off,                \
+                      const int64_t *d_len, int64_t max_len, double *d_median, double *d_mad) {     \
+        return mad_impl<T>(c, d_x, n_seg, d_off, d_len, max_len, d_median, d_mad);                  \
     }                                                                                               \
     int adn_wavedec_##SUF(adn_ctx *c, const T *d_x, int64_t n, int wavelet, int level, int ext,     \
                           T *d_coeffs, int64_t cap, int64_t *h_band_len) {                          \

@@ -55,6 +55,7 @@ struct Ctx {
     size_t ws_used = 0;        // bump pointer, reset per call
     int num_cus = 256;
     bool force_generic = false;   // test hook: skip the specialised kernels
+    int ablate = 0;               // diagnostics: stages the fused STFT kernel skips (timing only)
 };
 
 // Ensure the workspace holds at least `bytes`; growing synchronises the stream

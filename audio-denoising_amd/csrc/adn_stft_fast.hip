@@ -381,7 +381,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
         a_last = a_last > Tn - 1 ? Tn - 1 : a_last;
         Spec s;
         // ---- stage A: spectrum of frame t
-        if (t <= a_last) {
+        if (t <= a_last && !(a.ablate & 1)) {
             c2 r[16];
             load_frame(r, buf, xs, n, a.sg.n_ch, (int64_t)t * H, tb.window, lane);
             wave_fft1024<false>(r, buf, tw, lane);
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
         if (base + W - 1 >= Tn - 1) ue = Tn - 1;
         ue = ue > last_u ? last_u : ue;
         // ---- stage B: modify, inverse transform, window
-        if (t >= ub && t <= ue) {
+        if (t >= ub && t <= ue && !(a.ablate & 2)) {
             if (MODE == APPLY_SUBTRACT) {
                 const float inv_st = 1.0f / (float)a.st;
                 // rows of the time neighbours (clamped at the signal's first / last frame)
@@ -480,14 +480,13 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
         }
         __syncthreads();
         // ---- overlap-add of frames [ub, ue] into padded hops [ub, ue + R - 1]
-        if (ue >= ub) {
+        if (ue >= ub && !(a.ablate & 4)) {
             const bool final_group = (ue == Tn - 1);
             const int nj = ue - ub + R;                     // hops touched
-            const int i = tid & (H - 1);                    // sample inside the hop: fixed per thread
-            const int jstep = (W * 64) >> LOGH;             // hops advanced per sweep of the block
             const float *fbase = reinterpret_cast<const float *>(bufs);
 #pragma unroll 1
-            for (int jj = tid >> LOGH; jj < nj; jj += jstep) {
+            for (int idx = tid; idx < (nj << LOGH); idx += W * 64) {
+                const int jj = idx >> LOGH, i = idx & (H - 1);
                 const int j = ub + jj;
                 int slot_i = j % RING;
                 float *slot = acc + slot_i * H + i;
@@ -537,6 +536,8 @@ static size_t apply_lds(int W, int mode, int hop) {
 
 template <int MODE>
 int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
+    // 8 waves per workgroup: in SUBTRACT mode they share the time-smoothing halo frames
+    // (6 of 8 transforms useful); 4-wave workgroups, two per CU, measured 2x slower.
     constexpr int W = 8;
     const int64_t out_hops = Tmax - 1;
     if (out_hops <= 0) return ADN_OK;
@@ -545,6 +546,7 @@ int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
     seg = seg < 24 ? 24 : (seg > 96 ? 96 : seg);
     a.seg_hops = (int)seg;
     a.segs_per_sig = ceil_div(out_hops, seg);
+    a.ablate = c->ablate;
     auto kern = fast::k_apply_fast<W, MODE>;
     ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -81,6 +81,7 @@ struct ApplyArgs {
     int st, sf;          // box sizes along time / frequency
     int64_t segs_per_sig;
     int seg_hops;        // output hops per workgroup
+    int ablate;          // diagnostics: bit 0 skips the analysis, 1 the synthesis, 2 the overlap-add
 };
 
 

@@ -57,7 +57,10 @@ int adn_synchronize(adn_ctx *ctx);
 /* Tuning / test knobs.  ADN_OPT_FORCE_GENERIC (value != 0): run the shape-generic
  * kernels even where a specialised one exists (binary32, n_fft = 2048; fused wavelet
  * tiles), so that tests can cover both. */
-enum { ADN_OPT_FORCE_GENERIC = 1 };
+/* ADN_OPT_ABLATE (diagnostics, results become WRONG): bit mask of stages the fused
+ * binary32 STFT kernel skips - 1 analysis, 2 synthesis, 4 overlap-add - so that the
+ * cost of each stage can be timed.  0 restores normal operation. */
+enum { ADN_OPT_FORCE_GENERIC = 1, ADN_OPT_ABLATE = 2 };
 int adn_set_option(adn_ctx *ctx, int option, int value);
 /* Bytes of device workspace currently held by the context. */
 int64_t adn_workspace_bytes(adn_ctx *ctx);
@@ -104,6 +107,15 @@ int adn_wavelet_denoise_f64(adn_ctx *ctx, const double *d_in, double *d_out, int
                             const int64_t *d_out_off, int64_t max_frames, int n_ch, int wavelet,
                             int level, int thr_mode, double *d_sigma, double *d_thresh,
                             int64_t *d_zeroed);
+
+/* mad() of denoise.py:16-23 for a batch of segments: d_mad[s] = median(|x - median(x)|)
+ * over the len[s] values at d_x[d_off[s]] (numpy semantics: even counts average the two
+ * middle order statistics; no 0.6745 factor).  d_median (may be NULL) receives the medians.
+ * d_off / d_len: device arrays of n_seg int64; max_len bounds len[s]. */
+int adn_mad_f32(adn_ctx *ctx, const float *d_x, int64_t n_seg, const int64_t *d_off,
+                const int64_t *d_len, int64_t max_len, double *d_median, double *d_mad);
+int adn_mad_f64(adn_ctx *ctx, const double *d_x, int64_t n_seg, const int64_t *d_off,
+                const int64_t *d_len, int64_t max_len, double *d_median, double *d_mad);
 
 /* Multi-level analysis / synthesis of ONE signal (pywt.wavedec / pywt.waverec,
  * and the single-level steps pywt.WaveletPacket is built from:
