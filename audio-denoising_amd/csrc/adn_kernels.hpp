@@ -21,7 +21,14 @@ struct SelectArgs {
     int xform = XF_NONE;
     const double *d_center = nullptr;     // per segment, for XF_ABSDEV
     double *d_out = nullptr;              // per segment result
+    // optional, short segments only: masked mean of each segment in the same pass
+    const unsigned char *d_mask = nullptr;   // mask[(seg / mask_div) * mask_stride + i]
+    int64_t mask_div = 1, mask_stride = 0;
+    double *d_masked_mean = nullptr;
 };
+// longest segment launch_select handles inside one workgroup (longer ones take the
+// multi-workgroup path, which has no fused masked mean)
+int64_t select_short_limit();
 
 // Exact numpy-compatible median / linearly interpolated percentile of every
 // segment (NaN if the segment is empty or holds a NaN).

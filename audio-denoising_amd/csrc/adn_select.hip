@@ -49,6 +49,15 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *wsum) 
     return base + x - v;
 }
 
+// Optional fused statistic of the first pass: masked mean of the segment,
+// out[seg] = sum(vals[i] where mask[(seg / mask_div) * mask_stride + i] != 0) / max(count, 1)
+// (the VAD-guided speech PSD of src/wiener_filter.py:99-102 shares the row with the percentile).
+struct MaskedMean {
+    const unsigned char *mask;
+    int64_t mask_div, mask_stride;
+    double *out;
+};
+
 template <typename T, int XF>
 __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ vals,
                                                         const int64_t *__restrict__ seg_off,
@@ -57,23 +66,30 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
                                                         int64_t len_div, int64_t uniform_len,
                                                         int mode, double q,
                                                         const double *__restrict__ center,
-                                                        double *__restrict__ out, int lds_keys) {
+                                                        double *__restrict__ out, int lds_keys,
+                                                        MaskedMean mm) {
     using K = typename KeyT<T>::type;
     constexpr int BITS = KeyT<T>::bits;
+    constexpr int PASSES = BITS / 8;
     extern __shared__ __align__(16) unsigned char smem[];
-    K *keys = reinterpret_cast<K *>(smem);
+    K *cur = reinterpret_cast<K *>(smem);        // list the current pass walks (LDS-resident segments)
+    K *oth = cur + lds_keys;                     // the next, shorter list is gathered here
     __shared__ uint32_t hist[256];
     __shared__ uint32_t wsum[4];
-    __shared__ uint32_t s_digit, s_before, s_nan;
-    __shared__ unsigned long long s_cnt_le;
-    __shared__ K s_min_gt;
+    __shared__ uint32_t s_digit, s_before, s_count, s_nan, s_fill, s_next;
+    __shared__ K s_lo_max, s_hi_min;
+    __shared__ double s_msum[4];
+    __shared__ int s_mcnt[4];
 
     const int64_t seg = blockIdx.x;
     const int64_t off = seg_off ? seg_off[seg] : seg * seg_stride;
     const int64_t n = seg_len ? seg_len[seg / len_div] : uniform_len;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (n <= 0) {
-        if (tid == 0) out[seg] = __longlong_as_double(0x7FF8000000000000ll);
+        if (tid == 0) {
+            out[seg] = __longlong_as_double(0x7FF8000000000000ll);
+            if (mm.out) mm.out[seg] = 0.0;
+        }
         return;
     }
     int64_t r0, r1;
@@ -92,6 +108,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
     const T c = XF == XF_ABSDEV ? (T)center[seg] : (T)0;
     const bool cached = n <= (int64_t)lds_keys;
     const T *v = vals + off;
+    const unsigned char *mk = mm.out ? mm.mask + (seg / mm.mask_div) * mm.mask_stride : nullptr;
     auto load_key = [&](int64_t i) -> K {
         T x = v[i];
         if (XF == XF_ABSDEV) x = fabs(x - c);
@@ -99,70 +116,130 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
     };
 
     if (tid == 0) s_nan = 0;
-    K prefix = 0;
-    uint64_t r = (uint64_t)r0;
-    const int64_t iters = (n + SEL_THREADS - 1) / SEL_THREADS;
-    for (int pass = 0; pass < BITS / 8; ++pass) {
+    K prefix = 0;                   // digits fixed so far, right aligned
+    uint64_t r = (uint64_t)r0;      // rank of s[r0] inside the current list
+    int64_t n_act = n;              // length of the current list (cached) or of the segment
+    K k0 = 0, k1 = 0;
+    bool done = false;
+    T msum = 0;
+    int mcnt = 0;
+    for (int pass = 0; pass < PASSES && !done; ++pass) {
         const int shift = BITS - 8 * (pass + 1);
         hist[tid] = 0;
+        if (tid == 0) {
+            s_fill = 0;
+            s_next = 256;
+            s_lo_max = 0;
+            s_hi_min = ~(K)0;
+        }
         __syncthreads();
+        // ---- histogram of this pass's digit
         bool saw_nan = false;
-        for (int64_t it = 0; it < iters; ++it) {
+        const int64_t its = (n_act + SEL_THREADS - 1) / SEL_THREADS;
+        for (int64_t it = 0; it < its; ++it) {
             const int64_t i = it * SEL_THREADS + tid;
-            const bool in = i < n;
+            const bool in = i < n_act;
             K k = 0;
+            bool match = in;
             if (in) {
                 if (pass == 0) {
-                    k = load_key(i);
-                    if (cached) keys[i] = k;
+                    const T x = v[i];
+                    if (mk && mk[i]) {
+                        msum += x;
+                        ++mcnt;
+                    }
+                    T xx = x;
+                    if (XF == XF_ABSDEV) xx = fabs(x - c);
+                    k = xx != xx ? ~(K)0 : key_of(xx);
+                    if (cached) cur[i] = k;
                     saw_nan |= (k == ~(K)0);
+                } else if (cached) {
+                    k = cur[i];                      // the list holds only keys with this prefix
                 } else {
-                    k = cached ? keys[i] : load_key(i);
+                    k = load_key(i);
+                    match = (k >> (shift + 8)) == prefix;
                 }
             }
-            const bool match = in && (pass == 0 || (k >> (shift + 8)) == prefix);
             hist_add_matched(hist, (uint32_t)((k >> shift) & 0xFF), match);
         }
         if (pass == 0 && saw_nan) s_nan = 1;
         __syncthreads();
+        // ---- bin of s[r0]; is s[r1] in the same bin?
         const uint32_t h = hist[tid];
         const uint32_t before = block_excl_scan(h, wsum);
         if (r >= before && r < (uint64_t)before + h) {
             s_digit = tid;
             s_before = before;
+            s_count = h;
         }
         __syncthreads();
-        prefix = (prefix << 8) | (K)s_digit;
-        r -= s_before;
+        const uint32_t digit = s_digit, in_bin = s_count;
+        const uint64_t within = r - s_before;
+        const bool together = (r1 == r0) || (within + 1 < in_bin);
+        const K new_prefix = (prefix << 8) | (K)digit;
+        if (!together) {
+            // s[r0] is the largest key of its bin and s[r1] the smallest key of the next non-empty
+            // bin: one sweep over the current list settles both
+            if (h && (uint32_t)tid > digit) atomicMin(&s_next, (uint32_t)tid);
+            __syncthreads();
+            const K pre_hi = (prefix << 8) | (K)s_next;
+            K lo_max = 0, hi_min = ~(K)0;
+            for (int64_t i = tid; i < n_act; i += SEL_THREADS) {
+                const K k = (cached ) ? cur[i] : load_key(i);
+                const K top = k >> shift;
+                if (top == new_prefix && k > lo_max) lo_max = k;
+                if (top == pre_hi && k < hi_min) hi_min = k;
+            }
+            for (int d = 32; d >= 1; d >>= 1) {
+                const K a = __shfl_xor(lo_max, d), b = __shfl_xor(hi_min, d);
+                lo_max = a > lo_max ? a : lo_max;
+                hi_min = b < hi_min ? b : hi_min;
+            }
+            if (lane == 0) {
+                atomicMax(&s_lo_max, lo_max);
+                atomicMin(&s_hi_min, hi_min);
+            }
+            __syncthreads();
+            k0 = s_lo_max;
+            k1 = s_hi_min;
+            done = true;
+        } else if (pass + 1 == PASSES) {
+            k0 = k1 = new_prefix;             // both order statistics are copies of one key
+            done = true;
+        } else {
+            if (cached) {
+                // gather the keys of the chosen bin: later passes walk this short list only
+                for (int64_t it = 0; it < its; ++it) {
+                    const int64_t i = it * SEL_THREADS + tid;
+                    const bool in = i < n_act;
+                    const K k = in ? cur[i] : 0;
+                    const bool keep = in && (k >> shift) == new_prefix;
+                    const unsigned long long m = __ballot(keep);
+                    uint32_t base = 0;
+                    if (lane == 0 && m) base = atomicAdd(&s_fill, (uint32_t)__popcll(m));
+                    base = __shfl(base, 0);
+                    if (keep) oth[base + __popcll(m & ((1ull << lane) - 1ull))] = k;
+                }
+                n_act = in_bin;
+                K *t = cur;
+                cur = oth;
+                oth = t;
+            }
+            prefix = new_prefix;
+            r = within;
+        }
         __syncthreads();
     }
-    const K k0 = prefix;
-    K k1 = k0;
-    if (r1 != r0) {
-        // s[r0+1] equals s[r0] when at least r0+2 keys are <= k0, else the smallest key above k0
-        if (tid == 0) {
-            s_cnt_le = 0;
-            s_min_gt = ~(K)0;
-        }
-        __syncthreads();
-        unsigned long long cnt = 0;
-        K mn = ~(K)0;
-        for (int64_t i = tid; i < n; i += SEL_THREADS) {
-            const K k = cached ? keys[i] : load_key(i);
-            cnt += (k <= k0);
-            if (k > k0 && k < mn) mn = k;
-        }
+    if (mm.out) {
         for (int d = 32; d >= 1; d >>= 1) {
-            cnt += __shfl_xor(cnt, d);
-            const K o = __shfl_xor(mn, d);
-            mn = o < mn ? o : mn;
+            msum += __shfl_xor(msum, d);
+            mcnt += __shfl_xor(mcnt, d);
         }
-        if ((tid & 63) == 0) {
-            atomicAdd(&s_cnt_le, cnt);
-            atomicMin(&s_min_gt, mn);
+        if (lane == 0) {
+            s_msum[wave] = (double)msum;
+            s_mcnt[wave] = mcnt;
         }
         __syncthreads();
-        k1 = s_cnt_le >= (unsigned long long)r0 + 2 ? k0 : s_min_gt;
     }
     if (tid == 0) {
         double res;
@@ -180,6 +257,11 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
             }
         }
         out[seg] = res;
+        if (mm.out) {
+            const T tot = (T)s_msum[0] + (T)s_msum[1] + (T)s_msum[2] + (T)s_msum[3];
+            const int cn = s_mcnt[0] + s_mcnt[1] + s_mcnt[2] + s_mcnt[3];
+            mm.out[seg] = (double)(tot / (T)(cn > 1 ? cn : 1));
+        }
     }
 }
 
@@ -437,6 +519,8 @@ __global__ void k_big_finish(const BigState *__restrict__ st, const int64_t *__r
     out[seg] = res;
 }
 
+int64_t select_short_limit() { return BIG_THRESHOLD; }
+
 size_t select_ws_bytes(int64_t n_seg, int64_t max_len) {
     if (max_len <= BIG_THRESHOLD) return 0;
     return ws_need((size_t)n_seg, sizeof(BigState)) + ws_need((size_t)n_seg * BIG_BINS, sizeof(uint32_t));
@@ -484,21 +568,33 @@ int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {
     if (a.n_seg <= 0) return ADN_OK;
     using K = typename KeyT<T>::type;
     if (a.max_len > BIG_THRESHOLD) {
+        if (a.d_masked_mean) {
+            set_error("internal: the fused masked mean is only available for LDS-resident segments");
+            return ADN_ERR_UNSUPPORTED;
+        }
         return a.xform == XF_ABSDEV ? launch_select_big<T, XF_ABSDEV>(c, d_vals, a)
                                     : launch_select_big<T, XF_NONE>(c, d_vals, a);
     }
     int lds_keys = (int)(SEL_LDS_BYTES / sizeof(K));
     if (a.max_len > 0 && a.max_len < lds_keys) lds_keys = (int)a.max_len;
-    const size_t dyn = (size_t)lds_keys * sizeof(K);
+    const size_t dyn = 2 * (size_t)lds_keys * sizeof(K);      // keys + candidate list
+    MaskedMean mm{a.d_mask, a.mask_div, a.mask_stride, a.d_masked_mean};
+    if (a.xform == XF_ABSDEV) {
+        auto kern = k_select<T, XF_ABSDEV>;
+        ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    } else {
+        auto kern = k_select<T, XF_NONE>;
+        ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    }
     dim3 grid((unsigned)a.n_seg), block(SEL_THREADS);
     if (a.xform == XF_ABSDEV) {
         hipLaunchKernelGGL((k_select<T, XF_ABSDEV>), grid, block, dyn, c->stream, d_vals,
                            a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len,
-                           a.mode, a.q, a.d_center, a.d_out, lds_keys);
+                           a.mode, a.q, a.d_center, a.d_out, lds_keys, mm);
     } else {
         hipLaunchKernelGGL((k_select<T, XF_NONE>), grid, block, dyn, c->stream, d_vals,
                            a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len,
-                           a.mode, a.q, a.d_center, a.d_out, lds_keys);
+                           a.mode, a.q, a.d_center, a.d_out, lds_keys, mm);
     }
     ADN_HIP(hipGetLastError());
     return ADN_OK;

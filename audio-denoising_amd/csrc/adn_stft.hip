@@ -673,7 +673,9 @@ static int apply_dispatch(Ctx *c, const ApplyArgs<T> &a, int64_t n_sig, int64_t 
     };
     const int min_w = MODE == APPLY_SUBTRACT ? a.st : 1;
     if constexpr (std::is_same<T, float>::value) {
-        if (!c->force_generic && apply_fast_ok(N, a.sg.hop, a.st)) return apply_fast<MODE>(c, a, n_sig, Tmax);
+        // the register-resident kernel is built for the reference's 3-frame time smoothing
+        const bool st_ok = MODE == APPLY_GAIN || a.st == 3;
+        if (!c->force_generic && st_ok && apply_fast_ok(N, a.sg.hop, a.st, a.sf)) return apply_fast<MODE>(c, a, n_sig, Tmax);
     }
     if (need(8) <= 156 * 1024) return launch_apply<T, 8, MODE>(c, a, n_sig, Tmax);
     if (need(4) <= 156 * 1024 && min_w <= 4) return launch_apply<T, 4, MODE>(c, a, n_sig, Tmax);
@@ -794,6 +796,12 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     unsigned char *vad = ws_take<unsigned char>(c, (size_t)n_sig * Tmax);
     Signals sg{d_off, d_len, n_ch, n_fft, hop, 1};
     hipLaunchKernelGGL(k_frame_counts, dim3((unsigned)ceil_div(n_sig, 256)), dim3(256), 0, c->stream, sg, n_sig, Tn);
+    if (vad_guided) {
+        hipLaunchKernelGGL((k_vad_energy<T>), dim3((unsigned)ceil_div(n_sig * nv_max, 4)), dim3(256), 0, c->stream,
+                           d_x, sg, n_sig, frame_len, nv_max, speech);
+        hipLaunchKernelGGL(k_vad_map, dim3((unsigned)ceil_div(n_sig * Tmax, 256)), dim3(256), 0, c->stream, sg, n_sig,
+                           frame_len, nv_max, Tmax, speech, vad);
+    }
     ADN_TRY(rows_dispatch<T>(c, d_x, sg, tb, n_sig, Tmax, 1, S, nullptr));
     SelectArgs sa;
     sa.n_seg = n_sig * F;
@@ -804,15 +812,21 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     sa.mode = SEL_PERCENTILE;
     sa.q = 10.0;
     sa.d_out = p10;
+    // rows that fit one workgroup get the VAD-masked mean from the same pass over the row
+    const bool fuse_mean = vad_guided && Tmax <= select_short_limit();
+    if (fuse_mean) {
+        sa.d_mask = vad;
+        sa.mask_div = F;
+        sa.mask_stride = Tmax;
+        sa.d_masked_mean = sraw;
+    }
     ADN_TRY(launch_select<T>(c, S, sa));
-    if (vad_guided) {
-        hipLaunchKernelGGL((k_vad_energy<T>), dim3((unsigned)ceil_div(n_sig * nv_max, 4)), dim3(256), 0, c->stream,
-                           d_x, sg, n_sig, frame_len, nv_max, speech);
-        hipLaunchKernelGGL(k_vad_map, dim3((unsigned)ceil_div(n_sig * Tmax, 256)), dim3(256), 0, c->stream, sg, n_sig,
-                           frame_len, nv_max, Tmax, speech, vad);
+    sa.d_mask = nullptr;
+    sa.d_masked_mean = nullptr;
+    if (vad_guided && !fuse_mean) {
         hipLaunchKernelGGL((k_masked_mean<T>), dim3((unsigned)ceil_div(n_sig * F, 4)), dim3(256), 0, c->stream, S, F,
                            Tmax, n_sig * F, Tn, vad, sraw);
-    } else {
+    } else if (!vad_guided) {
         sa.mode = SEL_MEDIAN;
         sa.d_out = sraw;
         ADN_TRY(launch_select<T>(c, S, sa));

@@ -21,6 +21,8 @@ static constexpr int NC = 1024;     // complex points per frame
 static constexpr int RS = 68;       // exchange row stride (float2): 64 + 4 keeps quads on distinct banks
 static constexpr int WBUF = 1088;   // float2 per wave buffer: 16 * RS >= padded natural image + 1
 static constexpr int MROW = 1032;   // floats per magnitude row (1025 used)
+static constexpr int FAST_ST = 3;   // time-smoothing frames this specialisation is built for
+static constexpr int RAWPAD = 8;    // replicated bins kept beyond each end of a raw magnitude row
 
 __device__ __forceinline__ int nat(int k) { return k + ((k >> 8) << 3); }        // float2 index
 __device__ __forceinline__ int natf(int s) { return s + ((s >> 9) << 4); }       // float index of sample s
@@ -127,13 +129,16 @@ __device__ __forceinline__ void wave_fft1024(c2 (&r)[16], c2 *E, const LaneTw &t
     for (int a = 0; a < 16; ++a) r[a] = E[row + 4 * a];
     wave_sync();
     dft16<INV>(r);
+    // radix-4 across the four lanes of a quad as two butterfly steps:
+    //   step 1 (partner lane ^ 2):  b < 2: v + p      b >= 2: p - v, lane 3 also times -i (+i inverse)
+    //   step 2 (partner lane ^ 1):  even:  u + p      odd:    p - u
+    // (sum and difference are both formed and selected: the DPP move fuses into the add / sub)
     const int b = lane & 3;
     c2 u[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         c2 v = r[P16(c)];
         if (c) v = INV ? mulc(v, t.t2[(c - 1) * 4]) : mul(v, t.t2[(c - 1) * 4]);
-        // radix-4 across the quad, step 1 (partner = lane ^ 2)
         const c2 p = dpp2<0x4E>(v);
         c2 s = (b < 2) ? v + p : p - v;
         if (b == 3) s = INV ? c2{-s.y, s.x} : c2{s.y, -s.x};
@@ -141,7 +146,7 @@ __device__ __forceinline__ void wave_fft1024(c2 (&r)[16], c2 *E, const LaneTw &t
     }
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        const c2 p = dpp2<0xB1>(u[c]);                 // partner = lane ^ 1
+        const c2 p = dpp2<0xB1>(u[c]);
         r[c] = (b & 1) ? p - u[c] : u[c] + p;
     }
 }
@@ -289,8 +294,8 @@ __global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ 
                 float p0 = s.lo[j].x * s.lo[j].x + s.lo[j].y * s.lo[j].y;
                 float p1 = s.hi[j].x * s.hi[j].x + s.hi[j].y * s.hi[j].y;
                 if (!power) {
-                    p0 = sqrtf(p0);
-                    p1 = sqrtf(p1);
+                    p0 = __builtin_amdgcn_sqrtf(p0);
+                    p1 = __builtin_amdgcn_sqrtf(p1);
                 }
                 tile[k * ts + ft] = p0;
                 tile[(1024 - k) * ts + ft] = p1;
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ 
             }
             if (lane == 0) {
                 float pm = s.mid.x * s.mid.x + s.mid.y * s.mid.y;
-                if (!power) pm = sqrtf(pm);
+                if (!power) pm = __builtin_amdgcn_sqrtf(pm);
                 tile[512 * ts + ft] = pm;
                 vmax = fmaxf(vmax, pm);
             }
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
             const float w = tb.window[i + r * H];
             s += w * w;
         }
-        wsq[i] = s;
+        wsq[i] = 1.0f / (s > 1e-10f ? s : 1.0f);     // reciprocal of the full-overlap norm
     }
     __syncthreads();
 
@@ -390,32 +395,36 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
             split_spectrum(s, buf, rtw, fscale, lane);
             wave_sync();
             if (MODE == APPLY_SUBTRACT) {
-                // clean magnitudes of the lane's bins -> raw row in the wave's own buffer
+                // clean magnitudes of the lane's bins -> raw row in the wave's own buffer, stored
+                // with an offset of RAWPAD so that the box filter can read past both ends
+                float *raw = bufr + RAWPAD;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int k = lane + 64 * j;
-                    const float m0 = sqrtf(s.lo[j].x * s.lo[j].x + s.lo[j].y * s.lo[j].y);
-                    const float m1 = sqrtf(s.hi[j].x * s.hi[j].x + s.hi[j].y * s.hi[j].y);
-                    bufr[k] = fmaxf(m0 - a.alpha * row[k], a.beta * m0);
-                    bufr[1024 - k] = fmaxf(m1 - a.alpha * row[1024 - k], a.beta * m1);
+                    const float m0 = __builtin_amdgcn_sqrtf(s.lo[j].x * s.lo[j].x + s.lo[j].y * s.lo[j].y);
+                    const float m1 = __builtin_amdgcn_sqrtf(s.hi[j].x * s.hi[j].x + s.hi[j].y * s.hi[j].y);
+                    raw[k] = fmaxf(m0 - a.alpha * row[k], a.beta * m0);
+                    raw[1024 - k] = fmaxf(m1 - a.alpha * row[1024 - k], a.beta * m1);
                 }
                 if (lane == 0) {
-                    const float mm = sqrtf(s.mid.x * s.mid.x + s.mid.y * s.mid.y);
-                    bufr[512] = fmaxf(mm - a.alpha * row[512], a.beta * mm);
+                    const float mm = __builtin_amdgcn_sqrtf(s.mid.x * s.mid.x + s.mid.y * s.mid.y);
+                    raw[512] = fmaxf(mm - a.alpha * row[512], a.beta * mm);
                 }
                 wave_sync();
-                // box mean along frequency (edge replicated) -> shared row of this frame
-                float *mrow = mags + wave * MROW;
                 const int fl = a.sf / 2, fr = a.sf - fl - 1;
+                // edge replication: copies of the first / last bin beyond the row's ends
+                if (lane < RAWPAD) {
+                    raw[-1 - lane] = raw[0];
+                    raw[1025 + lane] = raw[1024];
+                }
+                wave_sync();
+                // box mean along frequency -> shared row of this frame
+                float *mrow = mags + wave * MROW;
                 const float inv_sf = 1.0f / (float)a.sf;
 #pragma unroll 1
                 for (int k = lane; k <= 1024; k += 64) {
                     float fs = 0.0f;
-                    for (int df = -fl; df <= fr; ++df) {
-                        int kk = k + df;
-                        kk = kk < 0 ? 0 : (kk > 1024 ? 1024 : kk);
-                        fs += bufr[kk];
-                    }
+                    for (int df = -fl; df <= fr; ++df) fs += raw[k + df];
                     mrow[k] = fs * inv_sf;
                 }
             }
@@ -429,19 +438,25 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
         if (t >= ub && t <= ue && !(a.ablate & 2)) {
             if (MODE == APPLY_SUBTRACT) {
                 const float inv_st = 1.0f / (float)a.st;
-                // rows of the time neighbours (clamped at the signal's first / last frame)
-                int r_lo = t - h, r_hi = t + hr;
+                // rows of the time neighbours, clamped at the signal's first / last frame
+                const float *rows[FAST_ST];
+#pragma unroll
+                for (int i = 0; i < FAST_ST; ++i) {
+                    int tt = t - h + i;
+                    tt = tt < 0 ? 0 : (tt > Tn - 1 ? Tn - 1 : tt);
+                    rows[i] = mags + (tt - base) * MROW;
+                }
                 auto smooth = [&](int k) {
                     float ts = 0.0f;
-                    for (int tt = r_lo; tt <= r_hi; ++tt) {
-                        const int tc = tt < 0 ? 0 : (tt > Tn - 1 ? Tn - 1 : tt);
-                        ts += mags[(tc - base) * MROW + k];
-                    }
+#pragma unroll
+                    for (int i = 0; i < FAST_ST; ++i) ts += rows[i][k];
                     return ts * inv_st;
                 };
+                // clean * exp(i angle(Z)) = clean * Z / |Z|, and angle(0) = 0
                 auto rephase = [&](c2 z, float sm) {
-                    const float mag = sqrtf(z.x * z.x + z.y * z.y);
-                    return mag > 0.0f ? c2{sm * (z.x / mag), sm * (z.y / mag)} : c2{sm, 0.0f};
+                    const float p2 = z.x * z.x + z.y * z.y;
+                    const float g = sm * __builtin_amdgcn_rsqf(p2);
+                    return p2 > 0.0f ? c2{z.x * g, z.y * g} : c2{sm, 0.0f};
                 };
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -498,11 +513,11 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                     v += fbase[(u - base) * (2 * WBUF) + natf(((j - u) << LOGH) + i)];
                 if (j <= ue || final_group) {
                     if (j >= ph0 && j < ph1) {
-                        float norm;
+                        float o;
                         if (j - R + 1 >= 0 && j <= Tn - 1) {
-                            norm = wsq[i];
+                            o = v * wsq[i];
                         } else {
-                            norm = 0.0f;
+                            float norm = 0.0f;
                             int t_lo = j - R + 1;
                             t_lo = t_lo < 0 ? 0 : t_lo;
                             const int t_hi = j < Tn - 1 ? j : Tn - 1;
@@ -510,8 +525,8 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                                 const float w = tb.window[((j - tt) << LOGH) + i];
                                 norm += w * w;
                             }
+                            o = v / (norm > 1e-10f ? norm : 1.0f);
                         }
-                        float o = v / (norm > 1e-10f ? norm : 1.0f);
                         o = o < -1.0f ? -1.0f : (o > 1.0f ? 1.0f : o);
                         ys[(int64_t)(j - R / 2) * H + i] = o;
                     }
@@ -555,8 +570,8 @@ int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
     return ADN_OK;
 }
 
-bool apply_fast_ok(int n_fft, int hop, int st) {
-    if (n_fft != 2048 || hop < 64 || st > 7) return false;
+bool apply_fast_ok(int n_fft, int hop, int st, int sf) {
+    if (n_fft != 2048 || hop < 64 || (st != fast::FAST_ST && st != 1) || sf > 2 * fast::RAWPAD) return false;
     return fast::apply_lds(8, APPLY_SUBTRACT, hop) <= 156 * 1024;
 }
 

@@ -86,7 +86,7 @@ struct ApplyArgs {
 
 
 // register-resident path (binary32, n_fft = 2048)
-bool apply_fast_ok(int n_fft, int hop, int st);
+bool apply_fast_ok(int n_fft, int hop, int st, int sf);
 template <int MODE>
 int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax);
 int rows_fast(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &tb, int64_t n_sig,
