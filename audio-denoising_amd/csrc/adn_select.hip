@@ -58,6 +58,17 @@ struct MaskedMean {
     double *out;
 };
 
+// Optional: the segment handed to k_select is a gathered SUBSET (the keys inside a value
+// bracket) of a longer segment.  Ranks are then those of the original segment minus the
+// number of keys below the bracket; segments flagged invalid are left untouched.
+struct SubsetRanks {
+    const int64_t *orig_len;              // per (seg / orig_div), or null: orig_uniform
+    int64_t orig_div, orig_uniform;
+    const unsigned long long *below;      // keys of the original segment below the bracket
+    const int *valid;                     // 0: skip this segment
+    const unsigned long long *lohi;       // bracket keys [2*seg], [2*seg+1]: every key lies between them
+};
+
 template <typename T, int XF>
 __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ vals,
                                                         const int64_t *__restrict__ seg_off,
@@ -67,7 +78,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
                                                         int mode, double q,
                                                         const double *__restrict__ center,
                                                         double *__restrict__ out, int lds_keys,
-                                                        MaskedMean mm) {
+                                                        MaskedMean mm, SubsetRanks sub) {
     using K = typename KeyT<T>::type;
     constexpr int BITS = KeyT<T>::bits;
     constexpr int PASSES = BITS / 8;
@@ -85,6 +96,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
     const int64_t off = seg_off ? seg_off[seg] : seg * seg_stride;
     const int64_t n = seg_len ? seg_len[seg / len_div] : uniform_len;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (sub.valid && !sub.valid[seg]) return;
     if (n <= 0) {
         if (tid == 0) {
             out[seg] = __longlong_as_double(0x7FF8000000000000ll);
@@ -94,19 +106,30 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
     }
     int64_t r0, r1;
     double frac;
-    if (mode == SEL_MEDIAN) {
-        r0 = (n - 1) / 2;
-        r1 = n / 2;
-        frac = 0.5;
-    } else {
-        const double pos = (double)(n - 1) * (q / 100.0);
-        r0 = (int64_t)floor(pos);
-        if (r0 > n - 1) r0 = n - 1;
-        frac = pos - (double)r0;
-        r1 = r0 + 1 < n ? r0 + 1 : n - 1;
+    {
+        // ranks come from the length of the ORIGINAL segment
+        const int64_t nr = sub.below ? (sub.orig_len ? sub.orig_len[seg / sub.orig_div] : sub.orig_uniform) : n;
+        if (mode == SEL_MEDIAN) {
+            r0 = (nr - 1) / 2;
+            r1 = nr / 2;
+            frac = 0.5;
+        } else {
+            const double pos = (double)(nr - 1) * (q / 100.0);
+            r0 = (int64_t)floor(pos);
+            if (r0 > nr - 1) r0 = nr - 1;
+            frac = pos - (double)r0;
+            r1 = r0 + 1 < nr ? r0 + 1 : nr - 1;
+        }
+        if (sub.below) {
+            r0 -= (int64_t)sub.below[seg];
+            r1 -= (int64_t)sub.below[seg];
+        }
     }
     const T c = XF == XF_ABSDEV ? (T)center[seg] : (T)0;
+    // n <= lds_keys: keys live in LDS and every pass gathers the chosen bin into a shorter list;
+    // n <= 2*lds_keys: keys live in LDS (both halves), passes re-scan them; else re-read memory
     const bool cached = n <= (int64_t)lds_keys;
+    const bool resident = !cached && n <= 2 * (int64_t)lds_keys;
     const T *v = vals + off;
     const unsigned char *mk = mm.out ? mm.mask + (seg / mm.mask_div) * mm.mask_stride : nullptr;
     auto load_key = [&](int64_t i) -> K {
@@ -123,7 +146,16 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
     bool done = false;
     T msum = 0;
     int mcnt = 0;
-    for (int pass = 0; pass < PASSES && !done; ++pass) {
+    // keys gathered from a value bracket share the leading digits of the bracket's ends:
+    // those passes are skipped (the first pass that runs still loads and stages the keys)
+    int first_pass = 0;
+    if (sub.lohi) {
+        const K blo = (K)sub.lohi[2 * seg], bhi = (K)sub.lohi[2 * seg + 1];
+        while (first_pass < PASSES - 1 && (blo >> (BITS - 8 * (first_pass + 1))) == (bhi >> (BITS - 8 * (first_pass + 1))))
+            ++first_pass;
+        if (first_pass) prefix = blo >> (BITS - 8 * first_pass);
+    }
+    for (int pass = first_pass; pass < PASSES && !done; ++pass) {
         const int shift = BITS - 8 * (pass + 1);
         hist[tid] = 0;
         if (tid == 0) {
@@ -136,33 +168,55 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
         // ---- histogram of this pass's digit
         bool saw_nan = false;
         const int64_t its = (n_act + SEL_THREADS - 1) / SEL_THREADS;
-        for (int64_t it = 0; it < its; ++it) {
-            const int64_t i = it * SEL_THREADS + tid;
-            const bool in = i < n_act;
-            K k = 0;
-            bool match = in;
-            if (in) {
-                if (pass == 0) {
-                    const T x = v[i];
-                    if (mk && mk[i]) {
-                        msum += x;
-                        ++mcnt;
+        if (pass == first_pass) {
+            // first pass: values come from memory; loads are issued in batches of 8 per thread so
+            // that their latency overlaps (the loop body would otherwise wait for every load)
+            for (int64_t it0 = 0; it0 < its; it0 += 8) {
+                T xv[8];
+                unsigned char mv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t i = (it0 + u) * SEL_THREADS + tid;
+                    xv[u] = i < n_act ? v[i] : (T)0;
+                    mv[u] = (mk && i < n_act) ? mk[i] : (unsigned char)0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t i = (it0 + u) * SEL_THREADS + tid;
+                    if (i < n_act) {
+                        const T x = xv[u];
+                        if (mv[u]) {
+                            msum += x;
+                            ++mcnt;
+                        }
+                        T xx = x;
+                        if (XF == XF_ABSDEV) xx = fabs(x - c);
+                        const K k = xx != xx ? ~(K)0 : key_of(xx);
+                        if (cached || resident) cur[i] = k;
+                        saw_nan |= (k == ~(K)0);
+                        atomicAdd(&hist[(uint32_t)((k >> shift) & 0xFF)], 1u);
                     }
-                    T xx = x;
-                    if (XF == XF_ABSDEV) xx = fabs(x - c);
-                    k = xx != xx ? ~(K)0 : key_of(xx);
-                    if (cached) cur[i] = k;
-                    saw_nan |= (k == ~(K)0);
-                } else if (cached) {
-                    k = cur[i];                      // the list holds only keys with this prefix
-                } else {
-                    k = load_key(i);
-                    match = (k >> (shift + 8)) == prefix;
                 }
             }
-            hist_add_matched(hist, (uint32_t)((k >> shift) & 0xFF), match);
+        } else {
+            for (int64_t it = 0; it < its; ++it) {
+                const int64_t i = it * SEL_THREADS + tid;
+                if (i < n_act) {
+                    K k;
+                    bool match = true;
+                    if (cached) {
+                        k = cur[i];                  // the list holds only keys with this prefix
+                    } else {
+                        k = resident ? cur[i] : load_key(i);
+                        match = (k >> (shift + 8)) == prefix;
+                    }
+                    // plain LDS atomics: keys of one segment spread over enough bins that
+                    // same-address serialisation costs less than matching lanes with ballots
+                    if (match) atomicAdd(&hist[(uint32_t)((k >> shift) & 0xFF)], 1u);
+                }
+            }
         }
-        if (pass == 0 && saw_nan) s_nan = 1;
+        if (pass == first_pass && saw_nan) s_nan = 1;
         __syncthreads();
         // ---- bin of s[r0]; is s[r1] in the same bin?
         const uint32_t h = hist[tid];
@@ -185,7 +239,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
             const K pre_hi = (prefix << 8) | (K)s_next;
             K lo_max = 0, hi_min = ~(K)0;
             for (int64_t i = tid; i < n_act; i += SEL_THREADS) {
-                const K k = (cached ) ? cur[i] : load_key(i);
+                const K k = (cached || resident) ? cur[i] : load_key(i);
                 const K top = k >> shift;
                 if (top == new_prefix && k > lo_max) lo_max = k;
                 if (top == pre_hi && k < hi_min) hi_min = k;
@@ -283,6 +337,11 @@ struct BigState {            // per segment
     unsigned long long min_gt;    // extra pass: smallest key > k0
     int need_extra;               // s[r1] lies beyond the last histogram of s[r0]
     int has_nan;
+    // value bracket from a sorted sample: keys in [lo, hi] are gathered, keys below lo counted
+    unsigned long long lo, hi, below;
+    unsigned int n_cand;
+    int overflow;                 // more candidates than the buffer holds
+    int resolved;                 // both order statistics lie inside the bracket
 };
 
 __device__ __forceinline__ void big_ranks(int64_t n, int mode, double q, int64_t *r0, int64_t *r1, double *frac) {
@@ -340,6 +399,7 @@ __global__ __launch_bounds__(256) void k_big_hist(const T *__restrict__ vals, co
     __shared__ uint32_t hist[BIG_BINS];
     __shared__ int s_nan;
     const int64_t seg = blockIdx.x / tiles_per_seg, tile = blockIdx.x % tiles_per_seg;
+    if (st[seg].resolved) return;
     const int64_t n = seg_len ? seg_len[seg / len_div] : uniform_len;
     const int64_t i0 = tile * BIG_TILE;
     if (i0 >= n) return;
@@ -387,6 +447,7 @@ __global__ __launch_bounds__(256) void k_big_scan(BigState *__restrict__ st, uin
     __shared__ unsigned long long s_before, s_count;
     const int64_t seg = blockIdx.x;
     const int tid = threadIdx.x;
+    if (st[seg].resolved) return;
     const int64_t n = seg_len ? seg_len[seg / len_div] : uniform_len;
     uint32_t *gh = ghist + seg * BIG_BINS;
     if (n <= 0) {
@@ -465,7 +526,7 @@ __global__ __launch_bounds__(256) void k_big_next(const T *__restrict__ vals, co
                                                   int64_t tiles_per_seg) {
     using K = typename KeyT<T>::type;
     const int64_t seg = blockIdx.x / tiles_per_seg, tile = blockIdx.x % tiles_per_seg;
-    if (!st[seg].need_extra) return;
+    if (st[seg].resolved || !st[seg].need_extra) return;
     const int64_t n = seg_len ? seg_len[seg / len_div] : uniform_len;
     const int64_t i0 = tile * BIG_TILE;
     if (i0 >= n) return;
@@ -501,6 +562,7 @@ __global__ void k_big_finish(const BigState *__restrict__ st, const int64_t *__r
         out[seg] = __longlong_as_double(0x7FF8000000000000ll);
         return;
     }
+    if (s.resolved) return;              // written by the selection over the gathered keys
     int64_t r0, r1;
     double frac;
     big_ranks(n, mode, q, &r0, &r1, &frac);
@@ -519,11 +581,177 @@ __global__ void k_big_finish(const BigState *__restrict__ st, const int64_t *__r
     out[seg] = res;
 }
 
+// ---- bracket fast path ---------------------------------------------------------------
+// A sorted sample of BIG_SAMPLE keys brackets the wanted order statistics; one pass over the
+// segment counts the keys below the bracket and gathers those inside it; the exact selection
+// then runs on the few gathered keys.  If the statistics fall outside the bracket (or the
+// bracket holds too many keys, e.g. a constant segment) the radix passes above run instead.
+static constexpr int BIG_SAMPLE = 4096;
+
+template <typename T, int XF>
+__global__ __launch_bounds__(256) void k_big_sample(const T *__restrict__ vals, const int64_t *__restrict__ seg_off,
+                                                    int64_t seg_stride, const int64_t *__restrict__ seg_len,
+                                                    int64_t len_div, int64_t uniform_len,
+                                                    const double *__restrict__ center, BigState *__restrict__ st,
+                                                    int mode, double q) {
+    using K = typename KeyT<T>::type;
+    __shared__ K sk[BIG_SAMPLE];
+    const int64_t seg = blockIdx.x;
+    const int64_t n = seg_len ? seg_len[seg / len_div] : uniform_len;
+    const int tid = threadIdx.x;
+    if (n < 2 * BIG_SAMPLE) {                       // too short to be worth it: radix passes
+        if (tid == 0) {
+            st[seg].lo = 1;
+            st[seg].hi = 0;                         // empty bracket -> nothing gathered, unresolved
+        }
+        return;
+    }
+    const T *v = vals + (seg_off ? seg_off[seg] : seg * seg_stride);
+    const T c = XF == XF_ABSDEV ? (T)center[seg] : (T)0;
+    for (int j = tid; j < BIG_SAMPLE; j += 256) {
+        const int64_t i = (int64_t)(((double)j + 0.5) * (double)n / (double)BIG_SAMPLE);
+        T x = v[i < n ? i : n - 1];
+        if (XF == XF_ABSDEV) x = fabs(x - c);
+        sk[j] = x != x ? ~(K)0 : key_of(x);
+    }
+    __syncthreads();
+    for (int k = 2; k <= BIG_SAMPLE; k <<= 1)        // bitonic sort, ascending
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < BIG_SAMPLE / 2; t += 256) {
+                const int lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
+                const bool up = ((lo & k) == 0);
+                const K a = sk[lo], b = sk[hi];
+                if ((a > b) == up) {
+                    sk[lo] = b;
+                    sk[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    if (tid == 0) {
+        int64_t r0, r1;
+        double frac;
+        big_ranks(n, mode, q, &r0, &r1, &frac);
+        const double p = (double)r0 / (double)n;
+        const int delta = (int)(4.5 * sqrt((double)BIG_SAMPLE * p * (1.0 - p))) + 3;
+        const int rs = (int)((double)r0 * (double)BIG_SAMPLE / (double)n);
+        const int il = rs - delta, ih = rs + delta + 1;
+        st[seg].lo = il < 0 ? 0ull : (unsigned long long)sk[il];
+        st[seg].hi = ih >= BIG_SAMPLE ? ~0ull : (unsigned long long)sk[ih];
+    }
+}
+
+template <typename T, int XF>
+__global__ __launch_bounds__(256) void k_big_gather(const T *__restrict__ vals, const int64_t *__restrict__ seg_off,
+                                                    int64_t seg_stride, const int64_t *__restrict__ seg_len,
+                                                    int64_t len_div, int64_t uniform_len,
+                                                    const double *__restrict__ center, BigState *__restrict__ st,
+                                                    T *__restrict__ cand, int64_t cap, int64_t tiles_per_seg) {
+    using K = typename KeyT<T>::type;
+    constexpr int STAGE = 2048;                    // candidates staged per workgroup before one append
+    __shared__ T stage[STAGE];
+    __shared__ unsigned long long s_below;
+    __shared__ unsigned int s_fill, s_base;
+    __shared__ int s_nan;
+    const int64_t seg = blockIdx.x / tiles_per_seg, tile = blockIdx.x % tiles_per_seg;
+    const int64_t n = seg_len ? seg_len[seg / len_div] : uniform_len;
+    const int64_t i0 = tile * BIG_TILE;
+    if (i0 >= n) return;
+    const K lo = (K)st[seg].lo, hi = (K)st[seg].hi;
+    if (lo > hi) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) {
+        s_below = 0;
+        s_nan = 0;
+        s_fill = 0;
+    }
+    __syncthreads();
+    const T *v = vals + (seg_off ? seg_off[seg] : seg * seg_stride);
+    const T c = XF == XF_ABSDEV ? (T)center[seg] : (T)0;
+    T *dst = cand + seg * cap;
+    unsigned int below = 0;
+    bool saw_nan = false, spilled = false;
+#pragma unroll 4
+    for (int it = 0; it < BIG_TILE / 256; ++it) {
+        const int64_t i = i0 + it * 256 + tid;
+        const bool in = i < n;
+        T x = 0;
+        K k = 0;
+        if (in) {
+            x = v[i];
+            if (XF == XF_ABSDEV) x = fabs(x - c);
+            saw_nan |= (x != x);
+            k = x != x ? ~(K)0 : key_of(x);
+        }
+        below += (in && k < lo);
+        const bool keep = in && k >= lo && k <= hi;
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+            const int leader = __ffsll((long long)m) - 1;
+            unsigned int base = 0;
+            if (lane == leader) base = atomicAdd(&s_fill, (unsigned int)__popcll(m));
+            base = __shfl(base, leader);
+            const unsigned int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (keep) {
+                if (pos < STAGE) stage[pos] = x;
+                else spilled = true;                 // far more candidates than a bracket should hold
+            }
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) below += __shfl_xor(below, d);
+    if (lane == 0 && below) atomicAdd(&s_below, (unsigned long long)below);
+    if (saw_nan) s_nan = 1;
+    if (spilled) st[seg].overflow = 1;
+    __syncthreads();
+    const unsigned int cnt = s_fill < STAGE ? s_fill : STAGE;
+    if (tid == 0) {
+        s_base = cnt ? atomicAdd(&st[seg].n_cand, s_fill) : 0;     // s_fill (not cnt): overflow stays visible
+        if (s_below) atomicAdd(&st[seg].below, s_below);
+        if (s_nan) st[seg].has_nan = 1;
+    }
+    __syncthreads();
+    const int64_t base = s_base;
+    for (unsigned int p = tid; p < cnt; p += 256) {
+        if (base + p < cap) dst[base + p] = stage[p];
+        else st[seg].overflow = 1;
+    }
+}
+
+// per segment: did the bracket catch both order statistics?
+__global__ void k_big_check(BigState *st, const int64_t *seg_len, int64_t len_div, int64_t uniform_len,
+                            int64_t n_seg, int mode, double q, int64_t cap, int64_t *cand_len, int *valid,
+                            unsigned long long *below, unsigned long long *lohi) {
+    const int64_t seg = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (seg >= n_seg) return;
+    const int64_t n = seg_len ? seg_len[seg / len_div] : uniform_len;
+    BigState s = st[seg];
+    int ok = 0;
+    if (n > 0 && s.lo <= s.hi && !s.overflow && (int64_t)s.n_cand <= cap && !s.has_nan) {
+        int64_t r0, r1;
+        double frac;
+        big_ranks(n, mode, q, &r0, &r1, &frac);
+        ok = (unsigned long long)r0 >= s.below && (unsigned long long)r1 < s.below + s.n_cand;
+    }
+    st[seg].resolved = ok;
+    valid[seg] = ok;
+    cand_len[seg] = ok ? (int64_t)s.n_cand : 0;
+    below[seg] = s.below;
+    lohi[2 * seg] = s.lo;
+    lohi[2 * seg + 1] = s.hi;
+}
+
 int64_t select_short_limit() { return BIG_THRESHOLD; }
+
+static int64_t big_cand_cap(int64_t max_len) {
+    const int64_t c = max_len / 8 + 1024;
+    return c < 16384 ? 16384 : c;
+}
 
 size_t select_ws_bytes(int64_t n_seg, int64_t max_len) {
     if (max_len <= BIG_THRESHOLD) return 0;
-    return ws_need((size_t)n_seg, sizeof(BigState)) + ws_need((size_t)n_seg * BIG_BINS, sizeof(uint32_t));
+    return ws_need((size_t)n_seg, sizeof(BigState)) + ws_need((size_t)n_seg * BIG_BINS, sizeof(uint32_t)) +
+           ws_need((size_t)n_seg * big_cand_cap(max_len), 8) + 4 * ws_need((size_t)n_seg, 8) +
+           ws_need((size_t)n_seg, 4);
 }
 
 template <typename T, int XF>
@@ -531,6 +759,12 @@ static int launch_select_big(Ctx *c, const T *d_vals, const SelectArgs &a) {
     constexpr int BITS = KeyT<T>::bits;
     BigState *st = ws_take<BigState>(c, (size_t)a.n_seg);
     uint32_t *ghist = ws_take<uint32_t>(c, (size_t)a.n_seg * BIG_BINS);
+    const int64_t cap = big_cand_cap(a.max_len);
+    T *cand = reinterpret_cast<T *>(ws_take<double>(c, (size_t)a.n_seg * cap));
+    int64_t *cand_len = ws_take<int64_t>(c, (size_t)a.n_seg);
+    unsigned long long *below = ws_take<unsigned long long>(c, (size_t)a.n_seg);
+    int *valid = ws_take<int>(c, (size_t)a.n_seg);
+    unsigned long long *lohi = ws_take<unsigned long long>(c, 2 * (size_t)a.n_seg);
     if (c->ws_used > c->ws_bytes) {
         set_error("internal: workspace not reserved for the long-segment select");
         return ADN_ERR_NOMEM;
@@ -541,6 +775,27 @@ static int launch_select_big(Ctx *c, const T *d_vals, const SelectArgs &a) {
     ADN_HIP(hipMemsetAsync(ghist, 0, sizeof(uint32_t) * a.n_seg * BIG_BINS, c->stream));
     hipLaunchKernelGGL(k_big_init, dim3(nb), dim3(256), 0, c->stream, st, a.d_seg_len, a.len_div, a.uniform_len,
                        a.n_seg, a.mode, a.q);
+    // ---- bracket fast path: sample, count + gather, exact selection over the gathered keys
+    hipLaunchKernelGGL((k_big_sample<T, XF>), dim3((unsigned)a.n_seg), dim3(256), 0, c->stream, d_vals, a.d_seg_off,
+                       a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len, a.d_center, st, a.mode, a.q);
+    hipLaunchKernelGGL((k_big_gather<T, XF>), dim3((unsigned)(a.n_seg * tiles)), dim3(256), 0, c->stream, d_vals,
+                       a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len, a.d_center, st, cand, cap,
+                       tiles);
+    hipLaunchKernelGGL(k_big_check, dim3(nb), dim3(256), 0, c->stream, st, a.d_seg_len, a.len_div, a.uniform_len,
+                       a.n_seg, a.mode, a.q, cap, cand_len, valid, below, lohi);
+    {
+        using K = typename KeyT<T>::type;
+        int lds_keys = (int)(SEL_LDS_BYTES / sizeof(K));
+        const size_t dyn = 2 * (size_t)lds_keys * sizeof(K);
+        auto kern = k_select<T, XF_NONE>;
+        ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        MaskedMean mm{nullptr, 1, 0, nullptr};
+        SubsetRanks sub{a.d_seg_len, a.len_div, a.uniform_len, below, valid, lohi};
+        hipLaunchKernelGGL(kern, dim3((unsigned)a.n_seg), dim3(SEL_THREADS), dyn, c->stream, cand,
+                           (const int64_t *)nullptr, cap, cand_len, (int64_t)1, (int64_t)0, a.mode, a.q,
+                           (const double *)nullptr, a.d_out, lds_keys, mm, sub);
+    }
+    // ---- exact radix passes for whatever the bracket did not resolve (early exit otherwise)
     int remaining = BITS;
     bool first = true;
     while (remaining > 0) {
@@ -590,11 +845,11 @@ int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {
     if (a.xform == XF_ABSDEV) {
         hipLaunchKernelGGL((k_select<T, XF_ABSDEV>), grid, block, dyn, c->stream, d_vals,
                            a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len,
-                           a.mode, a.q, a.d_center, a.d_out, lds_keys, mm);
+                           a.mode, a.q, a.d_center, a.d_out, lds_keys, mm, SubsetRanks{nullptr, 1, 0, nullptr, nullptr, nullptr});
     } else {
         hipLaunchKernelGGL((k_select<T, XF_NONE>), grid, block, dyn, c->stream, d_vals,
                            a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len,
-                           a.mode, a.q, a.d_center, a.d_out, lds_keys, mm);
+                           a.mode, a.q, a.d_center, a.d_out, lds_keys, mm, SubsetRanks{nullptr, 1, 0, nullptr, nullptr, nullptr});
     }
     ADN_HIP(hipGetLastError());
     return ADN_OK;

@@ -154,3 +154,34 @@ def test_error_reporting():
         e.denoise_signal(x, 100)
     with pytest.raises(ValueError, match="shorter than 10 frames"):
         e.denoise_signal(dev(np.zeros(5)), 8000)
+
+
+def test_mad_long_segments_exact():
+    """Long segments take the sampled-bracket path and fall back to the radix passes when the
+    bracket cannot hold the statistics (constant data, heavy ties); results stay exact."""
+    e = engine()
+    rng = np.random.default_rng(3)
+    n = 200001
+    cases = {
+        "normal_odd": rng.standard_normal(n),
+        "normal_even": rng.standard_normal(n - 1),
+        "constant": np.full(n, 0.25),
+        "zeros": np.zeros(100000),
+        "ties": rng.integers(0, 4, n).astype(np.float64),
+        "lognormal": np.exp(3.0 * rng.standard_normal(n)),
+        "short_big_boundary": rng.standard_normal(40000),
+    }
+    for name, a in cases.items():
+        for dt, tol in ((torch.float64, 0.0), (torch.float32, 0.0)):
+            x = a.astype(np.float32 if dt == torch.float32 else np.float64)
+            got = float(e.mad(dev(x)))
+            want = float(orc.mad(x.astype(np.float64))) if dt == torch.float64 else \
+                float(np.median(np.abs(x - np.median(x))))
+            assert abs(got - want) <= tol + 1e-7 * abs(want) * (dt == torch.float32), (name, dt, got, want)
+    # several segments of different lengths in one call, one of them with a NaN
+    parts = [rng.standard_normal(150000), rng.standard_normal(70000), rng.standard_normal(33000)]
+    parts[1][123] = np.nan
+    flat = np.concatenate(parts)
+    got = host(e.mad(dev(flat), [p.size for p in parts]))
+    assert np.isnan(got[1])
+    assert got[0] == orc.mad(parts[0]) and got[2] == orc.mad(parts[2])
