@@ -114,13 +114,14 @@ __global__ __launch_bounds__(256) void k_fwd_level(const T *__restrict__ x, T *_
     T *cD = D + b * g.d_stride + band_off(n0, l, F, ext);
     T sa = 0, sd = 0;
     if (ext == ADN_EXT_PERIODIZATION) {
-        const int64_t M = N + (N & 1);
-        int64_t i = (2 * k + F / 2) % M;
+        // block lengths fit 32 bits: one 32-bit modulo, then the window walks backwards with wrap
+        const int Mi = (int)(N + (N & 1)), Ni = (int)N;
+        int i = (int)((2 * k + F / 2) % Mi);
         for (int j = 0; j < F; ++j) {
-            const T v = in[i < N ? i : N - 1];
+            const T v = in[i < Ni ? i : Ni - 1];
             sa += tp.h[j] * v;
             sd += tp.g[j] * v;
-            i = i == 0 ? M - 1 : i - 1;
+            i = i == 0 ? Mi - 1 : i - 1;
         }
     } else {
         for (int j = 0; j < F; ++j) {
@@ -171,15 +172,15 @@ __global__ __launch_bounds__(256) void k_inv_level(T *__restrict__ y, T *__restr
     T s = 0;
     if (live) {
         if (ext == ADN_EXT_PERIODIZATION) {
-            for (int j = 0; j < F; ++j) {
-                const int64_t u = n - j + (F / 2 - 1);
-                if (u & 1) continue;
-                int64_t k = u % (2 * K);
-                if (k < 0) k += 2 * K;
-                k >>= 1;
+            // y[n] = sum over the taps j of n's parity class; k walks backwards with wrap
+            const int Ki = (int)K;
+            const int par = (int)((n + F / 2 - 1) & 1);
+            int k = (int)(((n + F / 2 - 1 - par) >> 1) % Ki);
+            for (int j = par; j < F; j += 2) {
                 T dv = d[k];
                 if (do_thr) dv = shrink(dv, t, thr_mode);
                 s += tp.rl[j] * a[k] + tp.rh[j] * dv;
+                k = k == 0 ? Ki - 1 : k - 1;
             }
         } else {
             const int64_t m = n + F - 2;
