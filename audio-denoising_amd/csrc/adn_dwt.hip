@@ -6,9 +6,10 @@
 // Two execution paths for mono blocks (transform along time):
 //   * level-by-level kernels: any block length, any level, both extension modes;
 //     every level round-trips through the workspace.
-//   * fused tile kernels (adn_dwt_fused.hip): periodization, block length a
-//     multiple of 2^level, up to FUSED_MAX_LEVEL levels; one read of the block for
-//     the statistics and one read + one write for analysis, shrink and synthesis.
+//   * fused tile kernels (adn_dwt_tiles.hpp): periodization, any block length; up to
+//     four levels stay in LDS per tile (deeper levels run on the level-4 approximation
+//     in one workgroup per block): one read of the block for the statistics and one
+//     read + one write for analysis, shrink and synthesis.  Used by wavelet_denoise.
 // Multi-channel blocks are transformed across the channel axis of every frame, as
 // the reference does (pywt's default axis is the last one); that per-frame
 // transform is a tiny linear map, built on the host and applied from registers.
@@ -404,13 +405,6 @@ __global__ __launch_bounds__(256) void k_ch_apply(const T *__restrict__ x, T *__
 
 // ---------------------------------------------------------- host drivers
 template <typename T>
-int wavelet_denoise_fused(Ctx *c, const T *d_in, T *d_out, int64_t n_blocks,
-                          const int64_t *d_in_off, const int64_t *d_frames,
-                          const int64_t *d_out_off, int64_t max_frames, int wavelet, int level,
-                          int thr_mode, double *d_sigma, double *d_thresh, int64_t *d_zeroed,
-                          bool *handled);
-
-template <typename T>
 static int mad_threshold(Ctx *c, const T *D, const BlockGeom &g, int F, int ext,
                          int64_t per_frame, int64_t max_seg, double *d_sigma_out,
                          double *d_thresh_out, double **thresh_ws) {
@@ -445,6 +439,8 @@ static size_t mad_ws_bytes(int64_t n_blocks, int64_t max_seg) {
     return 2 * ws_need(n_blocks, sizeof(int64_t)) + 3 * ws_need(n_blocks, sizeof(double)) +
            2 * select_ws_bytes(n_blocks, max_seg);
 }
+
+#include "adn_dwt_tiles.hpp"
 
 template <typename T, int NCH>
 static int channel_denoise(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_frames,
@@ -514,9 +510,8 @@ int wavelet_denoise(Ctx *c, const T *d_in, T *d_out, int64_t n_blocks, const int
     BlockGeom g{d_in_off, d_frames, d_out_off, n_blocks, 0, 0};
     if (n_ch == 1) {
         bool handled = false;
-        ADN_TRY(wavelet_denoise_fused<T>(c, d_in, d_out, n_blocks, d_in_off, d_frames, d_out_off,
-                                         max_frames, wavelet, level, thr_mode, d_sigma, d_thresh,
-                                         d_zeroed, &handled));
+        ADN_TRY(wavelet_denoise_fused<T>(c, d_in, d_out, g, max_frames, wavelet, level, thr_mode,
+                                         d_sigma, d_thresh, d_zeroed, &handled));
         if (handled) return ADN_OK;
         return general_denoise<T>(c, d_in, d_out, g, max_frames, wavelet, level, thr_mode, d_sigma,
                                   d_thresh, d_zeroed);

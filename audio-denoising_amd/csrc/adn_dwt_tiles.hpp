@@ -1,0 +1,565 @@
+// Fused tile kernels of the mono (time-axis, periodization) VisuShrink block denoiser.
+// Included by adn_dwt.hip (inside namespace adn, after Taps / shrink / BlockGeom / mad_threshold).
+//
+// One workgroup owns S consecutive samples of one block and keeps TL <= 4 transform levels
+// in LDS: pywt.wavedec (denoise.py:77), pywt.threshold (denoise.py:84) and pywt.waverec
+// (denoise.py:87) of those levels cost one read of the block for the statistics pass and one
+// read + one write for the apply pass.  Levels above TL (level > 4) run on the level-TL
+// approximation of the whole block, in one workgroup per block (k_deep).
+//
+// Index scheme.  For each in-tile level l the kernel holds a CANONICAL CONTIGUOUS RANGE of
+// the level's arrays: elements (s + i) mod N_l, i < c.  A tile whose ranges neither wrap nor
+// touch the replicated pad sample of an odd-length level ("interior") uses direct indexing;
+// every other tile evaluates pywt's periodization formulas with exact modular arithmetic,
+// so any block length (odd lengths at any level, blocks shorter than a tile) is covered.
+#pragma once
+
+namespace tiles {
+
+enum { MODE_STATS = 0, MODE_APPLY = 1 };
+constexpr int TL_MAX = 4;
+constexpr int THREADS = 256;
+
+template <typename T, int F>
+struct TapsF {
+    T h[F], g[F], rl[F], rh[F];
+};
+
+template <typename T, int F>
+static TapsF<T, F> make_taps_f(int wavelet) {
+    const FilterBank &b = filter_bank(wavelet);
+    TapsF<T, F> t{};
+    for (int j = 0; j < F; ++j) {
+        t.h[j] = (T)b.h[j];
+        t.g[j] = (T)b.g[j];
+        t.rl[j] = (T)b.rl[j];
+        t.rh[j] = (T)b.rh[j];
+    }
+    return t;
+}
+
+// canonical contiguous range: indices (s + i) mod N for i < c
+struct Rg {
+    int s, c, N;
+};
+__device__ __forceinline__ Rg rg_make(int s, int c, int N) {
+    if (c >= N) return Rg{0, N, N};
+    int m = s % N;
+    if (m < 0) m += N;
+    return Rg{m, c, N};
+}
+__device__ __forceinline__ int rg_local(const Rg &r, int q) {
+    int li = q - r.s;
+    if (li < 0) li += r.N;
+    return li < r.c ? li : r.c - 1;   // a miss cannot happen (ranges carry margins); stay in bounds anyway
+}
+__device__ __forceinline__ int rg_canon(const Rg &r, int i) {
+    const int q = r.s + i;
+    return q >= r.N ? q - r.N : q;
+}
+__device__ __forceinline__ bool rg_wraps(const Rg &r) { return r.s + r.c > r.N; }
+
+// Unwrapped first / last coefficient index of level l feeding outputs [lo, lo+cnt) of level
+// l-1.  One extra index on each side: when the output range wraps around an ODD length the
+// coefficient index of the wrapped outputs shifts by one (2 * N_l = N_{l-1} + 1).
+template <int F>
+__host__ __device__ constexpr int inv_lo(int lo) { return ((lo - F / 2) >> 1) - 1; }
+template <int F>
+__host__ __device__ constexpr int inv_hi(int lo, int cnt) { return ((lo + cnt - 1 + F / 2 - 1) >> 1) + 1; }
+
+// compile-time upper bounds of the range counts (mirrors make_plan) and the LDS layout
+template <int S, int F, int TL>
+struct Cap {
+    int ic[TL + 2], gc[TL + 2];     // bounds of I_l.c / G_l.c
+    int offA[TL + 2], offD[TL + 2]; // element offsets of A_l (l = 0..TL) and D_l (l = 1..TL)
+    int total;
+    constexpr Cap() : ic{}, gc{}, offA{}, offD{}, total(0) {
+        ic[0] = S;
+        for (int l = 1; l <= TL; ++l) ic[l] = (ic[l - 1] + F) / 2 + 3;
+        gc[TL] = ic[TL];
+        for (int l = TL - 1; l >= 0; --l) gc[l] = 2 * (gc[l + 1] - 1) + F + 3;
+        int off = 0;
+        for (int l = 0; l <= TL; ++l) {
+            offA[l] = off;
+            off += (gc[l] + 3) & ~1;    // +1 for the alignment shift, rounded to even
+        }
+        offD[0] = off;
+        for (int l = 1; l <= TL; ++l) {
+            offD[l] = off;
+            off += (ic[l] + 3) & ~1;
+        }
+        total = off;
+    }
+};
+
+template <int TL>
+struct Plan {
+    int N[TL + 1], M[TL + 1];
+    Rg G[TL + 1];      // range of A_l (and of the level-l outputs the forward pass computes)
+    Rg I[TL + 1];      // apply: range of R_l / D_l the synthesis needs; stats: owned coefficients
+    int own_lo[TL + 1], own_hi[TL + 1];   // coefficients this tile owns (counted / exported once)
+    bool interior;
+};
+
+template <int F, int TL, int MODE>
+__device__ __forceinline__ Plan<TL> make_plan(int n, int n0, int n1) {
+    Plan<TL> p;
+    p.N[0] = n;
+#pragma unroll
+    for (int l = 0; l < TL; ++l) {
+        p.M[l] = p.N[l] + (p.N[l] & 1);
+        p.N[l + 1] = p.M[l] >> 1;
+    }
+    p.M[TL] = p.N[TL] + (p.N[TL] & 1);
+    bool interior = true;
+    {
+        int lo = n0, hi = n1;
+        p.own_lo[0] = n0;
+        p.own_hi[0] = n1;
+#pragma unroll
+        for (int l = 1; l <= TL; ++l) {
+            lo >>= 1;
+            hi = (hi + 1) >> 1;
+            p.own_lo[l] = lo;
+            p.own_hi[l] = hi < p.N[l] ? hi : p.N[l];
+        }
+    }
+    if (MODE == MODE_APPLY) {
+        int lo = n0, cnt = n1 - n0;
+#pragma unroll
+        for (int l = 1; l <= TL; ++l) {
+            const int klo = inv_lo<F>(lo), khi = inv_hi<F>(lo, cnt);
+            p.I[l] = rg_make(klo, khi - klo + 1, p.N[l]);
+            interior = interior && klo >= 0 && khi <= p.N[l] - 1;
+            lo = klo;
+            cnt = khi - klo + 1;
+        }
+    } else {
+#pragma unroll
+        for (int l = 1; l <= TL; ++l) {
+            const int c = p.own_hi[l] - p.own_lo[l];
+            p.I[l] = rg_make(p.own_lo[l], c > 0 ? c : 0, p.N[l]);
+        }
+    }
+    p.I[0] = Rg{0, 0, 1};
+    p.G[TL] = p.I[TL];
+#pragma unroll
+    for (int l = TL - 1; l >= 0; --l) {
+        const Rg &g = p.G[l + 1];
+        const int lo = 2 * g.s - F / 2 + 1;
+        const int cnt = 2 * (g.c - 1) + F + 2;   // +2: the replicated pad sample shifts indices by one
+        int lo_c = lo % p.M[l];
+        if (lo_c < 0) lo_c += p.M[l];
+        if (lo_c == p.N[l]) lo_c = p.N[l] - 1;   // landed on the pad position
+        p.G[l] = rg_make(lo_c - 1, cnt + 1, p.N[l]);
+        interior = interior && lo >= 0 && 2 * (g.s + g.c - 1) + F / 2 <= p.N[l] - 1;
+    }
+#pragma unroll
+    for (int l = 0; l <= TL; ++l) interior = interior && !rg_wraps(p.G[l]);
+    p.interior = interior;
+    return p;
+}
+
+template <typename T> struct Vec2T;
+template <> struct Vec2T<float> { using type = float2; };
+template <> struct Vec2T<double> { using type = double2; };
+
+// One tile.  STATS: writes the owned finest-band details to d1_out (and, when top != null, the
+// owned level-TL approximation to top).  APPLY: analysis, shrink, synthesis of TL levels; the
+// level-TL approximation comes from `top` when use_top (output of k_deep), else from the
+// tile's own analysis.
+template <typename T, int F, int TL, int S, int MODE>
+__global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__restrict__ y,
+                                                  BlockGeom g, int tiles_per_block,
+                                                  TapsF<T, F> tp, const double *__restrict__ thresh,
+                                                  int thr_mode, int64_t *__restrict__ zeroed,
+                                                  T *__restrict__ d1_out, int64_t d1_stride,
+                                                  T *__restrict__ top, int64_t top_stride,
+                                                  int use_top, int ablate) {
+    constexpr Cap<S, F, TL> cap{};
+    using V2 = typename Vec2T<T>::type;
+    __shared__ __attribute__((aligned(16))) T lds[cap.total];
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x / tiles_per_block;
+    const int tile = (int)(blockIdx.x % tiles_per_block);
+    const int n = (int)g.frames[b];
+    const int n_lim = MODE == MODE_APPLY ? n + (n & 1) : n;
+    const int n0 = tile * S;
+    if (n0 >= n_lim) return;
+    const int n1 = n0 + S < n_lim ? n0 + S : n_lim;
+    const Plan<TL> p = make_plan<F, TL, MODE>(n, n0, n1);
+    const bool interior = p.interior;
+
+    // alignment shift of every forward source array: window starts land on even LDS indices
+    int sh[TL + 1];
+#pragma unroll
+    for (int l = 0; l < TL; ++l) sh[l] = (2 * p.G[l + 1].s + F / 2 - p.G[l].s - F + 1) & 1;
+    sh[TL] = 0;
+
+    // ---- level 0 from memory
+    {
+        const T *in = x + g.in_off[b];
+        T *A0 = lds + cap.offA[0] + sh[0];
+        const Rg r = p.G[0];
+        if (interior) {
+            for (int i = tid; i < r.c; i += THREADS) A0[i] = in[r.s + i];
+        } else {
+            for (int i = tid; i < r.c; i += THREADS) A0[i] = in[rg_canon(r, i)];
+        }
+    }
+    __syncthreads();
+
+    // ---- analysis
+#pragma unroll
+    for (int l = 1; l <= TL; ++l) {
+        if (ablate & 1) break;
+        const T *src = lds + cap.offA[l - 1] + sh[l - 1];
+        T *dA = lds + cap.offA[l] + sh[l];
+        T *dD = lds + cap.offD[l];
+        const Rg sr = p.G[l - 1], dr = p.G[l], ir = p.I[l];
+        const int Ns = p.N[l - 1], Ms = p.M[l - 1];
+        if (interior) {
+            const int off_lo = 2 * dr.s + F / 2 - sr.s - F + 1;   // window start of output 0
+            const int dI = ir.s - dr.s;
+            for (int i = tid; i < dr.c; i += THREADS) {
+                const V2 *w = reinterpret_cast<const V2 *>(src + off_lo + 2 * i);
+                T sa = 0, sd = 0;
+                // window element t pairs with tap F-1-t; keep pywt's summation order (tap 0 first)
+                T v[F];
+#pragma unroll
+                for (int t = 0; t < F / 2; ++t) {
+                    const V2 q = w[t];
+                    v[2 * t] = q.x;
+                    v[2 * t + 1] = q.y;
+                }
+#pragma unroll
+                for (int j = 0; j < F; ++j) {
+                    sa += tp.h[j] * v[F - 1 - j];
+                    sd += tp.g[j] * v[F - 1 - j];
+                }
+                dA[i] = sa;
+                if (MODE == MODE_APPLY) {
+                    const int il = i - dI;
+                    if (il >= 0 && il < ir.c) dD[il] = sd;
+                } else if (l == 1) {
+                    const int k = dr.s + i;
+                    if (k >= p.own_lo[1] && k < p.own_hi[1]) d1_out[b * d1_stride + k] = sd;
+                }
+            }
+        } else {
+            for (int i = tid; i < dr.c; i += THREADS) {
+                const int k = rg_canon(dr, i);
+                int idx = 2 * k + F / 2;
+                while (idx >= Ms) idx -= Ms;   // at most F/2/Ms + 1 rounds
+                T sa = 0, sd = 0;
+#pragma unroll
+                for (int j = 0; j < F; ++j) {
+                    const int q = idx < Ns ? idx : Ns - 1;
+                    const T v = src[rg_local(sr, q)];
+                    sa += tp.h[j] * v;
+                    sd += tp.g[j] * v;
+                    idx = idx == 0 ? Ms - 1 : idx - 1;
+                }
+                dA[i] = sa;
+                if (MODE == MODE_APPLY) {
+                    int il = k - ir.s;
+                    if (il < 0) il += ir.N;
+                    if (il < ir.c) dD[il] = sd;
+                } else if (l == 1) {
+                    if (k >= p.own_lo[1] && k < p.own_hi[1]) d1_out[b * d1_stride + k] = sd;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (MODE == MODE_STATS) {
+        if (top != nullptr) {
+            const T *aT = lds + cap.offA[TL];
+            const Rg r = p.G[TL];
+            for (int i = tid; i < r.c; i += THREADS) {
+                const int k = rg_canon(r, i);
+                if (k >= p.own_lo[TL] && k < p.own_hi[TL]) top[b * top_stride + k] = aT[i];
+            }
+        }
+        return;
+    }
+
+    // ---- shrink the details in place, count the zeroed ones this tile owns
+    const T t = (T)thresh[b];
+    int nz = 0;
+#pragma unroll
+    for (int l = 1; l <= TL; ++l) {
+        if (ablate & 2) break;
+        T *dD = lds + cap.offD[l];
+        const Rg ir = p.I[l];
+        for (int i = tid; i < ir.c; i += THREADS) {
+            const int k = rg_canon(ir, i);
+            const T d = dD[i];
+            nz += (k >= p.own_lo[l] && k < p.own_hi[l] && fabs(d) < t) ? 1 : 0;
+            dD[i] = shrink(d, t, thr_mode);
+        }
+    }
+    if (use_top) {
+        T *aT = lds + cap.offA[TL];
+        const Rg r = p.I[TL];
+        for (int i = tid; i < r.c; i += THREADS) aT[i] = top[b * top_stride + rg_canon(r, i)];
+    }
+    if (zeroed != nullptr) {
+        for (int d = 32; d >= 1; d >>= 1) nz += __shfl_xor(nz, d);
+        if ((tid & 63) == 0 && nz) atomicAdd((unsigned long long *)&zeroed[b], (unsigned long long)nz);
+    }
+    __syncthreads();
+
+    // ---- synthesis: R_{l-1} from R_l (in A_l's storage, I_l-local) and the shrunk D_l
+#pragma unroll
+    for (int l = TL; l >= 1; --l) {
+        if ((ablate & 4) && l > 1) continue;
+        const T *ra = lds + cap.offA[l] + (l == TL ? sh[TL] : 0);
+        const T *rd = lds + cap.offD[l];
+        const Rg ir = p.I[l];
+        const Rg orr = l > 1 ? p.I[l - 1] : Rg{n0, n1 - n0, 2 * p.N[1]};
+        T *out = l > 1 ? lds + cap.offA[l - 1] : y + g.out_off[b] + n0;
+        const int K = p.N[l];
+        if (interior) {
+            const int m0 = orr.s >> 1, m1 = (orr.s + orr.c - 1) >> 1;
+            for (int m = m0 + tid; m <= m1; m += THREADS) {
+                if (ablate & 8) {
+                    const int io = 2 * m - orr.s;
+                    if (io >= 0) out[io] = ra[(m - ir.s) & 1023];
+                    if (io + 1 < orr.c) out[io + 1] = rd[(m - ir.s) & 1023];
+                    continue;
+                }
+                const int lb = m - F / 4 - ir.s;
+                T a[F / 2 + 1], d[F / 2 + 1];
+#pragma unroll
+                for (int q = 0; q <= F / 2; ++q) {
+                    a[q] = ra[lb + q];
+                    d[q] = rd[lb + q];
+                }
+                T ye = 0, yo = 0;
+#pragma unroll
+                for (int q = 0; q < F / 2; ++q) {
+                    ye += tp.rl[2 * q + 1] * a[F / 2 - 1 - q] + tp.rh[2 * q + 1] * d[F / 2 - 1 - q];
+                    yo += tp.rl[2 * q] * a[F / 2 - q] + tp.rh[2 * q] * d[F / 2 - q];
+                }
+                const int io = 2 * m - orr.s;
+                if (io >= 0) out[io] = ye;
+                if (io + 1 < orr.c) out[io + 1] = yo;
+            }
+        } else {
+            for (int i = tid; i < orr.c; i += THREADS) {
+                const int nn = rg_canon(orr, i);
+                const int par = (nn + F / 2 - 1) & 1;
+                int k = (nn + F / 2 - 1 - par) >> 1;
+                while (k >= K) k -= K;       // at most (F/4)/K + 1 rounds; K >= 1
+                T s = 0;
+#pragma unroll
+                for (int q = 0; q < F / 2; ++q) {
+                    const int li = rg_local(ir, k);
+                    const T cl = par ? tp.rl[2 * q + 1] : tp.rl[2 * q];
+                    const T ch = par ? tp.rh[2 * q + 1] : tp.rh[2 * q];
+                    s += cl * ra[li] + ch * rd[li];
+                    k = k == 0 ? K - 1 : k - 1;
+                }
+                out[i] = s;
+            }
+        }
+        if (l > 1) __syncthreads();
+    }
+}
+
+// Levels TL+1 .. L of one block on the level-TL approximation (whole arrays in LDS, exact
+// modular indexing): analysis, shrink + zero count, synthesis back to level TL, in place in `top`.
+template <typename T, int F>
+__global__ __launch_bounds__(512) void k_deep(T *__restrict__ top, int64_t top_stride, BlockGeom g,
+                                              int TL, int L, TapsF<T, F> tp,
+                                              const double *__restrict__ thresh, int thr_mode,
+                                              int64_t *__restrict__ zeroed) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *lds = reinterpret_cast<T *>(smem_raw);
+    __shared__ int offA[34], offD[34], NN[34];
+    const int tid = threadIdx.x, NT = 512;
+    const int64_t b = blockIdx.x;
+    if (tid == 0) {
+        int n = (int)g.frames[b];
+        for (int l = 0; l < TL; ++l) n = (n + 1) >> 1;
+        int off = 0;
+        for (int l = TL; l <= L; ++l) {
+            NN[l] = n;
+            offA[l] = off;
+            off += n;
+            if (l > TL) {
+                offD[l] = off;
+                off += n;
+            }
+            n = (n + 1) >> 1;
+        }
+    }
+    __syncthreads();
+    T *tp_io = top + b * top_stride;
+    for (int i = tid; i < NN[TL]; i += NT) lds[offA[TL] + i] = tp_io[i];
+    __syncthreads();
+    for (int l = TL + 1; l <= L; ++l) {
+        const T *src = lds + offA[l - 1];
+        T *dA = lds + offA[l], *dD = lds + offD[l];
+        const int Ns = NN[l - 1], Ms = Ns + (Ns & 1), K = NN[l];
+        for (int k = tid; k < K; k += NT) {
+            int idx = 2 * k + F / 2;
+            while (idx >= Ms) idx -= Ms;
+            T sa = 0, sd = 0;
+#pragma unroll
+            for (int j = 0; j < F; ++j) {
+                const T v = src[idx < Ns ? idx : Ns - 1];
+                sa += tp.h[j] * v;
+                sd += tp.g[j] * v;
+                idx = idx == 0 ? Ms - 1 : idx - 1;
+            }
+            dA[k] = sa;
+            dD[k] = sd;
+        }
+        __syncthreads();
+    }
+    const T t = (T)thresh[b];
+    int nz = 0;
+    for (int l = TL + 1; l <= L; ++l) {
+        T *dD = lds + offD[l];
+        for (int k = tid; k < NN[l]; k += NT) {
+            const T d = dD[k];
+            nz += fabs(d) < t ? 1 : 0;
+            dD[k] = shrink(d, t, thr_mode);
+        }
+    }
+    if (zeroed != nullptr) {
+        for (int d = 32; d >= 1; d >>= 1) nz += __shfl_xor(nz, d);
+        if ((tid & 63) == 0 && nz) atomicAdd((unsigned long long *)&zeroed[b], (unsigned long long)nz);
+    }
+    __syncthreads();
+    for (int l = L; l > TL; --l) {
+        const T *ra = lds + offA[l], *rd = lds + offD[l];
+        T *out = lds + offA[l - 1];
+        const int K = NN[l], n_out = NN[l - 1];   // waverec drops the extra sample of an odd level
+        for (int nn = tid; nn < n_out; nn += NT) {
+            const int par = (nn + F / 2 - 1) & 1;
+            int k = (nn + F / 2 - 1 - par) >> 1;
+            while (k >= K) k -= K;
+            T s = 0;
+#pragma unroll
+            for (int q = 0; q < F / 2; ++q) {
+                const T cl = par ? tp.rl[2 * q + 1] : tp.rl[2 * q];
+                const T ch = par ? tp.rh[2 * q + 1] : tp.rh[2 * q];
+                s += cl * ra[k] + ch * rd[k];
+                k = k == 0 ? K - 1 : k - 1;
+            }
+            out[nn] = s;
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < NN[TL]; i += NT) tp_io[i] = lds[offA[TL] + i];
+}
+
+template <typename T> struct TileS;
+template <> struct TileS<float> { static constexpr int S = 4096; };
+template <> struct TileS<double> { static constexpr int S = 2048; };
+
+template <typename T, int F, int TL, int MODE>
+static void launch_tile(Ctx *c, const T *x, T *y, const BlockGeom &g, int64_t max_frames, int wavelet,
+                        const double *thresh, int thr_mode, int64_t *zeroed, T *d1, int64_t d1_stride,
+                        T *top, int64_t top_stride, int use_top) {
+    constexpr int S = TileS<T>::S;
+    const int tiles = (int)ceil_div(max_frames + 1, S);
+    const TapsF<T, F> tp = make_taps_f<T, F>(wavelet);
+    hipLaunchKernelGGL((k_tile<T, F, TL, S, MODE>), dim3((unsigned)(tiles * g.n_blocks)), dim3(THREADS),
+                       0, c->stream, x, y, g, tiles, tp, thresh, thr_mode, zeroed, d1, d1_stride, top,
+                       top_stride, use_top, c->ablate);
+}
+
+template <typename T, int F, int MODE>
+static void launch_tile_tl(Ctx *c, int TL, const T *x, T *y, const BlockGeom &g, int64_t max_frames,
+                           int wavelet, const double *thresh, int thr_mode, int64_t *zeroed, T *d1,
+                           int64_t d1_stride, T *top, int64_t top_stride, int use_top) {
+    switch (TL) {
+        case 1: launch_tile<T, F, 1, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top); break;
+        case 2: launch_tile<T, F, 2, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top); break;
+        case 3: launch_tile<T, F, 3, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top); break;
+        default: launch_tile<T, F, 4, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top); break;
+    }
+}
+
+// LDS bytes k_deep needs for the longest block
+template <typename T>
+static size_t deep_lds_bytes(int64_t max_frames, int TL, int L) {
+    int64_t n = max_frames;
+    for (int l = 0; l < TL; ++l) n = (n + 1) / 2;
+    size_t total = 0;
+    for (int l = TL; l <= L; ++l) {
+        total += (size_t)n * (l > TL ? 2 : 1);
+        n = (n + 1) / 2;
+    }
+    return total * sizeof(T) + 16;
+}
+
+template <typename T, int F>
+static int denoise_f(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_frames, int wavelet,
+                     int level, int thr_mode, double *d_sigma, double *d_thresh, int64_t *d_zeroed,
+                     bool *handled) {
+    const int TL = level < TL_MAX ? level : TL_MAX;
+    const bool deep = level > TL;
+    size_t deep_lds = 0;
+    if (deep) {
+        deep_lds = deep_lds_bytes<T>(max_frames, TL, level);
+        if (deep_lds > 158 * 1024) return ADN_OK;   // the level-TL approximation does not fit one CU's LDS
+    }
+    const int64_t d1_stride = (max_frames + 1) / 2 + 1;
+    int64_t top_stride = max_frames;
+    for (int l = 0; l < TL; ++l) top_stride = (top_stride + 1) / 2;
+    top_stride += 1;
+    g.d_stride = d1_stride;
+    const size_t nD = (size_t)g.n_blocks * d1_stride, nT = deep ? (size_t)g.n_blocks * top_stride : 0;
+    ADN_TRY(ws_reserve(c, ws_need(nD, sizeof(T)) + ws_need(nT, sizeof(T)) +
+                              mad_ws_bytes(g.n_blocks, (max_frames + 1) / 2)));
+    T *D1 = ws_take<T>(c, nD);
+    T *top = deep ? ws_take<T>(c, nT) : nullptr;
+    if (deep)
+        launch_tile_tl<T, F, MODE_STATS>(c, TL, d_in, (T *)nullptr, g, max_frames, wavelet, nullptr, thr_mode,
+                                         nullptr, D1, d1_stride, top, top_stride, 0);
+    else
+        launch_tile_tl<T, F, MODE_STATS>(c, 1, d_in, (T *)nullptr, g, max_frames, wavelet, nullptr, thr_mode,
+                                         nullptr, D1, d1_stride, (T *)nullptr, 0, 0);
+    double *thresh = nullptr;
+    ADN_TRY(mad_threshold<T>(c, D1, g, F, ADN_EXT_PERIODIZATION, 0, (max_frames + 1) / 2, d_sigma, d_thresh,
+                             &thresh));
+    if (deep) {
+        const TapsF<T, F> tp = make_taps_f<T, F>(wavelet);
+        if (deep_lds > 48 * 1024)
+            ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_deep<T, F>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)deep_lds));
+        hipLaunchKernelGGL((k_deep<T, F>), dim3((unsigned)g.n_blocks), dim3(512), deep_lds, c->stream, top,
+                           top_stride, g, TL, level, tp, thresh, thr_mode, d_zeroed);
+    }
+    launch_tile_tl<T, F, MODE_APPLY>(c, TL, d_in, d_out, g, max_frames, wavelet, thresh, thr_mode, d_zeroed,
+                                     (T *)nullptr, 0, top, top_stride, deep ? 1 : 0);
+    ADN_HIP(hipGetLastError());
+    *handled = true;
+    return ADN_OK;
+}
+
+}  // namespace tiles
+
+// Mono blocks through the tile kernels.  *handled stays false when the batch is outside
+// their limits (block length >= 2^30, or level > 4 with a level-4 approximation too long
+// for one CU's LDS); the caller then takes the level-by-level path.
+template <typename T>
+static int wavelet_denoise_fused(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_frames,
+                                 int wavelet, int level, int thr_mode, double *d_sigma,
+                                 double *d_thresh, int64_t *d_zeroed, bool *handled) {
+    *handled = false;
+    if (c->force_generic || max_frames >= (int64_t(1) << 30)) return ADN_OK;
+    const int64_t tiles = ceil_div(max_frames + 1, tiles::TileS<T>::S);
+    if (tiles * g.n_blocks >= (int64_t)0x7FFFFFFF) return ADN_OK;
+    if (filter_bank(wavelet).F == 8)
+        return tiles::denoise_f<T, 8>(c, d_in, d_out, g, max_frames, wavelet, level, thr_mode, d_sigma,
+                                      d_thresh, d_zeroed, handled);
+    return tiles::denoise_f<T, 16>(c, d_in, d_out, g, max_frames, wavelet, level, thr_mode, d_sigma,
+                                   d_thresh, d_zeroed, handled);
+}

@@ -596,6 +596,8 @@ __global__ __launch_bounds__(256) void k_big_sample(const T *__restrict__ vals, 
                                                     int mode, double q) {
     using K = typename KeyT<T>::type;
     __shared__ K sk[BIG_SAMPLE];
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned int s_digit, s_rank;
     const int64_t seg = blockIdx.x;
     const int64_t n = seg_len ? seg_len[seg / len_div] : uniform_len;
     const int tid = threadIdx.x;
@@ -608,36 +610,68 @@ __global__ __launch_bounds__(256) void k_big_sample(const T *__restrict__ vals, 
     }
     const T *v = vals + (seg_off ? seg_off[seg] : seg * seg_stride);
     const T c = XF == XF_ABSDEV ? (T)center[seg] : (T)0;
+    // stratified sample: BIG_SAMPLE / RUN evenly spaced runs of RUN consecutive elements (one or
+    // two cache lines per run instead of one line per sample)
+    constexpr int RUN = 16, NRUN = BIG_SAMPLE / RUN;
     for (int j = tid; j < BIG_SAMPLE; j += 256) {
-        const int64_t i = (int64_t)(((double)j + 0.5) * (double)n / (double)BIG_SAMPLE);
-        T x = v[i < n ? i : n - 1];
+        const int run = j / RUN, w = j % RUN;
+        int64_t i = (int64_t)(((double)run + 0.5) * (double)n / (double)NRUN) - RUN / 2 + w;
+        i = i < 0 ? 0 : (i < n ? i : n - 1);
+        T x = v[i];
         if (XF == XF_ABSDEV) x = fabs(x - c);
         sk[j] = x != x ? ~(K)0 : key_of(x);
     }
-    __syncthreads();
-    for (int k = 2; k <= BIG_SAMPLE; k <<= 1)        // bitonic sort, ascending
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < BIG_SAMPLE / 2; t += 256) {
-                const int lo = ((t / j) * 2 * j) + (t % j), hi = lo + j;
-                const bool up = ((lo & k) == 0);
-                const K a = sk[lo], b = sk[hi];
-                if ((a > b) == up) {
-                    sk[lo] = b;
-                    sk[hi] = a;
+    int64_t r0, r1;
+    double frac;
+    big_ranks(n, mode, q, &r0, &r1, &frac);
+    const double p = (double)r0 / (double)n;
+    const int delta = (int)(4.5 * sqrt((double)BIG_SAMPLE * p * (1.0 - p))) + 3;
+    const int rs = (int)((double)r0 * (double)BIG_SAMPLE / (double)n);
+    const int want[2] = {rs - delta, rs + delta + 1};
+    K found[2] = {(K)0, ~(K)0};
+    // two order statistics of the sample by 8-bit MSD radix selection (no full sort)
+    constexpr int BITS = KeyT<T>::bits;
+    for (int which = 0; which < 2; ++which) {
+        int rank = want[which];
+        if (rank < 0 || rank >= BIG_SAMPLE) continue;   // open end of the bracket
+        K prefix = 0;
+        for (int shift = BITS - 8; shift >= 0; shift -= 8) {
+            hist[tid] = 0;
+            __syncthreads();
+            for (int j = tid; j < BIG_SAMPLE; j += 256) {
+                const K k = sk[j];
+                const bool match = shift == BITS - 8 || ((k ^ prefix) >> (shift + 8 < BITS ? shift + 8 : 0)) == 0;
+                if (match) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const unsigned c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+                const unsigned sum = c0 + c1 + c2 + c3;
+                unsigned incl = sum;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const unsigned o = __shfl_up(incl, d);
+                    if (tid >= d) incl += o;
+                }
+                const unsigned long long m = __ballot(incl > (unsigned)rank);
+                if (m && tid == (int)__ffsll((unsigned long long)m) - 1) {
+                    unsigned r = (unsigned)rank - (incl - sum);
+                    int dgt = 4 * tid;
+                    if (r >= c0) { r -= c0; ++dgt;
+                        if (r >= c1) { r -= c1; ++dgt;
+                            if (r >= c2) { r -= c2; ++dgt; } } }
+                    s_digit = (unsigned)dgt;
+                    s_rank = r;
                 }
             }
             __syncthreads();
+            prefix |= (K)s_digit << shift;
+            rank = (int)s_rank;
         }
+        found[which] = prefix;
+    }
     if (tid == 0) {
-        int64_t r0, r1;
-        double frac;
-        big_ranks(n, mode, q, &r0, &r1, &frac);
-        const double p = (double)r0 / (double)n;
-        const int delta = (int)(4.5 * sqrt((double)BIG_SAMPLE * p * (1.0 - p))) + 3;
-        const int rs = (int)((double)r0 * (double)BIG_SAMPLE / (double)n);
-        const int il = rs - delta, ih = rs + delta + 1;
-        st[seg].lo = il < 0 ? 0ull : (unsigned long long)sk[il];
-        st[seg].hi = ih >= BIG_SAMPLE ? ~0ull : (unsigned long long)sk[ih];
+        st[seg].lo = want[0] < 0 ? 0ull : (unsigned long long)found[0];
+        st[seg].hi = want[1] >= BIG_SAMPLE ? ~0ull : (unsigned long long)found[1];
     }
 }
 

@@ -185,3 +185,52 @@ def test_mad_long_segments_exact():
     got = host(e.mad(dev(flat), [p.size for p in parts]))
     assert np.isnan(got[1])
     assert got[0] == orc.mad(parts[0]) and got[2] == orc.mad(parts[2])
+
+
+def _batch_denoise(e, xs, dt, wavelet, level, thr_mode):
+    """All blocks of `xs` (list of 1-D arrays) in one C-ABI call; returns outputs + stats."""
+    lens = np.array([len(x) for x in xs], dtype=np.int64)
+    in_off = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    out_len = 2 * ((lens + 1) // 2)
+    out_off = np.concatenate([[0], np.cumsum(out_len)[:-1]])
+    xd = dev(np.concatenate(xs), dt)
+    out = torch.full((int(out_len.sum()),), float("nan"), dtype=dt, device="cuda:0")
+    st = e.wavelet_denoise(xd, e._i64(in_off), e._i64(lens), out, e._i64(out_off), wavelet=wavelet, level=level,
+                           thr_mode=thr_mode, max_frames=int(lens.max()), want_stats=True)
+    o = host(out)
+    return [o[a:a + l] for a, l in zip(out_off, out_len)], [host(s) for s in st]
+
+
+@pytest.mark.parametrize("wavelet,level", [("db4", 1), ("db4", 2), ("db4", 3), ("db8", 4), ("db8", 5), ("db8", 8),
+                                           ("db4", 7)])
+def test_tile_kernels_any_block_length(wavelet, level):
+    """Mono blocks of awkward lengths in one batch: shorter than a filter, shorter than one tile,
+    several tiles, odd at the first / at deeper levels, a multiple of 2^level.  The fused tile
+    kernels (interior and boundary index paths, deep kernel for level > 4) must match the
+    oracle, the level-by-level kernels, and count the same zeroed coefficients."""
+    e = engine()
+    lens = [1, 2, 3, 7, 17, 100, 255, 4095, 4096, 4097, 8191, 9001, 12288, 20000, 20001, 20003, 33333, 40960]
+    rng = np.random.default_rng(5)
+    xs = [synth.noisy_speech(n, 16000, 42, i) if n > 50 else rng.standard_normal(n) for i, n in enumerate(lens)]
+    for thr_mode in ("soft", "hard"):
+        ys, st = _batch_denoise(e, xs, torch.float64, wavelet, level, thr_mode)
+        e.force_generic(True)
+        try:
+            ys_g, st_g = _batch_denoise(e, xs, torch.float64, wavelet, level, thr_mode)
+        finally:
+            e.force_generic(False)
+        for x, y, yg in zip(xs, ys, ys_g):
+            want, s_or, t_or = orc.denoise_block(x, wavelet, level, thr_mode)
+            if np.all(np.isfinite(want)):
+                check64(y, want)
+                check64(yg, want)
+            else:
+                assert np.array_equal(np.isnan(y), np.isnan(want))
+        for a, b in zip(st, st_g):
+            assert np.array_equal(a, b, equal_nan=True), (a, b)
+    # fp32: same batch, tolerance of the fp32 path
+    ys32, _ = _batch_denoise(e, [x.astype(np.float32) for x in xs], torch.float32, wavelet, level, "soft")
+    for x, y in zip(xs, ys32):
+        want, _, _ = orc.denoise_block(x.astype(np.float32).astype(np.float64), wavelet, level, "soft")
+        if len(x) > 50:
+            check32(y, want)
