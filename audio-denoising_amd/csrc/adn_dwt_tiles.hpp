@@ -20,9 +20,16 @@ enum { MODE_STATS = 0, MODE_APPLY = 1 };
 constexpr int TL_MAX = 4;
 constexpr int THREADS = 256;
 
+template <typename T> struct Pk;
+template <> struct Pk<float> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct Pk<double> { typedef double type __attribute__((ext_vector_type(2))); };
+
 template <typename T, int F>
 struct TapsF {
     T h[F], g[F], rl[F], rh[F];
+    // the same taps as operand pairs of the two-wide multiply-adds:
+    // hg[j] = (h[j], g[j]); rlp[q] = (rl[2q+1], rl[2q]); rhp[q] = (rh[2q+1], rh[2q])
+    typename Pk<T>::type hg[F], rlp[F / 2], rhp[F / 2];
 };
 
 template <typename T, int F>
@@ -34,9 +41,29 @@ static TapsF<T, F> make_taps_f(int wavelet) {
         t.g[j] = (T)b.g[j];
         t.rl[j] = (T)b.rl[j];
         t.rh[j] = (T)b.rh[j];
+        t.hg[j].x = (T)b.h[j];
+        t.hg[j].y = (T)b.g[j];
+    }
+    for (int q = 0; q < F / 2; ++q) {
+        t.rlp[q].x = (T)b.rl[2 * q + 1];
+        t.rlp[q].y = (T)b.rl[2 * q];
+        t.rhp[q].x = (T)b.rh[2 * q + 1];
+        t.rhp[q].y = (T)b.rh[2 * q];
     }
     return t;
 }
+
+// pywt.threshold with the fp32 division replaced by the hardware reciprocal (1 ulp); keeps the
+// NaN / inf behaviour of the exact form (0/0 -> NaN, t/0 -> inf -> factor 0)
+__device__ __forceinline__ float shrink_fast(float d, float t, int thr_mode) {
+    if (thr_mode == ADN_THR_SOFT) {
+        float f = 1.0f - t * __builtin_amdgcn_rcpf(fabsf(d));
+        f = f < 0.0f ? 0.0f : f;
+        return d * f;
+    }
+    return fabsf(d) < t ? 0.0f : d;
+}
+__device__ __forceinline__ double shrink_fast(double d, double t, int thr_mode) { return shrink(d, t, thr_mode); }
 
 // canonical contiguous range: indices (s + i) mod N for i < c
 struct Rg {
@@ -178,6 +205,7 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
                                                   int use_top, int ablate) {
     constexpr Cap<S, F, TL> cap{};
     using V2 = typename Vec2T<T>::type;
+    using P = typename Pk<T>::type;
     __shared__ __attribute__((aligned(16))) T lds[cap.total];
     const int tid = threadIdx.x;
     const int64_t b = blockIdx.x / tiles_per_block;
@@ -209,10 +237,13 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
     }
     __syncthreads();
 
-    // ---- analysis
+    // ---- analysis (apply: details are shrunk as they are produced)
+    const T thr = MODE == MODE_APPLY ? (T)thresh[b] : (T)0;
+    int nz = 0;
 #pragma unroll
     for (int l = 1; l <= TL; ++l) {
         if (ablate & 1) break;
+        if (ablate & 2) thr_mode = -1;      // timing only: neither soft nor hard
         const T *src = lds + cap.offA[l - 1] + sh[l - 1];
         T *dA = lds + cap.offA[l] + sh[l];
         T *dD = lds + cap.offD[l];
@@ -223,8 +254,8 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
             const int dI = ir.s - dr.s;
             for (int i = tid; i < dr.c; i += THREADS) {
                 const V2 *w = reinterpret_cast<const V2 *>(src + off_lo + 2 * i);
-                T sa = 0, sd = 0;
-                // window element t pairs with tap F-1-t; keep pywt's summation order (tap 0 first)
+                // window element t pairs with tap F-1-t; pywt's summation order (tap 0 first);
+                // both filters advance together in one two-wide fused multiply-add per tap
                 T v[F];
 #pragma unroll
                 for (int t = 0; t < F / 2; ++t) {
@@ -232,15 +263,22 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
                     v[2 * t] = q.x;
                     v[2 * t + 1] = q.y;
                 }
+                P acc = {(T)0, (T)0};
 #pragma unroll
                 for (int j = 0; j < F; ++j) {
-                    sa += tp.h[j] * v[F - 1 - j];
-                    sd += tp.g[j] * v[F - 1 - j];
+                    const P vv = {v[F - 1 - j], v[F - 1 - j]};
+                    acc = __builtin_elementwise_fma(tp.hg[j], vv, acc);
                 }
+                const T sa = acc.x, sd = acc.y;
                 dA[i] = sa;
                 if (MODE == MODE_APPLY) {
+                    // shrink on the way into LDS; a tile counts the zeroed coefficients it owns
                     const int il = i - dI;
-                    if (il >= 0 && il < ir.c) dD[il] = sd;
+                    if (il >= 0 && il < ir.c) {
+                        const int k = dr.s + i;
+                        nz += (k >= p.own_lo[l] && k < p.own_hi[l] && fabs(sd) < thr) ? 1 : 0;
+                        dD[il] = shrink_fast(sd, thr, thr_mode);
+                    }
                 } else if (l == 1) {
                     const int k = dr.s + i;
                     if (k >= p.own_lo[1] && k < p.own_hi[1]) d1_out[b * d1_stride + k] = sd;
@@ -264,7 +302,10 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
                 if (MODE == MODE_APPLY) {
                     int il = k - ir.s;
                     if (il < 0) il += ir.N;
-                    if (il < ir.c) dD[il] = sd;
+                    if (il < ir.c) {
+                        nz += (k >= p.own_lo[l] && k < p.own_hi[l] && fabs(sd) < thr) ? 1 : 0;
+                        dD[il] = shrink_fast(sd, thr, thr_mode);
+                    }
                 } else if (l == 1) {
                     if (k >= p.own_lo[1] && k < p.own_hi[1]) d1_out[b * d1_stride + k] = sd;
                 }
@@ -285,21 +326,6 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
         return;
     }
 
-    // ---- shrink the details in place, count the zeroed ones this tile owns
-    const T t = (T)thresh[b];
-    int nz = 0;
-#pragma unroll
-    for (int l = 1; l <= TL; ++l) {
-        if (ablate & 2) break;
-        T *dD = lds + cap.offD[l];
-        const Rg ir = p.I[l];
-        for (int i = tid; i < ir.c; i += THREADS) {
-            const int k = rg_canon(ir, i);
-            const T d = dD[i];
-            nz += (k >= p.own_lo[l] && k < p.own_hi[l] && fabs(d) < t) ? 1 : 0;
-            dD[i] = shrink(d, t, thr_mode);
-        }
-    }
     if (use_top) {
         T *aT = lds + cap.offA[TL];
         const Rg r = p.I[TL];
@@ -321,6 +347,9 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
         const Rg orr = l > 1 ? p.I[l - 1] : Rg{n0, n1 - n0, 2 * p.N[1]};
         T *out = l > 1 ? lds + cap.offA[l - 1] : y + g.out_off[b] + n0;
         const int K = p.N[l];
+        // the level-1 output pair (y[2m], y[2m+1]) goes out as one store when that address is aligned
+        const bool pair_store = l == 1 && ((orr.s & 1) == 0) &&
+                                ((reinterpret_cast<uintptr_t>(out) & (2 * sizeof(T) - 1)) == 0);
         if (interior) {
             const int m0 = orr.s >> 1, m1 = (orr.s + orr.c - 1) >> 1;
             for (int m = m0 + tid; m <= m1; m += THREADS) {
@@ -337,15 +366,24 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
                     a[q] = ra[lb + q];
                     d[q] = rd[lb + q];
                 }
-                T ye = 0, yo = 0;
+                P acc = {(T)0, (T)0};           // (y[2m], y[2m+1])
 #pragma unroll
                 for (int q = 0; q < F / 2; ++q) {
-                    ye += tp.rl[2 * q + 1] * a[F / 2 - 1 - q] + tp.rh[2 * q + 1] * d[F / 2 - 1 - q];
-                    yo += tp.rl[2 * q] * a[F / 2 - q] + tp.rh[2 * q] * d[F / 2 - q];
+                    const P av = {a[F / 2 - 1 - q], a[F / 2 - q]};
+                    const P dv = {d[F / 2 - 1 - q], d[F / 2 - q]};
+                    acc = __builtin_elementwise_fma(tp.rlp[q], av, acc);
+                    acc = __builtin_elementwise_fma(tp.rhp[q], dv, acc);
                 }
                 const int io = 2 * m - orr.s;
-                if (io >= 0) out[io] = ye;
-                if (io + 1 < orr.c) out[io + 1] = yo;
+                if (l == 1 && pair_store && io >= 0 && io + 1 < orr.c) {
+                    V2 o2;
+                    o2.x = acc.x;
+                    o2.y = acc.y;
+                    *reinterpret_cast<V2 *>(out + io) = o2;
+                } else {
+                    if (io >= 0) out[io] = acc.x;
+                    if (io + 1 < orr.c) out[io + 1] = acc.y;
+                }
             }
         } else {
             for (int i = tid; i < orr.c; i += THREADS) {

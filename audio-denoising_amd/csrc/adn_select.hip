@@ -705,32 +705,49 @@ __global__ __launch_bounds__(256) void k_big_gather(const T *__restrict__ vals, 
     T *dst = cand + seg * cap;
     unsigned int below = 0;
     bool saw_nan = false, spilled = false;
-#pragma unroll 4
-    for (int it = 0; it < BIG_TILE / 256; ++it) {
-        const int64_t i = i0 + it * 256 + tid;
-        const bool in = i < n;
-        T x = 0;
-        K k = 0;
-        if (in) {
-            x = v[i];
+    // batches of BATCH elements per thread: all loads of a batch are in flight together, the
+    // keep decisions are one bit each, and a wave appends with ONE LDS atomic per batch
+    constexpr int BATCH = 16;
+    for (int b0 = 0; b0 < BIG_TILE / 256; b0 += BATCH) {
+        if (i0 + (int64_t)b0 * 256 >= n) break;
+        T xs[BATCH];
+        unsigned int keepmask = 0;
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int64_t i = i0 + (int64_t)(b0 + u) * 256 + tid;
+            xs[u] = i < n ? v[i] : (T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int64_t i = i0 + (int64_t)(b0 + u) * 256 + tid;
+            const bool in = i < n;
+            T x = xs[u];
             if (XF == XF_ABSDEV) x = fabs(x - c);
-            saw_nan |= (x != x);
-            k = x != x ? ~(K)0 : key_of(x);
+            xs[u] = x;
+            saw_nan |= in && (x != x);
+            const K k = x != x ? ~(K)0 : key_of(x);
+            below += (in && k < lo);
+            keepmask |= (in && k >= lo && k <= hi) ? (1u << u) : 0u;
         }
-        below += (in && k < lo);
-        const bool keep = in && k >= lo && k <= hi;
-        const unsigned long long m = __ballot(keep);
-        if (m) {
-            const int leader = __ffsll((long long)m) - 1;
-            unsigned int base = 0;
-            if (lane == leader) base = atomicAdd(&s_fill, (unsigned int)__popcll(m));
-            base = __shfl(base, leader);
-            const unsigned int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-            if (keep) {
-                if (pos < STAGE) stage[pos] = x;
+        const unsigned int cnt = __popc(keepmask);
+        unsigned int incl = cnt;
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        const unsigned int total = __shfl(incl, 63);
+        if (total == 0) continue;
+        unsigned int base = 0;
+        if (lane == 63) base = atomicAdd(&s_fill, total);
+        base = __shfl(base, 63);
+        unsigned int pos = base + incl - cnt;
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u)
+            if (keepmask & (1u << u)) {
+                if (pos < STAGE) stage[pos] = xs[u];
                 else spilled = true;                 // far more candidates than a bracket should hold
+                ++pos;
             }
-        }
     }
     for (int d = 32; d >= 1; d >>= 1) below += __shfl_xor(below, d);
     if (lane == 0 && below) atomicAdd(&s_below, (unsigned long long)below);
