@@ -17,6 +17,7 @@ namespace adn {
 
 static constexpr int SEL_THREADS = 256;
 static constexpr int SEL_LDS_BYTES = 48 * 1024;
+static constexpr size_t SEL_CACHED_BYTES = 20 * 1024;   // keys + compaction list up to this size
 
 __device__ __forceinline__ void hist_add_matched(uint32_t *hist, uint32_t digit, bool active) {
     unsigned long long m = __ballot(active);
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
     __shared__ uint32_t hist[256];
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t s_digit, s_before, s_count, s_nan, s_fill, s_next;
-    __shared__ K s_lo_max, s_hi_min;
+    __shared__ K s_lo_max, s_hi_min, s_kmin, s_kmax;
     __shared__ double s_msum[4];
     __shared__ int s_mcnt[4];
 
@@ -138,7 +139,11 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
         return x != x ? ~(K)0 : key_of(x);
     };
 
-    if (tid == 0) s_nan = 0;
+    if (tid == 0) {
+        s_nan = 0;
+        s_kmin = ~(K)0;
+        s_kmax = 0;
+    }
     K prefix = 0;                   // digits fixed so far, right aligned
     uint64_t r = (uint64_t)r0;      // rank of s[r0] inside the current list
     int64_t n_act = n;              // length of the current list (cached) or of the segment
@@ -146,17 +151,70 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
     bool done = false;
     T msum = 0;
     int mcnt = 0;
-    // keys gathered from a value bracket share the leading digits of the bracket's ends:
-    // those passes are skipped (the first pass that runs still loads and stages the keys)
-    int first_pass = 0;
-    if (sub.lohi) {
-        const K blo = (K)sub.lohi[2 * seg], bhi = (K)sub.lohi[2 * seg + 1];
-        while (first_pass < PASSES - 1 && (blo >> (BITS - 8 * (first_pass + 1))) == (bhi >> (BITS - 8 * (first_pass + 1))))
-            ++first_pass;
-        if (first_pass) prefix = blo >> (BITS - 8 * first_pass);
+    const bool in_lds = cached || resident;
+    // LDS-resident segments: one load phase stages the keys and finds their range.  The digits
+    // are then taken from (key - min): every pass spreads over up to 256 bins even when all
+    // values share sign and exponent (no same-address LDS atomics), and only the
+    // ceil(bits(max - min) / 8) passes that can differ are run.
+    K kmin = 0;
+    int passes = PASSES;
+    __syncthreads();
+    if (in_lds) {
+        K tmin = ~(K)0, tmax = 0;
+        bool saw_nan = false;
+        const int64_t its = (n + SEL_THREADS - 1) / SEL_THREADS;
+        for (int64_t it0 = 0; it0 < its; it0 += 8) {
+            T xv[8];
+            unsigned char mv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t i = (it0 + u) * SEL_THREADS + tid;
+                xv[u] = i < n ? v[i] : (T)0;
+                mv[u] = (mk && i < n) ? mk[i] : (unsigned char)0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t i = (it0 + u) * SEL_THREADS + tid;
+                if (i < n) {
+                    const T x = xv[u];
+                    if (mv[u]) {
+                        msum += x;
+                        ++mcnt;
+                    }
+                    T xx = x;
+                    if (XF == XF_ABSDEV) xx = fabs(x - c);
+                    const K k = xx != xx ? ~(K)0 : key_of(xx);
+                    cur[i] = k;
+                    saw_nan |= (k == ~(K)0);
+                    tmin = k < tmin ? k : tmin;
+                    tmax = k > tmax ? k : tmax;
+                }
+            }
+        }
+        for (int d = 32; d >= 1; d >>= 1) {
+            const K a = __shfl_xor(tmin, d), b = __shfl_xor(tmax, d);
+            tmin = a < tmin ? a : tmin;
+            tmax = b > tmax ? b : tmax;
+        }
+        if (lane == 0) {
+            atomicMin(&s_kmin, tmin);
+            atomicMax(&s_kmax, tmax);
+        }
+        if (saw_nan) s_nan = 1;
+        __syncthreads();
+        kmin = s_kmin;
+        const K width = s_kmax - kmin;
+        const int bits = width ? BITS - (BITS == 64 ? __clzll((long long)width) : __clz((int)width)) : 0;
+        passes = (bits + 7) / 8;
+        if (s_nan) {
+            done = true;                  // the result is NaN whatever the keys are
+        } else if (passes == 0) {
+            k0 = k1 = 0;                  // all keys equal: both order statistics are the minimum
+            done = true;
+        }
     }
-    for (int pass = first_pass; pass < PASSES && !done; ++pass) {
-        const int shift = BITS - 8 * (pass + 1);
+    for (int pass = 0; pass < passes && !done; ++pass) {
+        const int shift = 8 * (passes - 1 - pass);
         hist[tid] = 0;
         if (tid == 0) {
             s_fill = 0;
@@ -168,9 +226,9 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
         // ---- histogram of this pass's digit
         bool saw_nan = false;
         const int64_t its = (n_act + SEL_THREADS - 1) / SEL_THREADS;
-        if (pass == first_pass) {
-            // first pass: values come from memory; loads are issued in batches of 8 per thread so
-            // that their latency overlaps (the loop body would otherwise wait for every load)
+        if (!in_lds && pass == 0) {
+            // segments too long for LDS: every pass reads memory; the first one also looks for
+            // NaNs and accumulates the masked mean.  Loads go out in batches of 8 per thread.
             for (int64_t it0 = 0; it0 < its; it0 += 8) {
                 T xv[8];
                 unsigned char mv[8];
@@ -192,12 +250,12 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
                         T xx = x;
                         if (XF == XF_ABSDEV) xx = fabs(x - c);
                         const K k = xx != xx ? ~(K)0 : key_of(xx);
-                        if (cached || resident) cur[i] = k;
                         saw_nan |= (k == ~(K)0);
                         atomicAdd(&hist[(uint32_t)((k >> shift) & 0xFF)], 1u);
                     }
                 }
             }
+            if (saw_nan) s_nan = 1;
         } else {
             for (int64_t it = 0; it < its; ++it) {
                 const int64_t i = it * SEL_THREADS + tid;
@@ -205,18 +263,15 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
                     K k;
                     bool match = true;
                     if (cached) {
-                        k = cur[i];                  // the list holds only keys with this prefix
+                        k = cur[i] - kmin;           // the list holds only keys with this prefix
                     } else {
-                        k = resident ? cur[i] : load_key(i);
-                        match = (k >> (shift + 8)) == prefix;
+                        k = resident ? cur[i] - kmin : load_key(i);
+                        match = pass == 0 || (k >> (shift + 8)) == prefix;
                     }
-                    // plain LDS atomics: keys of one segment spread over enough bins that
-                    // same-address serialisation costs less than matching lanes with ballots
                     if (match) atomicAdd(&hist[(uint32_t)((k >> shift) & 0xFF)], 1u);
                 }
             }
         }
-        if (pass == first_pass && saw_nan) s_nan = 1;
         __syncthreads();
         // ---- bin of s[r0]; is s[r1] in the same bin?
         const uint32_t h = hist[tid];
@@ -239,7 +294,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
             const K pre_hi = (prefix << 8) | (K)s_next;
             K lo_max = 0, hi_min = ~(K)0;
             for (int64_t i = tid; i < n_act; i += SEL_THREADS) {
-                const K k = (cached || resident) ? cur[i] : load_key(i);
+                const K k = in_lds ? cur[i] - kmin : load_key(i);
                 const K top = k >> shift;
                 if (top == new_prefix && k > lo_max) lo_max = k;
                 if (top == pre_hi && k < hi_min) hi_min = k;
@@ -257,7 +312,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
             k0 = s_lo_max;
             k1 = s_hi_min;
             done = true;
-        } else if (pass + 1 == PASSES) {
+        } else if (pass + 1 == passes) {
             k0 = k1 = new_prefix;             // both order statistics are copies of one key
             done = true;
         } else {
@@ -267,7 +322,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
                     const int64_t i = it * SEL_THREADS + tid;
                     const bool in = i < n_act;
                     const K k = in ? cur[i] : 0;
-                    const bool keep = in && (k >> shift) == new_prefix;
+                    const bool keep = in && ((K)(k - kmin) >> shift) == new_prefix;
                     const unsigned long long m = __ballot(keep);
                     uint32_t base = 0;
                     if (lane == 0 && m) base = atomicAdd(&s_fill, (uint32_t)__popcll(m));
@@ -284,6 +339,8 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
         }
         __syncthreads();
     }
+    k0 += kmin;                               // digits were taken from (key - kmin)
+    k1 += kmin;
     if (mm.out) {
         for (int d = 32; d >= 1; d >>= 1) {
             msum += __shfl_xor(msum, d);
@@ -881,8 +938,14 @@ int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {
         return a.xform == XF_ABSDEV ? launch_select_big<T, XF_ABSDEV>(c, d_vals, a)
                                     : launch_select_big<T, XF_NONE>(c, d_vals, a);
     }
+    // LDS layout per segment length: short segments keep the keys plus a compaction list (later
+    // passes walk only the surviving keys); longer ones keep the keys only and re-scan them, so
+    // that several workgroups still share a CU (the kernel is latency bound, occupancy matters)
     int lds_keys = (int)(SEL_LDS_BYTES / sizeof(K));
     if (a.max_len > 0 && a.max_len < lds_keys) lds_keys = (int)a.max_len;
+    if (a.max_len > 0 && 2 * (size_t)a.max_len * sizeof(K) > SEL_CACHED_BYTES &&
+        a.max_len <= 2 * (int64_t)(SEL_LDS_BYTES / sizeof(K)))
+        lds_keys = (int)((a.max_len + 1) / 2);
     const size_t dyn = 2 * (size_t)lds_keys * sizeof(K);      // keys + candidate list
     MaskedMean mm{a.d_mask, a.mask_div, a.mask_stride, a.d_masked_mean};
     if (a.xform == XF_ABSDEV) {
