@@ -369,7 +369,7 @@ __global__ void k_vad_map(Signals sg, int64_t n_sig, int64_t frame_len, int64_t 
 // speech_raw[row] = sum over VAD frames of S[row][t] / max(count, 1)  (src/wiener_filter.py:99-102)
 template <typename T>
 __global__ __launch_bounds__(256) void k_masked_mean(const T *__restrict__ S, int F, int64_t Tmax,
-                                                     int64_t n_rows, const int64_t *__restrict__ Tn,
+                                                     int64_t s_stride, int64_t n_rows, const int64_t *__restrict__ Tn,
                                                      const unsigned char *__restrict__ vad,
                                                      double *__restrict__ out) {
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void k_masked_mean(const T *__restrict__ S, in
     if (row >= n_rows) return;
     const int64_t sig = row / F;
     const int64_t T_ = Tn[sig];
-    const T *r = S + row * Tmax;
+    const T *r = S + row * s_stride;
     const unsigned char *m = vad + sig * Tmax;
     T acc = 0;
     int c = 0;                     // frames flagged as speech (every row recounts: no atomics)
@@ -619,6 +619,10 @@ static int launch_rows(Ctx *c, const T *d_x, const Signals &sg, const Tables<T> 
     return ADN_OK;
 }
 
+// Row stride of the transposed magnitude / power matrix: a multiple of 32 frames, so that the
+// 16-frame segments a workgroup writes are aligned sectors of the row (no partial-line writes).
+static inline int64_t row_stride(int64_t Tmax) { return (Tmax + 31) & ~int64_t(31); }
+
 template <typename T>
 static int rows_dispatch(Ctx *c, const T *d_x, const Signals &sg, const Tables<T> &tb, int64_t n_sig,
                          int64_t Tmax, int power, T *S, unsigned long long *sig_max) {
@@ -703,7 +707,8 @@ int noise_psd(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const i
     ADN_TRY(get_tables<T>(c, n_fft, &tb));
     const int F = n_fft / 2 + 1;
     const int64_t Tmax = stft_frames(max_len, n_fft, hop, padded);
-    const size_t nS = (size_t)n_sig * F * Tmax;
+    const int64_t Ts = row_stride(Tmax);
+    const size_t nS = (size_t)n_sig * F * Ts;
     ADN_TRY(ws_reserve(c, ws_need(nS, sizeof(T)) + ws_need(n_sig, 8) * 2 + ws_need((size_t)n_sig * F, 8) +
                               select_ws_bytes(n_sig * F, Tmax)));
     T *S = ws_take<T>(c, nS);
@@ -713,10 +718,10 @@ int noise_psd(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const i
     Signals sg{d_off, d_len, n_ch, n_fft, hop, padded};
     ADN_HIP(hipMemsetAsync(sig_max, 0, sizeof(unsigned long long) * n_sig, c->stream));
     hipLaunchKernelGGL(k_frame_counts, dim3((unsigned)ceil_div(n_sig, 256)), dim3(256), 0, c->stream, sg, n_sig, Tn);
-    ADN_TRY(rows_dispatch<T>(c, d_x, sg, tb, n_sig, Tmax, 0, S, sig_max));
+    ADN_TRY(rows_dispatch<T>(c, d_x, sg, tb, n_sig, Ts, 0, S, sig_max));
     SelectArgs sa;
     sa.n_seg = n_sig * F;
-    sa.seg_stride = Tmax;
+    sa.seg_stride = Ts;
     sa.d_seg_len = Tn;
     sa.len_div = F;
     sa.max_len = Tmax;
@@ -784,7 +789,8 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     const int F = n_fft / 2 + 1;
     const int64_t Tmax = stft_frames(max_len, n_fft, hop, 1);
     const int64_t nv_max = vad_guided ? (ceil_div(max_len, frame_len) < 1 ? 1 : ceil_div(max_len, frame_len)) : 1;
-    const size_t nS = (size_t)n_sig * F * Tmax, nR = (size_t)n_sig * F;
+    const int64_t Ts = row_stride(Tmax);
+    const size_t nS = (size_t)n_sig * F * Ts, nR = (size_t)n_sig * F;
     ADN_TRY(ws_reserve(c, ws_need(nS, sizeof(T)) + ws_need(n_sig, 8) + 2 * ws_need(nR, 8) + ws_need(nR, sizeof(T)) +
                               ws_need((size_t)n_sig * nv_max, 1) + ws_need((size_t)n_sig * Tmax, 1) + ws_need(n_sig, 4) +
                               2 * select_ws_bytes(n_sig * F, Tmax)));
@@ -802,10 +808,10 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
         hipLaunchKernelGGL(k_vad_map, dim3((unsigned)ceil_div(n_sig * Tmax, 256)), dim3(256), 0, c->stream, sg, n_sig,
                            frame_len, nv_max, Tmax, speech, vad);
     }
-    ADN_TRY(rows_dispatch<T>(c, d_x, sg, tb, n_sig, Tmax, 1, S, nullptr));
+    ADN_TRY(rows_dispatch<T>(c, d_x, sg, tb, n_sig, Ts, 1, S, nullptr));
     SelectArgs sa;
     sa.n_seg = n_sig * F;
-    sa.seg_stride = Tmax;
+    sa.seg_stride = Ts;
     sa.d_seg_len = Tn;
     sa.len_div = F;
     sa.max_len = Tmax;
@@ -825,7 +831,7 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     sa.d_masked_mean = nullptr;
     if (vad_guided && !fuse_mean) {
         hipLaunchKernelGGL((k_masked_mean<T>), dim3((unsigned)ceil_div(n_sig * F, 4)), dim3(256), 0, c->stream, S, F,
-                           Tmax, n_sig * F, Tn, vad, sraw);
+                           Tmax, Ts, n_sig * F, Tn, vad, sraw);
     } else if (!vad_guided) {
         sa.mode = SEL_MEDIAN;
         sa.d_out = sraw;
