@@ -499,23 +499,19 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
             const bool final_group = (ue == Tn - 1);
             const int nj = ue - ub + R;                     // hops touched
             const float *fbase = reinterpret_cast<const float *>(bufs);
-#pragma unroll 1
-            for (int idx = tid; idx < (nj << LOGH); idx += W * 64) {
-                const int jj = idx >> LOGH, i = idx & (H - 1);
-                const int j = ub + jj;
-                int slot_i = j % RING;
-                float *slot = acc + slot_i * H + i;
+            // one hop j, sample i of it: add the frames that overlap the hop, emit it if complete
+            auto hop_sample = [&](int j, int i, float *slot, const int (&off)[4], int r_eff, float wq) {
                 float v = *slot;
-                int u_lo = j - R + 1;
-                u_lo = u_lo < ub ? ub : u_lo;
-                const int u_hi = j < ue ? j : ue;
-                for (int u = u_lo; u <= u_hi; ++u)
-                    v += fbase[(u - base) * (2 * WBUF) + natf(((j - u) << LOGH) + i)];
+#pragma unroll
+                for (int qq = 3; qq >= 0; --qq) {          // frames u = j - qq, oldest first
+                    const int u = j - qq;
+                    if (qq < r_eff && u >= ub && u <= ue) v += fbase[(u - base) * (2 * WBUF) + off[qq]];
+                }
                 if (j <= ue || final_group) {
                     if (j >= ph0 && j < ph1) {
                         float o;
                         if (j - R + 1 >= 0 && j <= Tn - 1) {
-                            o = v * wsq[i];
+                            o = v * wq;
                         } else {
                             float norm = 0.0f;
                             int t_lo = j - R + 1;
@@ -533,6 +529,37 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                     *slot = 0.0f;
                 } else {
                     *slot = v;
+                }
+            };
+            if (H == W * 64) {
+                // hop == threads per workgroup: a thread owns sample i = tid of every hop, so the
+                // sample offsets inside a frame and the norm are per-thread constants
+                const int i = tid;
+                int off[4];
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) off[qq] = natf((qq << LOGH) + i);
+                const float wq = wsq[i];
+                int slot_i = ub % RING;
+#pragma unroll 1
+                for (int jj = 0; jj < nj; ++jj) {
+                    hop_sample(ub + jj, i, acc + slot_i * H + i, off, 4, wq);
+                    slot_i = slot_i + 1 == RING ? 0 : slot_i + 1;
+                }
+            } else {
+#pragma unroll 1
+                for (int idx = tid; idx < (nj << LOGH); idx += W * 64) {
+                    const int jj = idx >> LOGH, i = idx & (H - 1);
+                    const int j = ub + jj;
+                    int off[4];
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) off[qq] = natf((qq << LOGH) + i);
+                    // R > 4 (hop < 512): the frames beyond the four unrolled ones
+                    float *slot = acc + (j % RING) * H + i;
+                    for (int qq = R - 1; qq >= 4; --qq) {
+                        const int u = j - qq;
+                        if (u >= ub && u <= ue) *slot += fbase[(u - base) * (2 * WBUF) + natf((qq << LOGH) + i)];
+                    }
+                    hop_sample(j, i, slot, off, R < 4 ? R : 4, wsq[i]);
                 }
             }
         }
