@@ -326,7 +326,7 @@ __global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ 
 // transform W consecutive frames (stage A), the frames whose time-smoothing neighbours are
 // all present are modified and inverse-transformed (stage B), and all threads overlap-add
 // the finished frames into a ring of hop accumulators, emitting the hops that are complete.
-template <int W, int MODE>
+template <int W, int MODE, bool PROF>
 __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const Tables<float> &tb = a.tb;
@@ -377,8 +377,18 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
     }
     __syncthreads();
 
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+    constexpr bool prof = PROF;
 #pragma unroll 1
     while (next_u <= last_u) {
+        unsigned long long tk = prof ? clock64() : 0;
+        auto tick = [&](int i) {
+            if (prof) {
+                const unsigned long long now = clock64();
+                ph[i] += now - tk;
+                tk = now;
+            }
+        };
         int base = next_u - h;
         base = base < 0 ? 0 : base;
         const int t = base + wave;
@@ -429,7 +439,9 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                 }
             }
         }
-        if (MODE == APPLY_SUBTRACT) __syncthreads();
+        tick(0);
+        if (MODE == APPLY_SUBTRACT) lds_barrier();
+        tick(1);
         const int ub = next_u;
         int ue = base + W - 1 - hr;
         if (base + W - 1 >= Tn - 1) ue = Tn - 1;
@@ -493,7 +505,9 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
             }
             store_natural(r, buf, lane);
         }
-        __syncthreads();
+        tick(2);
+        lds_barrier();
+        tick(3);
         // ---- overlap-add of frames [ub, ue] into padded hops [ub, ue + R - 1]
         if (ue >= ub && !(a.ablate & 4)) {
             const bool final_group = (ue == Tn - 1);
@@ -502,11 +516,18 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
             // one hop j, sample i of it: add the frames that overlap the hop, emit it if complete
             auto hop_sample = [&](int j, int i, float *slot, const int (&off)[4], int r_eff, float wq) {
                 float v = *slot;
+                // all four reads are issued together (a frame outside [ub, ue] reads frame slot 0
+                // and contributes zero), then added oldest frame first
+                float c[4];
+                bool ok[4];
 #pragma unroll
-                for (int qq = 3; qq >= 0; --qq) {          // frames u = j - qq, oldest first
+                for (int qq = 0; qq < 4; ++qq) {
                     const int u = j - qq;
-                    if (qq < r_eff && u >= ub && u <= ue) v += fbase[(u - base) * (2 * WBUF) + off[qq]];
+                    ok[qq] = qq < r_eff && u >= ub && u <= ue;
+                    c[qq] = fbase[(ok[qq] ? u - base : 0) * (2 * WBUF) + off[qq]];
                 }
+#pragma unroll
+                for (int qq = 3; qq >= 0; --qq) v += ok[qq] ? c[qq] : 0.0f;
                 if (j <= ue || final_group) {
                     if (j >= ph0 && j < ph1) {
                         float o;
@@ -563,9 +584,13 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                 }
             }
         }
-        __syncthreads();
+        tick(4);
+        lds_barrier();
+        tick(5);
         next_u = ue + 1;
     }
+    if (prof && tid == 0)
+        for (int i = 0; i < 6; ++i) atomicAdd(&a.dbg[i], ph[i]);
 }
 
 static size_t apply_lds(int W, int mode, int hop) {
@@ -589,11 +614,24 @@ int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
     a.seg_hops = (int)seg;
     a.segs_per_sig = ceil_div(out_hops, seg);
     a.ablate = c->ablate;
-    auto kern = fast::k_apply_fast<W, MODE>;
+    a.dbg = nullptr;
+    if (c->ablate & 16) {       // diagnostics: per-phase cycle totals, printed after the launch
+        ADN_HIP(hipMalloc(&a.dbg, 6 * sizeof(unsigned long long)));
+        ADN_HIP(hipMemset(a.dbg, 0, 6 * sizeof(unsigned long long)));
+    }
+    auto kern = a.dbg ? fast::k_apply_fast<W, MODE, true> : fast::k_apply_fast<W, MODE, false>;
     ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.segs_per_sig * n_sig)), dim3(W * 64), lds, c->stream, a);
     ADN_HIP(hipGetLastError());
+    if (a.dbg) {
+        unsigned long long hp[6];
+        ADN_HIP(hipStreamSynchronize(c->stream));
+        ADN_HIP(hipMemcpy(hp, a.dbg, sizeof(hp), hipMemcpyDeviceToHost));
+        ADN_HIP(hipFree(a.dbg));
+        fprintf(stderr, "k_apply_fast<%d> wave-0 cycles: stageA %llu barrier %llu stageB %llu barrier %llu ola %llu barrier %llu (workgroups %lld)\n",
+                MODE, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], (long long)(a.segs_per_sig * n_sig));
+    }
     return ADN_OK;
 }
 

@@ -27,6 +27,14 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every
+// outstanding global store to be acknowledged; the sliding kernels store finished output
+// samples right before a barrier and never read them back, so they wait for LDS alone and
+// let the stores drain in the background.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ int brev(int k, int logn) { return (int)(__brev((unsigned)k) >> (32 - logn)); }
 
 template <typename T>
@@ -82,6 +90,7 @@ struct ApplyArgs {
     int64_t segs_per_sig;
     int seg_hops;        // output hops per workgroup
     int ablate;          // diagnostics: bit 0 skips the analysis, 1 the synthesis, 2 the overlap-add
+    unsigned long long *dbg;   // diagnostics (ablate bit 4): per-phase shader-clock totals of wave 0
 };
 
 
