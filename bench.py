@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend; gloo lets several ranks rehearse on one GPU")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline time budget")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline time budget")
     return ap.parse_args()
 
 
@@ -118,14 +118,30 @@ class Workload:
                 events.setdefault(name, []).append((a, b))
 
     def algorithmic_bytes(self):
-        """Compulsory HBM bytes per step and stage: every stage reads its input once and
-        writes its output once; B bytes per sample.  Phase 2 counts both channels; the STFT
-        stages are priced per mono sample (2*B per sample), phase 1 per noise sample (1*B)."""
+        """Compulsory HBM bytes per step and stage: every stage reads its input once and writes
+        its output once, nothing else.  Phase 1: the noise samples in, one 1025-bin profile out.
+        Phase 2: both channels in and out.  Phase 2b: the stereo signal in (the mono fold is part
+        of the stage, src/spectral_subtract.py:80-81), the mono result out.  Phase 2c: mono in,
+        mono out."""
         bts = 4 if self.dtype == torch.float32 else 8
-        return {"phase1": self.B * self.nn * bts,
+        return {"phase1": self.B * (self.nn + 1025) * bts,
                 "phase2": self.B * self.n * 2 * 2 * bts,
-                "phase2b": self.B * self.n * 2 * bts,
-                "phase2c": self.B * self.l2b * 2 * bts}
+                "phase2b": self.B * (self.n * 2 + self.l2b) * bts,
+                "phase2c": self.B * (self.l2b + self.l2c) * bts}
+
+
+def measured_traffic(kernel_key, clips):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r1_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this
+    script, FETCH_SIZE doubled as gfx950 requires), scaled from the profiled batch to this one;
+    None when no profile is committed for this kernel."""
+    path = os.path.join(REPO, "profiles", "r1_pmc_traffic.json")
+    try:
+        prof = json.load(open(path))
+        k = prof["kernels"][kernel_key]
+        return k["hbm_bytes_per_clip"] * clips
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(budget_s):
@@ -145,7 +161,7 @@ def cpu_baseline(budget_s):
         orc.wiener(y2b, SR)
         done += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or done >= 8:
+        if el >= budget_s or done >= 16:
             break
     return {"value": done * CLIP_S / el, "unit": "audio-sec/sec", "cores": 1, "kind": "port",
             "sample": "%d x (60 s 48 kHz stereo clip + 5 s noise), fp64 numpy restatement, %.1f s of CPU work"
@@ -222,10 +238,13 @@ def main():
                                    "samples, STFT n_fft=2048 hop=512 (BASELINE config 2), %d clips per GPU per step"
                                    % args.clips,
                        "clips_per_gpu": args.clips, "sharding": "clips round-robin over ranks, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "adn::fast::k_apply_fast<8, SUBTRACT> (phase 2b, one launch per step)"
+            "roofline": {"bound": "hbm", "kernel": "adn::fast::k_apply_fast<8, SUBTRACT, false> (phase 2b, one launch per step)"
                          if args.dtype == "f32" else "adn::k_stft_apply<double, 4, SUBTRACT> (phase 2b)",
                          "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": stages[dom]["hbm_frac"], "traffic": None,
+                         "frac": stages[dom]["hbm_frac"],
+                         "traffic": measured_traffic("void adn::fast::k_apply_fast<8, 0, false>", args.clips)
+                         if args.dtype == "f32" else None,
+                         "traffic_unit": "bytes per launch",
                          "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": stages[dom]["ms"]},
             "chain": {"ms": round(chain_ms, 4), "algorithmic_bytes": chain_bytes,
                       "GBps": round(chain_bytes / chain_ms / 1e6, 1),
