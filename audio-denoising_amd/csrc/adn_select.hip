@@ -17,7 +17,7 @@ namespace adn {
 
 static constexpr int SEL_THREADS = 256;
 static constexpr int SEL_LDS_BYTES = 48 * 1024;
-static constexpr size_t SEL_CACHED_BYTES = 20 * 1024;   // keys + compaction list up to this size
+static constexpr size_t SEL_LDS_MAX_BYTES = 96 * 1024;  // longest segment the lean LDS kernel stages
 
 __device__ __forceinline__ void hist_add_matched(uint32_t *hist, uint32_t digit, bool active) {
     unsigned long long m = __ballot(active);
@@ -369,6 +369,225 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
         }
         out[seg] = res;
         if (mm.out) {
+            const T tot = (T)s_msum[0] + (T)s_msum[1] + (T)s_msum[2] + (T)s_msum[3];
+            const int cn = s_mcnt[0] + s_mcnt[1] + s_mcnt[2] + s_mcnt[3];
+            mm.out[seg] = (double)(tot / (T)(cn > 1 ? cn : 1));
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// Lean variant for segments whose keys fit LDS (the common case: rows of the transposed
+// spectra, bracket candidates): 32-bit indexing, keys staged once, every pass re-scans them
+// (only keys that match the digits fixed so far touch the histogram), LDS = n keys exactly so
+// that several workgroups share a CU.  Same results as k_select.
+template <typename T, int XF, bool MASKED>
+__global__ __launch_bounds__(SEL_THREADS) void k_select_lds(const T *__restrict__ vals,
+                                                            const int64_t *__restrict__ seg_off,
+                                                            int64_t seg_stride,
+                                                            const int64_t *__restrict__ seg_len,
+                                                            int64_t len_div, int64_t uniform_len,
+                                                            int mode, double q,
+                                                            const double *__restrict__ center,
+                                                            double *__restrict__ out,
+                                                            MaskedMean mm, SubsetRanks sub) {
+    using K = typename KeyT<T>::type;
+    constexpr int BITS = KeyT<T>::bits;
+    extern __shared__ __align__(16) unsigned char smem[];
+    K *keys = reinterpret_cast<K *>(smem);
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t s_digit, s_before, s_count, s_nan, s_next;
+    __shared__ K s_lo_max, s_hi_min, s_kmin, s_kmax;
+    __shared__ double s_msum[4];
+    __shared__ int s_mcnt[4];
+
+    const int64_t seg = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (sub.valid && !sub.valid[seg]) return;
+    const int n = (int)(seg_len ? seg_len[seg / len_div] : uniform_len);
+    if (n <= 0) {
+        if (tid == 0) {
+            out[seg] = __longlong_as_double(0x7FF8000000000000ll);
+            if (MASKED) mm.out[seg] = 0.0;
+        }
+        return;
+    }
+    int64_t r0l, r1l;
+    double frac;
+    {
+        const int64_t nr = sub.below ? (sub.orig_len ? sub.orig_len[seg / sub.orig_div] : sub.orig_uniform) : n;
+        if (mode == SEL_MEDIAN) {
+            r0l = (nr - 1) / 2;
+            r1l = nr / 2;
+            frac = 0.5;
+        } else {
+            const double pos = (double)(nr - 1) * (q / 100.0);
+            r0l = (int64_t)floor(pos);
+            if (r0l > nr - 1) r0l = nr - 1;
+            frac = pos - (double)r0l;
+            r1l = r0l + 1 < nr ? r0l + 1 : nr - 1;
+        }
+        if (sub.below) {
+            r0l -= (int64_t)sub.below[seg];
+            r1l -= (int64_t)sub.below[seg];
+        }
+    }
+    const uint32_t r0 = (uint32_t)r0l, r1 = (uint32_t)r1l;
+    const T c = XF == XF_ABSDEV ? (T)center[seg] : (T)0;
+    const T *v = vals + (seg_off ? seg_off[seg] : seg * seg_stride) + tid;
+    const unsigned char *mk = MASKED ? mm.mask + (seg / mm.mask_div) * mm.mask_stride + tid : nullptr;
+    if (tid == 0) {
+        s_nan = 0;
+        s_kmin = ~(K)0;
+        s_kmax = 0;
+    }
+    __syncthreads();
+    // ---- load phase: keys to LDS, their range, NaN flag, masked mean
+    K tmin = ~(K)0, tmax = 0;
+    bool saw_nan = false;
+    T msum = 0;
+    int mcnt = 0;
+    constexpr int LB = 8;
+    for (int i0 = 0; i0 < n; i0 += LB * SEL_THREADS) {
+        T xv[LB];
+        unsigned char mv[LB];
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            const int i = i0 + u * SEL_THREADS;            // + tid is folded into the pointers
+            const bool ok = i + tid < n;
+            xv[u] = ok ? v[i] : (T)0;
+            if (MASKED) mv[u] = ok ? mk[i] : (unsigned char)0;
+        }
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            const int i = i0 + u * SEL_THREADS + tid;
+            if (i < n) {
+                T x = xv[u];
+                if (MASKED && mv[u]) {
+                    msum += x;
+                    ++mcnt;
+                }
+                if (XF == XF_ABSDEV) x = fabs(x - c);
+                const K k = x != x ? ~(K)0 : key_of(x);
+                keys[i] = k;
+                saw_nan |= (k == ~(K)0);
+                tmin = k < tmin ? k : tmin;
+                tmax = k > tmax ? k : tmax;
+            }
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const K a = __shfl_xor(tmin, d), b = __shfl_xor(tmax, d);
+        tmin = a < tmin ? a : tmin;
+        tmax = b > tmax ? b : tmax;
+        if (MASKED) {
+            msum += __shfl_xor(msum, d);
+            mcnt += __shfl_xor(mcnt, d);
+        }
+    }
+    if (lane == 0) {
+        atomicMin(&s_kmin, tmin);
+        atomicMax(&s_kmax, tmax);
+        if (MASKED) {
+            s_msum[wave] = (double)msum;
+            s_mcnt[wave] = mcnt;
+        }
+    }
+    if (saw_nan) s_nan = 1;
+    __syncthreads();
+    const K kmin = s_kmin;
+    const K width = s_kmax - kmin;
+    const int bits = width ? BITS - (BITS == 64 ? __clzll((long long)width) : __clz((int)width)) : 0;
+    const int passes = (bits + 7) / 8;
+    K k0 = 0, k1 = 0, prefix = 0;
+    uint32_t r = r0;
+    bool done = s_nan != 0 || passes == 0;
+    for (int pass = 0; pass < passes && !done; ++pass) {
+        const int shift = 8 * (passes - 1 - pass);
+        hist[tid] = 0;
+        if (tid == 0) {
+            s_next = 256;
+            s_lo_max = 0;
+            s_hi_min = ~(K)0;
+        }
+        __syncthreads();
+        if (pass == 0) {
+#pragma unroll 4
+            for (int i = tid; i < n; i += SEL_THREADS)
+                atomicAdd(&hist[(uint32_t)((keys[i] - kmin) >> shift) & 0xFFu], 1u);
+        } else {
+#pragma unroll 4
+            for (int i = tid; i < n; i += SEL_THREADS) {
+                const K u = keys[i] - kmin;
+                if ((u >> (shift + 8)) == prefix) atomicAdd(&hist[(uint32_t)(u >> shift) & 0xFFu], 1u);
+            }
+        }
+        __syncthreads();
+        const uint32_t h = hist[tid];
+        const uint32_t before = block_excl_scan(h, wsum);
+        if (r >= before && r < before + h) {
+            s_digit = tid;
+            s_before = before;
+            s_count = h;
+        }
+        __syncthreads();
+        const uint32_t digit = s_digit, in_bin = s_count;
+        const uint32_t within = r - s_before;
+        const bool together = (r1 == r0) || (within + 1 < in_bin);
+        const K new_prefix = (prefix << 8) | (K)digit;
+        if (!together) {
+            // s[r0] is the largest key of its bin and s[r1] the smallest key of the next
+            // non-empty bin: one sweep settles both
+            if (h && (uint32_t)tid > digit) atomicMin(&s_next, (uint32_t)tid);
+            __syncthreads();
+            const K pre_hi = (prefix << 8) | (K)s_next;
+            K lo_max = 0, hi_min = ~(K)0;
+            for (int i = tid; i < n; i += SEL_THREADS) {
+                const K u = keys[i] - kmin;
+                const K top = u >> shift;
+                if (top == new_prefix && u > lo_max) lo_max = u;
+                if (top == pre_hi && u < hi_min) hi_min = u;
+            }
+            for (int d = 32; d >= 1; d >>= 1) {
+                const K a = __shfl_xor(lo_max, d), b = __shfl_xor(hi_min, d);
+                lo_max = a > lo_max ? a : lo_max;
+                hi_min = b < hi_min ? b : hi_min;
+            }
+            if (lane == 0) {
+                atomicMax(&s_lo_max, lo_max);
+                atomicMin(&s_hi_min, hi_min);
+            }
+            __syncthreads();
+            k0 = s_lo_max;
+            k1 = s_hi_min;
+            done = true;
+        } else if (pass + 1 == passes) {
+            k0 = k1 = new_prefix;
+            done = true;
+        } else {
+            prefix = new_prefix;
+            r = within;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double res;
+        if (s_nan) {
+            res = __longlong_as_double(0x7FF8000000000000ll);
+        } else {
+            const T a = val_of((K)(k0 + kmin)), b = val_of((K)(k1 + kmin));
+            if (mode == SEL_MEDIAN) {
+                res = (r0 == r1) ? (double)a : (double)(T)((a + b) / (T)2);
+            } else {
+                const double da = (double)a, db = (double)b, diff = db - da;
+                res = frac >= 0.5 ? db - diff * (1.0 - frac) : da + diff * frac;
+                if (r0 == r1) res = da;
+                res = (double)(T)res;
+            }
+        }
+        out[seg] = res;
+        if (MASKED) {
             const T tot = (T)s_msum[0] + (T)s_msum[1] + (T)s_msum[2] + (T)s_msum[3];
             const int cn = s_mcnt[0] + s_mcnt[1] + s_mcnt[2] + s_mcnt[3];
             mm.out[seg] = (double)(tot / (T)(cn > 1 ? cn : 1));
@@ -893,15 +1112,24 @@ static int launch_select_big(Ctx *c, const T *d_vals, const SelectArgs &a) {
                        a.n_seg, a.mode, a.q, cap, cand_len, valid, below, lohi);
     {
         using K = typename KeyT<T>::type;
-        int lds_keys = (int)(SEL_LDS_BYTES / sizeof(K));
-        const size_t dyn = 2 * (size_t)lds_keys * sizeof(K);
-        auto kern = k_select<T, XF_NONE>;
-        ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         MaskedMean mm{nullptr, 1, 0, nullptr};
         SubsetRanks sub{a.d_seg_len, a.len_div, a.uniform_len, below, valid, lohi};
-        hipLaunchKernelGGL(kern, dim3((unsigned)a.n_seg), dim3(SEL_THREADS), dyn, c->stream, cand,
-                           (const int64_t *)nullptr, cap, cand_len, (int64_t)1, (int64_t)0, a.mode, a.q,
-                           (const double *)nullptr, a.d_out, lds_keys, mm, sub);
+        if ((size_t)cap * sizeof(K) <= SEL_LDS_MAX_BYTES) {
+            const size_t dyn = (size_t)cap * sizeof(K);
+            auto kern = k_select_lds<T, XF_NONE, false>;
+            ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            hipLaunchKernelGGL(kern, dim3((unsigned)a.n_seg), dim3(SEL_THREADS), dyn, c->stream, cand,
+                               (const int64_t *)nullptr, cap, cand_len, (int64_t)1, (int64_t)0, a.mode, a.q,
+                               (const double *)nullptr, a.d_out, mm, sub);
+        } else {
+            int lds_keys = (int)(SEL_LDS_BYTES / sizeof(K));
+            const size_t dyn = 2 * (size_t)lds_keys * sizeof(K);
+            auto kern = k_select<T, XF_NONE>;
+            ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            hipLaunchKernelGGL(kern, dim3((unsigned)a.n_seg), dim3(SEL_THREADS), dyn, c->stream, cand,
+                               (const int64_t *)nullptr, cap, cand_len, (int64_t)1, (int64_t)0, a.mode, a.q,
+                               (const double *)nullptr, a.d_out, lds_keys, mm, sub);
+        }
     }
     // ---- exact radix passes for whatever the bracket did not resolve (early exit otherwise)
     int remaining = BITS;
@@ -938,15 +1166,35 @@ int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {
         return a.xform == XF_ABSDEV ? launch_select_big<T, XF_ABSDEV>(c, d_vals, a)
                                     : launch_select_big<T, XF_NONE>(c, d_vals, a);
     }
-    // LDS layout per segment length: short segments keep the keys plus a compaction list (later
-    // passes walk only the surviving keys); longer ones keep the keys only and re-scan them, so
-    // that several workgroups still share a CU (the kernel is latency bound, occupancy matters)
+    // segments whose keys fit LDS take the lean kernel (LDS = the keys, several workgroups per CU)
+    if (a.max_len > 0 && (size_t)a.max_len * sizeof(K) <= SEL_LDS_MAX_BYTES) {
+        const size_t dyn = (size_t)a.max_len * sizeof(K);
+        MaskedMean mm{a.d_mask, a.mask_div, a.mask_stride, a.d_masked_mean};
+        const SubsetRanks none{nullptr, 1, 0, nullptr, nullptr, nullptr};
+        dim3 grid((unsigned)a.n_seg), block(SEL_THREADS);
+#define ADN_LAUNCH_LDS(XFV, MK)                                                                              \
+    do {                                                                                                     \
+        auto kern = k_select_lds<T, XFV, MK>;                                                                \
+        ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));                  \
+        hipLaunchKernelGGL(kern, grid, block, dyn, c->stream, d_vals, a.d_seg_off, a.seg_stride, a.d_seg_len, \
+                           a.len_div, a.uniform_len, a.mode, a.q, a.d_center, a.d_out, mm, none);            \
+    } while (0)
+        const bool masked = a.d_masked_mean != nullptr;
+        if (a.xform == XF_ABSDEV) {
+            if (masked) ADN_LAUNCH_LDS(XF_ABSDEV, true);
+            else ADN_LAUNCH_LDS(XF_ABSDEV, false);
+        } else {
+            if (masked) ADN_LAUNCH_LDS(XF_NONE, true);
+            else ADN_LAUNCH_LDS(XF_NONE, false);
+        }
+#undef ADN_LAUNCH_LDS
+        ADN_HIP(hipGetLastError());
+        return ADN_OK;
+    }
+    // longer segments (up to the multi-workgroup threshold): keys are re-read from memory each pass
     int lds_keys = (int)(SEL_LDS_BYTES / sizeof(K));
-    if (a.max_len > 0 && a.max_len < lds_keys) lds_keys = (int)a.max_len;
-    if (a.max_len > 0 && 2 * (size_t)a.max_len * sizeof(K) > SEL_CACHED_BYTES &&
-        a.max_len <= 2 * (int64_t)(SEL_LDS_BYTES / sizeof(K)))
-        lds_keys = (int)((a.max_len + 1) / 2);
-    const size_t dyn = 2 * (size_t)lds_keys * sizeof(K);      // keys + candidate list
+    const size_t dyn = 2 * (size_t)lds_keys * sizeof(K);
     MaskedMean mm{a.d_mask, a.mask_div, a.mask_stride, a.d_masked_mean};
     if (a.xform == XF_ABSDEV) {
         auto kern = k_select<T, XF_ABSDEV>;
