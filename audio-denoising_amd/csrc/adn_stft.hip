@@ -792,21 +792,21 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     const int64_t Ts = row_stride(Tmax);
     const size_t nS = (size_t)n_sig * F * Ts, nR = (size_t)n_sig * F;
     ADN_TRY(ws_reserve(c, ws_need(nS, sizeof(T)) + ws_need(n_sig, 8) + 2 * ws_need(nR, 8) + ws_need(nR, sizeof(T)) +
-                              ws_need((size_t)n_sig * nv_max, 1) + ws_need((size_t)n_sig * Tmax, 1) + ws_need(n_sig, 4) +
+                              ws_need((size_t)n_sig * nv_max, 1) + ws_need((size_t)n_sig * Ts, 1) + ws_need(n_sig, 4) +
                               2 * select_ws_bytes(n_sig * F, Tmax)));
     T *S = ws_take<T>(c, nS);
     int64_t *Tn = ws_take<int64_t>(c, n_sig);
     double *p10 = ws_take<double>(c, nR), *sraw = ws_take<double>(c, nR);
     T *gain = d_gain ? d_gain : ws_take<T>(c, nR);
     unsigned char *speech = ws_take<unsigned char>(c, (size_t)n_sig * nv_max);
-    unsigned char *vad = ws_take<unsigned char>(c, (size_t)n_sig * Tmax);
+    unsigned char *vad = ws_take<unsigned char>(c, (size_t)n_sig * Ts);   // rows padded like S
     Signals sg{d_off, d_len, n_ch, n_fft, hop, 1};
     hipLaunchKernelGGL(k_frame_counts, dim3((unsigned)ceil_div(n_sig, 256)), dim3(256), 0, c->stream, sg, n_sig, Tn);
     if (vad_guided) {
         hipLaunchKernelGGL((k_vad_energy<T>), dim3((unsigned)ceil_div(n_sig * nv_max, 4)), dim3(256), 0, c->stream,
                            d_x, sg, n_sig, frame_len, nv_max, speech);
-        hipLaunchKernelGGL(k_vad_map, dim3((unsigned)ceil_div(n_sig * Tmax, 256)), dim3(256), 0, c->stream, sg, n_sig,
-                           frame_len, nv_max, Tmax, speech, vad);
+        hipLaunchKernelGGL(k_vad_map, dim3((unsigned)ceil_div(n_sig * Ts, 256)), dim3(256), 0, c->stream, sg, n_sig,
+                           frame_len, nv_max, Ts, speech, vad);
     }
     ADN_TRY(rows_dispatch<T>(c, d_x, sg, tb, n_sig, Ts, 1, S, nullptr));
     SelectArgs sa;
@@ -823,7 +823,7 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     if (fuse_mean) {
         sa.d_mask = vad;
         sa.mask_div = F;
-        sa.mask_stride = Tmax;
+        sa.mask_stride = Ts;
         sa.d_masked_mean = sraw;
     }
     ADN_TRY(launch_select<T>(c, S, sa));
@@ -831,7 +831,7 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     sa.d_masked_mean = nullptr;
     if (vad_guided && !fuse_mean) {
         hipLaunchKernelGGL((k_masked_mean<T>), dim3((unsigned)ceil_div(n_sig * F, 4)), dim3(256), 0, c->stream, S, F,
-                           Tmax, Ts, n_sig * F, Tn, vad, sraw);
+                           Ts, Ts, n_sig * F, Tn, vad, sraw);
     } else if (!vad_guided) {
         sa.mode = SEL_MEDIAN;
         sa.d_out = sraw;
