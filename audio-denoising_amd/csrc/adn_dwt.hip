@@ -330,26 +330,71 @@ static int build_channel_map(int n_ch, int wavelet, int level, ChannelMap<T> *ou
     return ADN_OK;
 }
 
+// Frames per thread of the channel-axis kernels: as many as one 16-byte access covers.
+template <typename T, int NCH>
+struct ChVec {
+    static constexpr int FPT = (16 / (int)sizeof(T)) / NCH > 0 ? (16 / (int)sizeof(T)) / NCH : 1;
+    static constexpr bool one_access = FPT * NCH * (int)sizeof(T) == 16;
+};
+
+// Loads FPT consecutive frames (FPT * NCH values).  When they are exactly 16 bytes and the
+// address is 16-byte aligned (uniform per block) that is ONE memory instruction.
+template <typename T, int NCH>
+__device__ __forceinline__ void ch_load(const T *__restrict__ p, T (&v)[ChVec<T, NCH>::FPT * NCH], bool vec, int nf) {
+    constexpr int FPT = ChVec<T, NCH>::FPT, VE = FPT * NCH;
+    if (ChVec<T, NCH>::one_access && vec && nf == FPT) {
+        const float4 q = *reinterpret_cast<const float4 *>(p);
+        const T *e = reinterpret_cast<const T *>(&q);
+#pragma unroll
+        for (int i = 0; i < VE; ++i) v[i] = e[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < VE; ++i) v[i] = i < nf * NCH ? p[i] : (T)0;
+    }
+}
+template <typename T, int NCH>
+__device__ __forceinline__ void ch_store(T *__restrict__ p, const T (&v)[ChVec<T, NCH>::FPT * NCH], bool vec, int nf) {
+    constexpr int FPT = ChVec<T, NCH>::FPT, VE = FPT * NCH;
+    if (ChVec<T, NCH>::one_access && vec && nf == FPT) {
+        float4 q;
+        T *e = reinterpret_cast<T *>(&q);
+#pragma unroll
+        for (int i = 0; i < VE; ++i) e[i] = v[i];
+        *reinterpret_cast<float4 *>(p) = q;
+    } else {
+#pragma unroll
+        for (int i = 0; i < VE; ++i)
+            if (i < nf * NCH) p[i] = v[i];
+    }
+}
+
 // Pass 1: finest-band coefficients of every frame -> D (frames * n_d1 values per block).
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void k_ch_stats(const T *__restrict__ x, T *__restrict__ D,
                                                   BlockGeom g, ChannelMap<T> m,
                                                   int64_t tiles_per_block) {
+    constexpr int FPT = ChVec<T, NCH>::FPT;
     const int64_t b = blockIdx.x / tiles_per_block;
-    const int64_t f = (blockIdx.x % tiles_per_block) * 256 + threadIdx.x;
-    if (f >= g.frames[b]) return;
-    const T *in = x + g.in_off[b] + f * NCH;
-    T v[NCH];
+    const int64_t f0 = ((blockIdx.x % tiles_per_block) * 256 + threadIdx.x) * FPT;
+    const int64_t frames = g.frames[b];
+    if (f0 >= frames) return;
+    const int nf = frames - f0 < FPT ? (int)(frames - f0) : FPT;
+    const T *in = x + g.in_off[b];
+    const bool vec = (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+    T v[FPT * NCH];
+    ch_load<T, NCH>(in + f0 * NCH, v, vec, nf);
+    T *dst = D + b * g.d_stride + f0 * m.n_d1;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) v[i] = in[i];
-    T *dst = D + b * g.d_stride + f * m.n_d1;
+    for (int f = 0; f < FPT; ++f) {
+        if (f >= nf) break;
 #pragma unroll
-    for (int k = 0; k < CH_MAXC; ++k) {
-        if (k >= m.n_coef - m.n_d1 && k < m.n_coef) {
-            T s = 0;
+        for (int k = 0; k < CH_MAXC; ++k) {
+            if (k >= m.n_coef - m.n_d1 && k < m.n_coef) {
+                T s = 0;
 #pragma unroll
-            for (int i = 0; i < NCH; ++i) s += m.W[k][i] * v[i];
-            dst[k - (m.n_coef - m.n_d1)] = s;
+                for (int i = 0; i < NCH; ++i) s += m.W[k][i] * v[f * NCH + i];
+                dst[f * m.n_d1 + k - (m.n_coef - m.n_d1)] = s;
+            }
         }
     }
 }
@@ -361,41 +406,47 @@ __global__ __launch_bounds__(256) void k_ch_apply(const T *__restrict__ x, T *__
                                                   int64_t tiles_per_block,
                                                   const double *__restrict__ thresh, int thr_mode,
                                                   int64_t *__restrict__ zeroed) {
+    constexpr int FPT = ChVec<T, NCH>::FPT;
     const int64_t b = blockIdx.x / tiles_per_block;
-    const int64_t f = (blockIdx.x % tiles_per_block) * 256 + threadIdx.x;
-    const bool live = f < g.frames[b];
+    const int64_t f0 = ((blockIdx.x % tiles_per_block) * 256 + threadIdx.x) * FPT;
+    const int64_t frames = g.frames[b];
+    const bool live = f0 < frames;
     const T t = (T)thresh[b];
     int nz = 0;
     if (live) {
-        const T *in = x + g.in_off[b] + f * NCH;
-        T v[NCH], c[CH_MAXC], o[NCH];
+        const int nf = frames - f0 < FPT ? (int)(frames - f0) : FPT;
+        const T *in = x + g.in_off[b];
+        T *out = y + g.out_off[b];
+        const bool vec_in = (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+        const bool vec_out = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+        T v[FPT * NCH], o[FPT * NCH];
+        ch_load<T, NCH>(in + f0 * NCH, v, vec_in, nf);
 #pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            v[i] = in[i];
-            o[i] = 0;
-        }
+        for (int f = 0; f < FPT; ++f) {
+            T c[CH_MAXC];
 #pragma unroll
-        for (int k = 0; k < CH_MAXC; ++k) {
-            T s = 0;
-            if (k < m.n_coef) {
+            for (int i = 0; i < NCH; ++i) o[f * NCH + i] = 0;
 #pragma unroll
-                for (int i = 0; i < NCH; ++i) s += m.W[k][i] * v[i];
-                if (k >= m.n_approx) {
-                    nz += fabs(s) < t;
-                    s = shrink(s, t, thr_mode);
+            for (int k = 0; k < CH_MAXC; ++k) {
+                T s = 0;
+                if (k < m.n_coef) {
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i) s += m.W[k][i] * v[f * NCH + i];
+                    if (k >= m.n_approx) {
+                        nz += (f < nf && fabs(s) < t) ? 1 : 0;
+                        s = shrink(s, t, thr_mode);
+                    }
                 }
+                c[k] = s;
             }
-            c[k] = s;
+#pragma unroll
+            for (int k = 0; k < CH_MAXC; ++k)
+                if (k < m.n_coef) {
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i) o[f * NCH + i] += m.V[i][k] * c[k];
+                }
         }
-#pragma unroll
-        for (int k = 0; k < CH_MAXC; ++k)
-            if (k < m.n_coef) {
-#pragma unroll
-                for (int i = 0; i < NCH; ++i) o[i] += m.V[i][k] * c[k];
-            }
-        T *dst = y + g.out_off[b] + f * NCH;
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) dst[i] = o[i];
+        ch_store<T, NCH>(out + f0 * NCH, o, vec_out, nf);
     }
     if (zeroed != nullptr) {
         for (int d = 32; d >= 1; d >>= 1) nz += __shfl_xor(nz, d);
@@ -450,7 +501,7 @@ static int channel_denoise(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t
     ADN_TRY(ws_reserve(c, ws_need((size_t)g.n_blocks * g.d_stride, sizeof(T)) +
                           mad_ws_bytes(g.n_blocks, max_frames * m.n_d1)));
     T *D = ws_take<T>(c, (size_t)g.n_blocks * g.d_stride);
-    const int64_t tiles = ceil_div(max_frames, 256);
+    const int64_t tiles = ceil_div(max_frames, 256 * ChVec<T, NCH>::FPT);
     dim3 grid((unsigned)(tiles * g.n_blocks)), block(256);
     hipLaunchKernelGGL((k_ch_stats<T, NCH>), grid, block, 0, c->stream, d_in, D, g, m, tiles);
     double *thresh = nullptr;
