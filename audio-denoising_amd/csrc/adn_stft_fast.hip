@@ -552,19 +552,78 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                     *slot = v;
                 }
             };
-            if (H == W * 64) {
-                // hop == threads per workgroup: a thread owns sample i = tid of every hop, so the
-                // sample offsets inside a frame and the norm are per-thread constants
-                const int i = tid;
+            if (H == W * 64 && R == 4) {
+                // hop == threads per workgroup: a thread owns FOUR consecutive samples
+                // i .. i+3 of every fourth hop, so every LDS access is 16 bytes, the finished
+                // samples leave in one 16-byte store, and the sample offsets inside a frame
+                // and the norm are per-thread constants
+                const int i = (tid & (W * 16 - 1)) * 4;
                 int off[4];
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) off[qq] = natf((qq << LOGH) + i);
-                const float wq = wsq[i];
-                int slot_i = ub % RING;
+                const float4 wq = *reinterpret_cast<const float4 *>(wsq + i);
+                const bool y_vec = (reinterpret_cast<uintptr_t>(ys) & 15) == 0;
+                const int jj0 = tid / (W * 16);                 // 0..3
+                int slot_i = (ub + jj0) % RING;
 #pragma unroll 1
-                for (int jj = 0; jj < nj; ++jj) {
-                    hop_sample(ub + jj, i, acc + slot_i * H + i, off, 4, wq);
-                    slot_i = slot_i + 1 == RING ? 0 : slot_i + 1;
+                for (int jj = jj0; jj < nj; jj += 4) {
+                    const int j = ub + jj;
+                    float4 *slot = reinterpret_cast<float4 *>(acc + slot_i * H + i);
+                    float4 v = *slot;
+                    float4 c[4];
+                    bool ok[4];
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const int u = j - qq;
+                        ok[qq] = u >= ub && u <= ue;
+                        c[qq] = *reinterpret_cast<const float4 *>(fbase + (ok[qq] ? u - base : 0) * (2 * WBUF) + off[qq]);
+                    }
+#pragma unroll
+                    for (int qq = 3; qq >= 0; --qq) {          // oldest frame first
+                        v.x += ok[qq] ? c[qq].x : 0.0f;
+                        v.y += ok[qq] ? c[qq].y : 0.0f;
+                        v.z += ok[qq] ? c[qq].z : 0.0f;
+                        v.w += ok[qq] ? c[qq].w : 0.0f;
+                    }
+                    if (j <= ue || final_group) {
+                        if (j >= ph0 && j < ph1) {
+                            float4 o;
+                            if (j - R + 1 >= 0 && j <= Tn - 1) {
+                                o = float4{v.x * wq.x, v.y * wq.y, v.z * wq.z, v.w * wq.w};
+                            } else {
+                                float nrm[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                                int t_lo = j - R + 1;
+                                t_lo = t_lo < 0 ? 0 : t_lo;
+                                const int t_hi = j < Tn - 1 ? j : Tn - 1;
+                                for (int tt = t_lo; tt <= t_hi; ++tt)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const float w = tb.window[((j - tt) << LOGH) + i + e];
+                                        nrm[e] += w * w;
+                                    }
+                                o = float4{v.x / (nrm[0] > 1e-10f ? nrm[0] : 1.0f), v.y / (nrm[1] > 1e-10f ? nrm[1] : 1.0f),
+                                           v.z / (nrm[2] > 1e-10f ? nrm[2] : 1.0f), v.w / (nrm[3] > 1e-10f ? nrm[3] : 1.0f)};
+                            }
+                            o.x = o.x < -1.0f ? -1.0f : (o.x > 1.0f ? 1.0f : o.x);
+                            o.y = o.y < -1.0f ? -1.0f : (o.y > 1.0f ? 1.0f : o.y);
+                            o.z = o.z < -1.0f ? -1.0f : (o.z > 1.0f ? 1.0f : o.z);
+                            o.w = o.w < -1.0f ? -1.0f : (o.w > 1.0f ? 1.0f : o.w);
+                            float *yp = ys + (int64_t)(j - R / 2) * H + i;
+                            if (y_vec) {
+                                *reinterpret_cast<float4 *>(yp) = o;
+                            } else {
+                                yp[0] = o.x;
+                                yp[1] = o.y;
+                                yp[2] = o.z;
+                                yp[3] = o.w;
+                            }
+                        }
+                        *slot = float4{0.0f, 0.0f, 0.0f, 0.0f};
+                    } else {
+                        *slot = v;
+                    }
+                    slot_i += 4;
+                    slot_i = slot_i >= RING ? slot_i - RING : slot_i;
                 }
             } else {
 #pragma unroll 1
