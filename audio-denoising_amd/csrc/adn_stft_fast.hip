@@ -377,7 +377,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
     }
     __syncthreads();
 
-    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     constexpr bool prof = PROF;
 #pragma unroll 1
     while (next_u <= last_u) {
@@ -399,11 +399,15 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
         if (t <= a_last && !(a.ablate & 1)) {
             c2 r[16];
             load_frame(r, buf, xs, n, a.sg.n_ch, (int64_t)t * H, tb.window, lane);
+            if (prof) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tick(6);
             wave_fft1024<false>(r, buf, tw, lane);
+            tick(7);
             store_natural(r, buf, lane);
             wave_sync();
             split_spectrum(s, buf, rtw, fscale, lane);
             wave_sync();
+            tick(8);
             if (MODE == APPLY_SUBTRACT) {
                 // clean magnitudes of the lane's bins -> raw row in the wave's own buffer, stored
                 // with an offset of RAWPAD so that the box filter can read past both ends
@@ -431,11 +435,37 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                 // box mean along frequency -> shared row of this frame
                 float *mrow = mags + wave * MROW;
                 const float inv_sf = 1.0f / (float)a.sf;
+                if (a.sf == 5) {
+                    // the reference's box (smooth_freq = 5): all reads of a group of bins are
+                    // issued together; same summation order as the general loop
+#pragma unroll
+                    for (int j0 = 0; j0 < 16; j0 += 8) {
+                        float rv[8][5];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+#pragma unroll
+                            for (int d = 0; d < 5; ++d) rv[j][d] = raw[lane + 64 * (j0 + j) + d - 2];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            float fs = 0.0f;
+#pragma unroll
+                            for (int d = 0; d < 5; ++d) fs += rv[j][d];
+                            mrow[lane + 64 * (j0 + j)] = fs * inv_sf;
+                        }
+                    }
+                    if (lane == 0) {
+                        float fs = 0.0f;
+#pragma unroll
+                        for (int d = 0; d < 5; ++d) fs += raw[1024 + d - 2];
+                        mrow[1024] = fs * inv_sf;
+                    }
+                } else {
 #pragma unroll 1
-                for (int k = lane; k <= 1024; k += 64) {
-                    float fs = 0.0f;
-                    for (int df = -fl; df <= fr; ++df) fs += raw[k + df];
-                    mrow[k] = fs * inv_sf;
+                    for (int k = lane; k <= 1024; k += 64) {
+                        float fs = 0.0f;
+                        for (int df = -fl; df <= fr; ++df) fs += raw[k + df];
+                        mrow[k] = fs * inv_sf;
+                    }
                 }
             }
         }
@@ -488,13 +518,16 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                 const float gm = row[512];
                 s.mid = c2{s.mid.x * gm, s.mid.y * gm};
             }
+            tick(9);
             merge_spectrum(s, buf, rtw, lane);
             wave_sync();
             c2 r[16];
 #pragma unroll
             for (int j = 0; j < 16; ++j) r[j] = buf[nat(lane + 64 * j)];
             wave_sync();
+            tick(10);
             wave_fft1024<true>(r, buf, tw, lane);
+            tick(11);
             // time samples of this lane: n = k1 + 16 c + 256 d; apply the synthesis window
             const int b = lane & 3, d = ((b >> 1) | ((b & 1) << 1));
             const c2 *wv = reinterpret_cast<const c2 *>(tb.window) + (lane >> 2) + 256 * d;
@@ -649,7 +682,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
         next_u = ue + 1;
     }
     if (prof && tid == 0)
-        for (int i = 0; i < 6; ++i) atomicAdd(&a.dbg[i], ph[i]);
+        for (int i = 0; i < 12; ++i) atomicAdd(&a.dbg[i], ph[i]);
 }
 
 static size_t apply_lds(int W, int mode, int hop) {
@@ -675,8 +708,8 @@ int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
     a.ablate = c->ablate;
     a.dbg = nullptr;
     if (c->ablate & 16) {       // diagnostics: per-phase cycle totals, printed after the launch
-        ADN_HIP(hipMalloc(&a.dbg, 6 * sizeof(unsigned long long)));
-        ADN_HIP(hipMemset(a.dbg, 0, 6 * sizeof(unsigned long long)));
+        ADN_HIP(hipMalloc(&a.dbg, 12 * sizeof(unsigned long long)));
+        ADN_HIP(hipMemset(a.dbg, 0, 12 * sizeof(unsigned long long)));
     }
     auto kern = a.dbg ? fast::k_apply_fast<W, MODE, true> : fast::k_apply_fast<W, MODE, false>;
     ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -684,12 +717,16 @@ int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.segs_per_sig * n_sig)), dim3(W * 64), lds, c->stream, a);
     ADN_HIP(hipGetLastError());
     if (a.dbg) {
-        unsigned long long hp[6];
+        unsigned long long hp[12];
         ADN_HIP(hipStreamSynchronize(c->stream));
         ADN_HIP(hipMemcpy(hp, a.dbg, sizeof(hp), hipMemcpyDeviceToHost));
         ADN_HIP(hipFree(a.dbg));
         fprintf(stderr, "k_apply_fast<%d> wave-0 cycles: stageA %llu barrier %llu stageB %llu barrier %llu ola %llu barrier %llu (workgroups %lld)\n",
                 MODE, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], (long long)(a.segs_per_sig * n_sig));
+        // the finer marks restart the interval clock: stage A = load + fft + split + rest (hp[0]),
+        // stage B = modify (hp[9]) + merge/reload (hp[10]) + inverse fft (hp[11]) + window/store (hp[2])
+        fprintf(stderr, "  stage A: load %llu fft %llu store+split %llu rest %llu | stage B: modify %llu merge+reload %llu ifft %llu window+store %llu\n",
+                hp[6], hp[7], hp[8], hp[0], hp[9], hp[10], hp[11], hp[2]);
     }
     return ADN_OK;
 }
