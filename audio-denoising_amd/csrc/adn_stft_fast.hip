@@ -337,6 +337,8 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
     float *acc = mags + (MODE == APPLY_SUBTRACT ? (size_t)W * MROW : 0);              // [RING][H]
     float *wsq = acc + (size_t)RING * H;                                              // [H] full-overlap norm
     c2 *twtab = reinterpret_cast<c2 *>(wsq + H);
+    // GAIN mode has LDS to spare: the window lives there (analysis and synthesis reads)
+    float *wtab = reinterpret_cast<float *>(twtab + TWTAB);                           // [2048], GAIN only
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
     const int64_t sig = blockIdx.x / a.segs_per_sig, seg = blockIdx.x % a.segs_per_sig;
     const int64_t n = a.sg.len[sig];
@@ -360,12 +362,18 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
     const float iscale = (float)(tb.wsum / 1024.0);
     c2 *buf = bufs + wave * WBUF;
     float *bufr = reinterpret_cast<float *>(buf);
+    // hop == workgroup size: the overlap-add owns fixed sample positions per thread and applies
+    // the synthesis window (and the inverse-transform scale) there, from four 16-byte loads per
+    // iteration, instead of sixteen 8-byte window loads per frame after the inverse transform
+    const bool win_in_ola = (H == W * 64 && R == 4);
 
     fill_tw_table(twtab, tb.tw, tid, W * 64);
     const LaneTw tw = lane_tw(twtab, lane);
     c2 rtw[8];
     load_rtw(rtw, tb.rtw, lane);
 
+    if (MODE == APPLY_GAIN)
+        for (int i = tid; i < 2048; i += W * 64) wtab[i] = tb.window[i];
     for (int i = tid; i < RING * H; i += W * 64) acc[i] = 0.0f;
     for (int i = tid; i < H; i += W * 64) {
         float s = 0.0f;
@@ -398,7 +406,8 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
         // ---- stage A: spectrum of frame t
         if (t <= a_last && !(a.ablate & 1)) {
             c2 r[16];
-            load_frame(r, buf, xs, n, a.sg.n_ch, (int64_t)t * H, tb.window, lane);
+            if (MODE == APPLY_GAIN) load_frame(r, buf, xs, n, a.sg.n_ch, (int64_t)t * H, wtab, lane);
+            else load_frame(r, buf, xs, n, a.sg.n_ch, (int64_t)t * H, tb.window, lane);
             if (prof) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             tick(6);
             wave_fft1024<false>(r, buf, tw, lane);
@@ -528,13 +537,15 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
             tick(10);
             wave_fft1024<true>(r, buf, tw, lane);
             tick(11);
-            // time samples of this lane: n = k1 + 16 c + 256 d; apply the synthesis window
-            const int b = lane & 3, d = ((b >> 1) | ((b & 1) << 1));
-            const c2 *wv = reinterpret_cast<const c2 *>(tb.window) + (lane >> 2) + 256 * d;
+            if (!win_in_ola) {
+                // time samples of this lane: n = k1 + 16 c + 256 d; apply the synthesis window
+                const int b = lane & 3, d = ((b >> 1) | ((b & 1) << 1));
+                const c2 *wv = reinterpret_cast<const c2 *>(tb.window) + (lane >> 2) + 256 * d;
 #pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                const c2 w = wv[16 * c];
-                r[c] = c2{r[c].x * iscale * w.x, r[c].y * iscale * w.y};
+                for (int c = 0; c < 16; ++c) {
+                    const c2 w = wv[16 * c];
+                    r[c] = c2{r[c].x * iscale * w.x, r[c].y * iscale * w.y};
+                }
             }
             store_natural(r, buf, lane);
         }
@@ -595,6 +606,13 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) off[qq] = natf((qq << LOGH) + i);
                 const float4 wq = *reinterpret_cast<const float4 *>(wsq + i);
+                float4 wsyn[4];                                  // synthesis window * scale at (qq * H + i ..)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const float4 w = MODE == APPLY_GAIN ? *reinterpret_cast<const float4 *>(wtab + (qq << LOGH) + i)
+                                                        : *reinterpret_cast<const float4 *>(tb.window + (qq << LOGH) + i);
+                    wsyn[qq] = float4{w.x * iscale, w.y * iscale, w.z * iscale, w.w * iscale};
+                }
                 const bool y_vec = (reinterpret_cast<uintptr_t>(ys) & 15) == 0;
                 const int jj0 = tid / (W * 16);                 // 0..3
                 int slot_i = (ub + jj0) % RING;
@@ -613,10 +631,10 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                     }
 #pragma unroll
                     for (int qq = 3; qq >= 0; --qq) {          // oldest frame first
-                        v.x += ok[qq] ? c[qq].x : 0.0f;
-                        v.y += ok[qq] ? c[qq].y : 0.0f;
-                        v.z += ok[qq] ? c[qq].z : 0.0f;
-                        v.w += ok[qq] ? c[qq].w : 0.0f;
+                        v.x += ok[qq] ? c[qq].x * wsyn[qq].x : 0.0f;
+                        v.y += ok[qq] ? c[qq].y * wsyn[qq].y : 0.0f;
+                        v.z += ok[qq] ? c[qq].z * wsyn[qq].z : 0.0f;
+                        v.w += ok[qq] ? c[qq].w * wsyn[qq].w : 0.0f;
                     }
                     if (j <= ue || final_group) {
                         if (j >= ph0 && j < ph1) {
@@ -688,7 +706,8 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
 static size_t apply_lds(int W, int mode, int hop) {
     const int R = 2048 / hop;
     return (size_t)W * WBUF * sizeof(c2) + (mode == APPLY_SUBTRACT ? (size_t)W * MROW * sizeof(float) : 0) +
-           (size_t)(W + R) * hop * sizeof(float) + (size_t)hop * sizeof(float) + (size_t)TWTAB * sizeof(c2);
+           (size_t)(W + R) * hop * sizeof(float) + (size_t)hop * sizeof(float) + (size_t)TWTAB * sizeof(c2) +
+           (mode == APPLY_GAIN ? 2048 * sizeof(float) : 0);
 }
 
 }  // namespace fast
