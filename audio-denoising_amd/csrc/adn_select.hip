@@ -1108,7 +1108,15 @@ __global__ void k_big_check(BigState *st, const int64_t *seg_len, int64_t len_di
 
 int64_t select_short_limit() { return BIG_THRESHOLD; }
 
-static int64_t big_cand_cap(int64_t max_len) {
+// Capacity (keys) of a segment's candidate list.  The 4096-key sample brackets about 7 % of the
+// segment (2 * 4.5 sigma of a binomial rank); 30 % head-room on top.  While that fits the lean LDS
+// kernel the capacity is kept that small (its LDS is sized by it: occupancy); beyond, the list is
+// an eighth of the segment and the general kernel reads it from memory.  A segment that gathers
+// more (many equal keys, e.g. silence) is flagged and takes the radix passes instead.
+static int64_t big_cand_cap(int64_t max_len, size_t key_bytes) {
+    const int64_t lds_cap = (int64_t)(SEL_LDS_MAX_BYTES / key_bytes);
+    const int64_t expect = (int64_t)(0.0703 * 1.3 * (double)max_len) + 1024;
+    if ((int64_t)(0.0703 * 1.05 * (double)max_len) + 256 <= lds_cap) return expect < lds_cap ? (expect < 4096 ? 4096 : expect) : lds_cap;
     const int64_t c = max_len / 8 + 1024;
     return c < 16384 ? 16384 : c;
 }
@@ -1116,7 +1124,7 @@ static int64_t big_cand_cap(int64_t max_len) {
 size_t select_ws_bytes(int64_t n_seg, int64_t max_len) {
     if (max_len <= BIG_THRESHOLD) return 0;
     return ws_need((size_t)n_seg, sizeof(BigState)) + ws_need((size_t)n_seg * BIG_BINS, sizeof(uint32_t)) +
-           ws_need((size_t)n_seg * big_cand_cap(max_len), 8) + 4 * ws_need((size_t)n_seg, 8) +
+           ws_need((size_t)n_seg * big_cand_cap(max_len, 4), 8) + 4 * ws_need((size_t)n_seg, 8) +
            ws_need((size_t)n_seg, 4);
 }
 
@@ -1125,7 +1133,7 @@ static int launch_select_big(Ctx *c, const T *d_vals, const SelectArgs &a) {
     constexpr int BITS = KeyT<T>::bits;
     BigState *st = ws_take<BigState>(c, (size_t)a.n_seg);
     uint32_t *ghist = ws_take<uint32_t>(c, (size_t)a.n_seg * BIG_BINS);
-    const int64_t cap = big_cand_cap(a.max_len);
+    const int64_t cap = big_cand_cap(a.max_len, sizeof(typename KeyT<T>::type));
     T *cand = reinterpret_cast<T *>(ws_take<double>(c, (size_t)a.n_seg * cap));
     int64_t *cand_len = ws_take<int64_t>(c, (size_t)a.n_seg);
     unsigned long long *below = ws_take<unsigned long long>(c, (size_t)a.n_seg);
