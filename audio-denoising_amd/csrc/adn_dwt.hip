@@ -641,11 +641,10 @@ int waverec(Ctx *c, const T *d_coeffs, const int64_t *h_band_len, int wavelet, i
     const Taps<T> tp = make_taps<T>(wavelet);
     const int F = tp.F;
     // pywt.waverec: a = cA; for each d: drop a's last sample when len(a) == len(d)+1, then idwt
-    int64_t max_len = 0, total = 0;
+    int64_t max_len = 0;
     for (int i = 0; i <= level; ++i) {
         ADN_REQUIRE(h_band_len[i] >= 1, "band %d is empty", i);
         max_len = h_band_len[i] > max_len ? h_band_len[i] : max_len;
-        total += h_band_len[i];
     }
     const int64_t buf = 2 * max_len + 2;
     ADN_TRY(ws_reserve(c, 2 * ws_need(buf, sizeof(T)) + 4 * 256));
