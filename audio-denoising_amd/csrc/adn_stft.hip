@@ -43,7 +43,11 @@ static int get_tables(Ctx *c, int n_fft, Tables<T> *out) {
         if (c->tables[i].n_fft == n_fft && c->tables[i].elem == (int)sizeof(T)) e = &c->tables[i];
     if (!e) {
         ADN_REQUIRE(c->n_tables < 16, "too many distinct (n_fft, precision) pairs on one context");
-        const size_t count = (size_t)n_fft + 2 * (Nc / 2) + 2 * (Nc / 2 + 1);
+        // n_fft = 2048: the inter-pass twiddles of the register-resident transform (15 * 64 + 15 * 4
+        // complex values, the layout of fast::fill_tw_table) are appended, ready to be copied to LDS
+        const size_t fast_n = n_fft == 2048 ? 2 * (15 * 64 + 15 * 4) : 0;
+        const size_t fast_off = ((size_t)n_fft + 2 * (Nc / 2) + 2 * (Nc / 2 + 1) + 3) & ~size_t(3);   // 16-byte aligned
+        const size_t count = fast_off + fast_n;
         std::vector<T> h(count);
         double wsum = 0.0;
         for (int k = 0; k < n_fft; ++k) {
@@ -63,6 +67,17 @@ static int get_tables(Ctx *c, int n_fft, Tables<T> *out) {
             rtw[2 * k] = (T)cos(a);
             rtw[2 * k + 1] = (T)sin(a);
         }
+        if (fast_n) {
+            T *ft = h.data() + fast_off;
+            auto w1024 = [&](int k, T *dst) {          // exp(-2 pi i k / 1024) from the rounded table above
+                k &= 1023;
+                const T re = tw[2 * (k & 511)], im = tw[2 * (k & 511) + 1];
+                dst[0] = (k & 512) ? -re : re;
+                dst[1] = (k & 512) ? -im : im;
+            };
+            for (int i = 0; i < 15 * 64; ++i) w1024((i & 63) * ((i >> 6) + 1), ft + 2 * i);
+            for (int i = 0; i < 15 * 4; ++i) w1024(16 * (i & 3) * ((i >> 2) + 1), ft + 2 * (15 * 64 + i));
+        }
         void *dev = nullptr;
         ADN_HIP(hipMalloc(&dev, count * sizeof(T)));
         ADN_HIP(hipMemcpy(dev, h.data(), count * sizeof(T), hipMemcpyHostToDevice));
@@ -76,6 +91,9 @@ static int get_tables(Ctx *c, int n_fft, Tables<T> *out) {
     out->window = base;
     out->tw = reinterpret_cast<const V *>(base + n_fft);
     out->rtw = reinterpret_cast<const V *>(base + n_fft + 2 * (Nc / 2));
+    out->fast_tw = n_fft == 2048
+                       ? reinterpret_cast<const V *>(base + (((size_t)n_fft + 2 * (Nc / 2) + 2 * (Nc / 2 + 1) + 3) & ~size_t(3)))
+                       : nullptr;
     out->wsum = e->wsum;
     out->n_fft = n_fft;
     out->logc = logc;

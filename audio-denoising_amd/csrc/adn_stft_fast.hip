@@ -103,10 +103,12 @@ __device__ __forceinline__ c2 w1024(const c2 *__restrict__ tw, int k) {
     return (k & 512) ? c2{-v.x, -v.y} : v;
 }
 
-// Cooperative fill by the whole workgroup; the caller synchronises before first use.
-__device__ __forceinline__ void fill_tw_table(c2 *tab, const c2 *__restrict__ tw, int tid, int nthreads) {
-    for (int i = tid; i < 15 * 64; i += nthreads) tab[i] = w1024(tw, (i & 63) * ((i >> 6) + 1));
-    for (int i = tid; i < 15 * 4; i += nthreads) tab[15 * 64 + i] = w1024(tw, 16 * (i & 3) * ((i >> 2) + 1));
+// Cooperative fill by the whole workgroup from the precomputed image (16-byte copies, the table
+// offset inside the blob is 16-byte aligned); the caller synchronises before first use.
+__device__ __forceinline__ void fill_tw_table(c2 *tab, const c2 *__restrict__ image, int tid, int nthreads) {
+    const float4 *src = reinterpret_cast<const float4 *>(image);
+    float4 *dst = reinterpret_cast<float4 *>(tab);
+    for (int i = tid; i < TWTAB / 2; i += nthreads) dst[i] = src[i];
 }
 
 __device__ __forceinline__ LaneTw lane_tw(const c2 *tab, int lane) {
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ 
     if (t0 >= Tn) return;
     const float *xs = x + sg.off[sig];
     c2 *buf = bufs + (size_t)wave * WBUF;
-    fill_tw_table(twtab, tb.tw, threadIdx.x, W * 64);
+    fill_tw_table(twtab, tb.fast_tw, threadIdx.x, W * 64);
     __syncthreads();
     const LaneTw tw = lane_tw(twtab, lane);
     c2 rtw[8];
@@ -311,9 +313,20 @@ __global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ 
     }
     __syncthreads();
     const int nft = (int)((Tn - t0) < FT ? (Tn - t0) : FT);
-    for (int idx = threadIdx.x; idx < 1025 * FT; idx += W * 64) {
-        const int k = idx / FT, ft = idx % FT;
-        if (ft < nft) S[((size_t)sig * 1025 + k) * Tmax + t0 + ft] = tile[k * ts + ft];
+    float *Srow = S + (size_t)sig * 1025 * Tmax + t0;
+    if (nft == FT && (FT & 3) == 0 && (reinterpret_cast<uintptr_t>(Srow) & 15) == 0 && (Tmax & 3) == 0) {
+        // four frames of one bin per 16-byte store
+        const int q4 = FT / 4;
+        for (int idx = threadIdx.x; idx < 1025 * q4; idx += W * 64) {
+            const int k = idx / q4, f4 = (idx % q4) * 4;
+            const float *tp = tile + k * ts + f4;
+            *reinterpret_cast<float4 *>(Srow + (size_t)k * Tmax + f4) = float4{tp[0], tp[1], tp[2], tp[3]};
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < 1025 * FT; idx += W * 64) {
+            const int k = idx / FT, ft = idx % FT;
+            if (ft < nft) Srow[(size_t)k * Tmax + ft] = tile[k * ts + ft];
+        }
     }
     if (sig_max != nullptr) {
         for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
@@ -367,7 +380,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
     // iteration, instead of sixteen 8-byte window loads per frame after the inverse transform
     const bool win_in_ola = (H == W * 64 && R == 4);
 
-    fill_tw_table(twtab, tb.tw, tid, W * 64);
+    fill_tw_table(twtab, tb.fast_tw, tid, W * 64);
     const LaneTw tw = lane_tw(twtab, lane);
     c2 rtw[8];
     load_rtw(rtw, tb.rtw, lane);

@@ -42,6 +42,7 @@ struct Tables {
     const T *window;
     const typename Vec2<T>::type *tw;
     const typename Vec2<T>::type *rtw;
+    const typename Vec2<T>::type *fast_tw;   // n_fft 2048 only: LDS image of the register-resident transform's twiddles
     double wsum;
     int n_fft, logc;   // logc = log2(N/2)
 };
