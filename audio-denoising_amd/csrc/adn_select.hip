@@ -563,12 +563,27 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_lds(const T *__restrict_
             }
         }
         __syncthreads();
-        const uint32_t h = hist[tid];
-        const uint32_t before = block_excl_scan(h, wsum);
-        if (r >= before && r < before + h) {
-            s_digit = tid;
-            s_before = before;
-            s_count = h;
+        // bin of s[r0]: one wave scans the 256 counters (4 per lane), no further barriers
+        if (tid < 64) {
+            const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2v = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+            const uint32_t sum = c0 + c1 + c2v + c3;
+            uint32_t incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if (tid >= d) incl += o;
+            }
+            const unsigned long long m = __ballot(incl > r);
+            if (m && tid == (int)__ffsll(m) - 1) {
+                uint32_t bef = incl - sum, cnt = c0;
+                int dg = 4 * tid;
+                if (r >= bef + cnt) { bef += cnt; cnt = c1; ++dg;
+                    if (r >= bef + cnt) { bef += cnt; cnt = c2v; ++dg;
+                        if (r >= bef + cnt) { bef += cnt; cnt = c3; ++dg; } } }
+                s_digit = (uint32_t)dg;
+                s_before = bef;
+                s_count = cnt;
+            }
         }
         __syncthreads();
         const uint32_t digit = s_digit, in_bin = s_count;
@@ -578,7 +593,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_lds(const T *__restrict_
         if (!together) {
             // s[r0] is the largest key of its bin and s[r1] the smallest key of the next
             // non-empty bin: one sweep settles both
-            if (h && (uint32_t)tid > digit) atomicMin(&s_next, (uint32_t)tid);
+            if (hist[tid] && (uint32_t)tid > digit) atomicMin(&s_next, (uint32_t)tid);
             __syncthreads();
             const K pre_hi = (prefix << 8) | (K)s_next;
             K lo_max = 0, hi_min = ~(K)0;
