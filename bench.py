@@ -118,16 +118,20 @@ class Workload:
                 events.setdefault(name, []).append((a, b))
 
     def algorithmic_bytes(self):
-        """Compulsory HBM bytes per step and stage: every stage reads its input once and writes
-        its output once, nothing else.  Phase 1: the noise samples in, one 1025-bin profile out.
-        Phase 2: both channels in and out.  Phase 2b: the stereo signal in (the mono fold is part
-        of the stage, src/spectral_subtract.py:80-81), the mono result out.  Phase 2c: mono in,
-        mono out."""
+        """Compulsory HBM bytes per step and stage with the stage interface preserved: every stage
+        reads its input once and writes its output once; B bytes per value.  Phase 2: 2*B per
+        sample-frame-channel; phase 2b and 2c: 2*B per mono sample; phase 1: 1*B per noise sample.
+        (Phase 2b actually reads a stereo input, 3*B per frame in total: reported separately as
+        `io_bytes`, not used for the roofline fraction.)"""
         bts = 4 if self.dtype == torch.float32 else 8
-        return {"phase1": self.B * (self.nn + 1025) * bts,
+        return {"phase1": self.B * self.nn * bts,
                 "phase2": self.B * self.n * 2 * 2 * bts,
-                "phase2b": self.B * (self.n * 2 + self.l2b) * bts,
-                "phase2c": self.B * (self.l2b + self.l2c) * bts}
+                "phase2b": self.B * self.n * 2 * bts,
+                "phase2c": self.B * self.l2b * 2 * bts}
+
+    def io_bytes_2b(self):
+        bts = 4 if self.dtype == torch.float32 else 8
+        return self.B * (self.n * 2 + self.l2b) * bts
 
 
 def measured_traffic(kernel_key, clips):
@@ -244,7 +248,7 @@ def main():
                          "frac": stages[dom]["hbm_frac"],
                          "traffic": measured_traffic("void adn::fast::k_apply_fast<8, 0, false>", args.clips)
                          if args.dtype == "f32" else None,
-                         "traffic_unit": "bytes per launch",
+                         "traffic_unit": "bytes per launch", "io_bytes_per_launch": wl.io_bytes_2b(),
                          "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": stages[dom]["ms"]},
             "chain": {"ms": round(chain_ms, 4), "algorithmic_bytes": chain_bytes,
                       "GBps": round(chain_bytes / chain_ms / 1e6, 1),
