@@ -38,6 +38,8 @@ _TYPED = {
     "adn_wavedec": [_vp, _vp, _i64, _i, _i, _i, _vp, _i64, C.POINTER(_i64)],
     "adn_waverec": [_vp, _vp, C.POINTER(_i64), _i, _i, _i, _vp, _i64, C.POINTER(_i64)],
     "adn_noise_psd": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _d, _d, _i, _i, _vp],
+    "adn_band_summary": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, C.POINTER(_d), C.POINTER(_d), _i,
+                         C.POINTER(_d), _vp, _vp, _vp, _vp],
     "adn_spectral_subtract": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _i, _i, _d, _d, _i, _i, _vp, _vp],
     "adn_wiener": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _d, _i, _i, _vp, _vp, _vp],
     "adn_window_rms": [_vp, _vp, _i64, _i, _i64, _vp],

@@ -196,6 +196,30 @@ class Engine:
                    float(spectral_floor), int(freq_bins), int(time_frames), _ptr(out))
         return out
 
+    def band_summary(self, x, lens, sample_rate, bands, percentiles=(95.0, 50.0), n_ch=1, n_fft=2048, hop=512,
+                     padded=True, offsets=None, want_time_mean=True, want_mag=False):
+        """Phase-1 analysis summaries of a batch (src/analyze_audio.py:50-62, :161).  bands: list of
+        (lo_hz, hi_hz).  Returns (mean_mag[n_sig, n_bands], perc_db[n_perc, n_sig, n_bands],
+        time_mean[n_sig, T_max] or None[, mag[n_sig, F, T_max]]), the first two as float64 device tensors."""
+        import ctypes as C
+        starts, lens = self._signals(lens, n_ch, n_fft)
+        if offsets is not None:
+            starts = np.asarray(offsets, dtype=np.int64)
+        nb, npc, ns = len(bands), len(percentiles), len(lens)
+        lo = (C.c_double * max(nb, 1))(*[float(b[0]) for b in bands])
+        hi = (C.c_double * max(nb, 1))(*[float(b[1]) for b in bands])
+        pc = (C.c_double * max(npc, 1))(*[float(p) for p in percentiles])
+        mean = torch.empty((ns, nb), dtype=torch.float64, device=x.device)
+        perc = torch.empty((npc, ns, nb), dtype=torch.float64, device=x.device)
+        t_max = self.stft_num_frames(int(lens.max()), n_fft, hop, padded)
+        tmean = torch.zeros((ns, t_max), dtype=x.dtype, device=x.device) if want_time_mean else None
+        d_off, d_len = self._i64(starts), self._i64(lens)
+        mag = torch.zeros((ns, n_fft // 2 + 1, t_max), dtype=x.dtype, device=x.device) if want_mag else None
+        self._call("adn_band_summary", x.dtype, _ptr(x), ns, _ptr(d_off), _ptr(d_len), int(lens.max()), int(n_ch),
+                   int(sample_rate), int(n_fft), int(hop), int(bool(padded)), nb, lo, hi, npc, pc, _ptr(mean),
+                   _ptr(perc), _ptr(tmean), _ptr(mag))
+        return (mean, perc, tmean, mag) if want_mag else (mean, perc, tmean)
+
     def spectral_subtract(self, x, lens, noise_mag, n_ch=1, n_fft=2048, hop=512, alpha=2.2, beta=0.1,
                           smooth_time=3, smooth_freq=5, offsets=None, out=None, out_offsets=None):
         """Phase 2b on a batch.  noise_mag: (F,) shared or (n_sig, F).  Returns (y, out_lens)

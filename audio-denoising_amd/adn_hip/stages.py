@@ -105,6 +105,97 @@ def noise_profile_main(argv=None):
     print(f"Phase 1 noise profile learned -> {out_npz}")
 
 
+def _band_report(e, x, sr, st, bands, want_mag):
+    """Band summaries of one file on the device -> ({band: {mean_db, p95_db, p50_db}}, time mean, |Z|)."""
+    n_ch = 1 if x.ndim == 1 else x.shape[1]
+    win, hop, padded = int(st["win_length"]), int(st["hop_length"]), bool(st["center"])
+    names = list(bands.keys())
+    res = e.band_summary(_to_device(x).reshape(-1), [x.shape[0]], sr, [tuple(bands[k]) for k in names],
+                         percentiles=(95.0, 50.0), n_ch=n_ch, n_fft=win, hop=hop, padded=padded, want_mag=want_mag)
+    mean, perc, tmean = res[0].cpu().numpy()[0], res[1].cpu().numpy()[:, 0, :], res[2].double().cpu().numpy()[0]
+    summary = {}
+    for i, name in enumerate(names):
+        summary[name] = {"mean_db": float(20 * np.log10(mean[i] + 1e-12)), "p95_db": float(perc[0, i]),
+                         "p50_db": float(perc[1, i])}
+    mag = res[3].double().cpu().numpy()[0] if want_mag else None
+    return summary, tmean, mag
+
+
+def analyze_audio_main(argv=None):
+    """src/analyze_audio.py (phase-1 analysis): band-energy summaries of the interview and the noise
+    sample, frame-wise mean noise magnitude, VAD frame count -> logs/phase1_analysis.json; the two
+    spectrogram plots are drawn on the host from the device's magnitude matrix when matplotlib is present."""
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", required=True)
+    ap.add_argument("--input", default=None)
+    ap.add_argument("--noise", default=None)
+    args = ap.parse_args(argv)
+    cfg = _load_config(args.config)
+    seed = cfg.get("seed", 42)
+    paths = cfg.get("paths", {})
+    input_path = args.input or cfg["paths"]["input"]
+    key = "noise" if "noise" in paths else ("noise_sample" if "noise_sample" in paths else None)
+    if key is None:
+        raise KeyError("Config missing paths.noise or paths.noise_sample")
+    noise_path = args.noise or paths[key]
+    out_dir, rep_dir, logs_dir = cfg["paths"]["outputs_dir"], cfg["paths"]["reports_dir"], cfg["paths"]["logs_dir"]
+    print(f"[DEBUG] CWD: {os.getcwd()}")
+    print(f"[DEBUG] input_path: {input_path}")
+    print(f"[DEBUG] noise_path: {noise_path}")
+    _mkdirs(out_dir, rep_dir, logs_dir)
+    ana = cfg["analysis"]
+    sr_cfg, st, spec_cfg = ana.get("samplerate", None), ana["stft"], ana["spectrogram"]
+    bands, vad_cfg = ana["child_bands_hz"], ana["vad"]
+    if str(st["window"]).lower() not in ("hann", "hanning"):
+        raise NotImplementedError("only the Hann window of the reference configs is implemented")
+    if int(st["n_fft"]) != int(st["win_length"]):
+        raise NotImplementedError("n_fft must equal win_length (all reference configs)")
+    x, sr_x = wavio.read(input_path)
+    n, sr_n = wavio.read(noise_path)
+    if sr_cfg and sr_x != sr_cfg:
+        print(f"[WARN] Interview SR {sr_x} != config {sr_cfg}. Proceeding with {sr_x}.")
+    if sr_x != sr_n:
+        print(f"[WARN] Interview SR {sr_x} != noise SR {sr_n}. Proceeding independently.")
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+    except ImportError:                                    # the report does not depend on the plots
+        plt = None
+        print("[WARN] matplotlib not importable: spectrogram plots skipped.")
+    e = _engine()
+    sum_x, _, mag_x = _band_report(e, x, sr_x, st, bands, plt is not None)
+    sum_n, tmean_n, mag_n = _band_report(e, n, sr_n, st, bands, plt is not None)
+    vad_enabled = vad_cfg.get("enabled", True)
+    frame_len = int(sr_x * vad_cfg.get("frame_ms", 30) / 1000)
+    frame_len = frame_len if frame_len > 0 else 1
+    if plt is not None:
+        win, hop, padded = int(st["win_length"]), int(st["hop_length"]), bool(st["center"])
+        for mag, sr, length, title, name in ((mag_x, sr_x, x.shape[0], "Interview Spectrogram", "phase1_interview_spectrogram.png"),
+                                             (mag_n, sr_n, n.shape[0], "Noise Sample Spectrogram", "phase1_noise_spectrogram.png")):
+            T = mag.shape[1]
+            n_pad = (T - 1) * hop + win if padded else length
+            t = np.arange(win / 2, n_pad - win / 2 + 1, hop) / float(sr)
+            f = np.fft.rfftfreq(win, 1.0 / sr)
+            fig = plt.figure(figsize=(10, 4))
+            s_db = 20 * np.log10(mag + 1e-12)
+            vmin = np.max(s_db) - spec_cfg["dynamic_range_db"]
+            plt.pcolormesh(t, f, s_db, shading="gouraud", cmap=spec_cfg["cmap"], vmin=vmin, vmax=np.max(s_db))
+            plt.colorbar(label="dB")
+            plt.title(title)
+            plt.xlabel("Time [s]")
+            plt.ylabel("Freq [Hz]")
+            fig.tight_layout()
+            fig.savefig(os.path.join(rep_dir, name), dpi=150)
+            plt.close(fig)
+    report = {"seed": seed, "samplerate_interview": sr_x, "samplerate_noise": sr_n,
+              "child_band_summary_interview_db": sum_x, "child_band_summary_noise_db": sum_n,
+              "noise_profile_time_mean_mag": tmean_n.tolist(),
+              "vad_frames": int(x.shape[0] / frame_len) if vad_enabled else 0}
+    _dump(os.path.join(logs_dir, "phase1_analysis.json"), report)
+    print("Phase 1 analysis complete. Plots in reports/plots and JSON in logs/.")
+
+
 # ------------------------------------------------------------------ phase 2
 def wavelet_denoise_main(argv=None):
     """src/wavelet_denoise.py: AudioDeNoise(input).deNoise(output) plus the sidecar."""

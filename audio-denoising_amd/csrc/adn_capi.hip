@@ -176,6 +176,15 @@ int64_t adn_istft_out_samples(int64_t n, int n_fft, int hop) {
         return adn::noise_psd<T>(c, d_x, n_sig, d_off, d_len, max_len, n_ch, n_fft, hop, padded,    \
                                  percentile, spectral_floor, freq_bins, time_frames, d_baseline);   \
     }                                                                                               \
+    int adn_band_summary_##SUF(adn_ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off,       \
+                               const int64_t *d_len, int64_t max_len, int n_ch, int sample_rate,    \
+                               int n_fft, int hop, int padded, int n_bands, const double *h_lo_hz,  \
+                               const double *h_hi_hz, int n_perc, const double *h_perc,             \
+                               double *d_mean_mag, double *d_perc_db, T *d_time_mean, T *d_mag) {   \
+        return adn::band_summary<T>(c, d_x, n_sig, d_off, d_len, max_len, n_ch, sample_rate, n_fft, \
+                                    hop, padded, n_bands, h_lo_hz, h_hi_hz, n_perc, h_perc,         \
+                                    d_mean_mag, d_perc_db, d_time_mean, d_mag);                     \
+    }                                                                                               \
     int adn_spectral_subtract_##SUF(adn_ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off,  \
                                     const int64_t *d_len, int64_t max_len, int n_ch,                \
                                     const T *d_noise, int64_t noise_stride, int n_fft, int hop,     \

@@ -5,7 +5,7 @@
 namespace adn {
 
 // ------------------------------------------------ segmented order statistics
-enum { SEL_MEDIAN = 0, SEL_PERCENTILE = 1 };
+enum { SEL_MEDIAN = 0, SEL_PERCENTILE = 1, SEL_PERCENTILE_DB20 = 2 };
 enum { XF_NONE = 0, XF_ABSDEV = 1 };
 
 struct SelectArgs {
@@ -65,6 +65,12 @@ template <typename T>
 int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int64_t *d_len,
            int64_t max_len, int n_ch, int sample_rate, int n_fft, int hop, double update_ms,
            int kernel_bins, int vad_guided, T *d_y, const int64_t *d_y_off, T *d_gain);
+
+template <typename T>
+int band_summary(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int64_t *d_len,
+                 int64_t max_len, int n_ch, int sample_rate, int n_fft, int hop, int padded, int n_bands,
+                 const double *h_lo_hz, const double *h_hi_hz, int n_perc, const double *h_perc,
+                 double *d_mean_mag, double *d_perc_db, T *d_time_mean, T *d_mag);
 
 // ------------------------------------------------------------------ misc
 template <typename T>

@@ -13,6 +13,8 @@
 // anywhere in the segment gives NaN.
 #include <type_traits>
 
+#include <algorithm>
+
 #include "adn_kernels.hpp"
 
 namespace adn {
@@ -33,6 +35,24 @@ __device__ __forceinline__ void hist_add_matched(uint32_t *hist, uint32_t digit,
         const int lane = threadIdx.x & 63;
         if (lane == __ffsll((long long)m) - 1) atomicAdd(&hist[digit], (uint32_t)__popcll(m));
     }
+}
+
+// Value of a selection from its two order statistics a <= b (numpy rules: the median of an even
+// count is the mean of the middle pair; percentiles interpolate linearly with numpy's t >= 0.5
+// branch, in the array's dtype).  SEL_PERCENTILE_DB20 interpolates 20*log10(v + 1e-12) of the two
+// order statistics instead (the percentile of a dB-converted array, in binary64: the map is monotone).
+template <typename T>
+__device__ __forceinline__ double select_result(T a, T b, bool same, double frac, int mode) {
+    if (mode == SEL_MEDIAN) return same ? (double)a : (double)(T)((a + b) / (T)2);
+    double da = (double)a, db = (double)b;
+    if (mode == SEL_PERCENTILE_DB20) {
+        da = 20.0 * log10(da + 1e-12);
+        db = 20.0 * log10(db + 1e-12);
+    }
+    const double diff = db - da;
+    double res = frac >= 0.5 ? db - diff * (1.0 - frac) : da + diff * frac;
+    if (same) res = da;
+    return mode == SEL_PERCENTILE_DB20 ? res : (double)(T)res;
 }
 
 // Exclusive prefix sum of one value per thread over the 256-thread workgroup.
@@ -360,14 +380,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
             res = __longlong_as_double(0x7FF8000000000000ll);
         } else {
             const T a = val_of(k0), b = val_of(k1);
-            if (mode == SEL_MEDIAN) {
-                res = (r0 == r1) ? (double)a : (double)(T)((a + b) / (T)2);
-            } else {
-                const double da = (double)a, db = (double)b, diff = db - da;
-                res = frac >= 0.5 ? db - diff * (1.0 - frac) : da + diff * frac;
-                if (r0 == r1) res = da;
-                res = (double)(T)res;
-            }
+            res = select_result<T>(a, b, r0 == r1, frac, mode);
         }
         out[seg] = res;
         if (mm.out) {
@@ -631,14 +644,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_lds(const T *__restrict_
             res = __longlong_as_double(0x7FF8000000000000ll);
         } else {
             const T a = val_of((K)(k0 + kmin)), b = val_of((K)(k1 + kmin));
-            if (mode == SEL_MEDIAN) {
-                res = (r0 == r1) ? (double)a : (double)(T)((a + b) / (T)2);
-            } else {
-                const double da = (double)a, db = (double)b, diff = db - da;
-                res = frac >= 0.5 ? db - diff * (1.0 - frac) : da + diff * frac;
-                if (r0 == r1) res = da;
-                res = (double)(T)res;
-            }
+            res = select_result<T>(a, b, r0 == r1, frac, mode);
         }
         out[seg] = res;
         if (MASKED) {
@@ -899,16 +905,7 @@ __global__ void k_big_finish(const BigState *__restrict__ st, const int64_t *__r
     const K k0 = (K)s.k0;
     const K k1 = s.need_extra ? (K)s.min_gt : (K)s.k1;
     const T a = val_of(k0), b = val_of(k1);
-    double res;
-    if (mode == SEL_MEDIAN) {
-        res = (r0 == r1) ? (double)a : (double)(T)((a + b) / (T)2);
-    } else {
-        const double da = (double)a, db = (double)b, diff = db - da;
-        res = frac >= 0.5 ? db - diff * (1.0 - frac) : da + diff * frac;
-        if (r0 == r1) res = da;
-        res = (double)(T)res;
-    }
-    out[seg] = res;
+    out[seg] = select_result<T>(a, b, r0 == r1, frac, mode);
 }
 
 // ---- bracket fast path ---------------------------------------------------------------
@@ -1139,7 +1136,7 @@ static int64_t big_cand_cap(int64_t max_len, size_t key_bytes) {
 size_t select_ws_bytes(int64_t n_seg, int64_t max_len) {
     if (max_len <= BIG_THRESHOLD) return 0;
     return ws_need((size_t)n_seg, sizeof(BigState)) + ws_need((size_t)n_seg * BIG_BINS, sizeof(uint32_t)) +
-           ws_need((size_t)n_seg * big_cand_cap(max_len, 4), 8) + 4 * ws_need((size_t)n_seg, 8) +
+           ws_need((size_t)n_seg * std::max(big_cand_cap(max_len, 4), big_cand_cap(max_len, 8)), 8) + 4 * ws_need((size_t)n_seg, 8) +
            ws_need((size_t)n_seg, 4);
 }
 

@@ -18,6 +18,8 @@
 // HBM sees the input once and the output once.
 #include <math.h>
 
+#include <algorithm>
+
 #include <vector>
 
 #include <type_traits>
@@ -871,6 +873,163 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     return apply_dispatch<T, APPLY_GAIN>(c, a, n_sig, Tmax);
 }
 
+// ------------------------------------------------ phase-1 analysis summaries
+// (src/analyze_audio.py:50-62 summarize_band_energy, :161 noise_profile_time_mean_mag)
+struct BandDesc {
+    int k_lo[16], n_bins[16];      // first bin and bin count per band
+    int64_t bin_prefix[17];        // bins of the bands before band b
+    int n_bands;
+};
+
+// seg_off / seg_len of the flattened band values: band b of signal s holds n_bins[b] * Tn[s] values
+__global__ void k_band_segments(BandDesc bd, const int64_t *__restrict__ Tn, int64_t n_sig, int64_t Tmax,
+                                int64_t *seg_off, int64_t *seg_len) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n_sig * bd.n_bands) return;
+    const int64_t sig = i / bd.n_bands;
+    const int b = (int)(i % bd.n_bands);
+    seg_off[i] = (sig * bd.bin_prefix[bd.n_bands] + bd.bin_prefix[b]) * Tmax;
+    seg_len[i] = (int64_t)bd.n_bins[b] * Tn[sig];
+}
+
+// Copies the band's rows (frames < Tn) into one contiguous segment and accumulates their sum.
+template <typename T>
+__global__ __launch_bounds__(256) void k_band_gather(const T *__restrict__ S, int F, int64_t Ts, BandDesc bd,
+                                                     const int64_t *__restrict__ Tn,
+                                                     const int64_t *__restrict__ seg_off, T *__restrict__ B,
+                                                     double *__restrict__ sum) {
+    const int64_t sig = blockIdx.z;
+    const int b = blockIdx.y;
+    const int64_t T_ = Tn[sig];
+    const int64_t seg = sig * bd.n_bands + b;
+    const int64_t total = (int64_t)bd.n_bins[b] * T_;
+    double acc = 0.0;
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t k = i / T_, t = i % T_;
+        const T v = S[(sig * F + bd.k_lo[b] + k) * Ts + t];
+        B[seg_off[seg] + i] = v;
+        acc += (double)v;
+    }
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if ((threadIdx.x & 63) == 0 && acc != 0.0) atomicAdd(&sum[seg], acc);
+}
+
+__global__ void k_band_mean(const double *__restrict__ sum, const int64_t *__restrict__ seg_len, int64_t n,
+                            double *__restrict__ mean) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < n) mean[i] = seg_len[i] > 0 ? sum[i] / (double)seg_len[i] : __longlong_as_double(0x7FF8000000000000ll);
+}
+
+// time_mean[sig * Tmax + t] = mean over the F bins of frame t
+template <typename T>
+__global__ __launch_bounds__(256) void k_time_mean(const T *__restrict__ S, int F, int64_t Ts, int64_t Tmax,
+                                                   const int64_t *__restrict__ Tn, T *__restrict__ out) {
+    const int64_t sig = blockIdx.y;
+    const int64_t t = blockIdx.x * 256ll + threadIdx.x;
+    if (t >= Tn[sig]) return;
+    // eight rows in flight per thread; the partial sums are combined in a fixed order
+    const T *p = S + sig * F * Ts + t;
+    double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int k = 0;
+    for (; k + 8 <= F; k += 8) {
+        T v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(k + u) * Ts];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a8[u] += (double)v[u];
+    }
+    for (; k < F; ++k) a8[0] += (double)p[(int64_t)k * Ts];
+    const double acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+    out[sig * Tmax + t] = (T)(acc / (double)F);
+}
+
+template <typename T>
+int band_summary(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int64_t *d_len,
+                 int64_t max_len, int n_ch, int sample_rate, int n_fft, int hop, int padded, int n_bands,
+                 const double *h_lo_hz, const double *h_hi_hz, int n_perc, const double *h_perc,
+                 double *d_mean_mag, double *d_perc_db, T *d_time_mean, T *d_mag) {
+    ADN_REQUIRE(c && d_x && d_off && d_len, "null pointer argument");
+    ADN_REQUIRE(n_bands >= 0 && n_bands <= 16 && n_perc >= 0 && n_perc <= 16, "at most 16 bands and 16 percentiles");
+    ADN_REQUIRE(n_bands == 0 || (h_lo_hz && h_hi_hz && d_mean_mag), "band arguments missing");
+    ADN_REQUIRE(n_perc == 0 || (h_perc && d_perc_db), "percentile arguments missing");
+    ADN_REQUIRE(sample_rate >= 1, "sample_rate must be >= 1");
+    ADN_TRY(check_stft_args(n_fft, hop, n_ch));
+    if (n_sig <= 0) return ADN_OK;
+    if (max_len < n_fft) {
+        set_error("window is longer than input signal (n_fft=%d, longest signal=%lld)", n_fft, (long long)max_len);
+        return ADN_ERR_SHORT;
+    }
+    DeviceGuard dg(c->device);
+    ws_reset(c);
+    Tables<T> tb;
+    ADN_TRY(get_tables<T>(c, n_fft, &tb));
+    const int F = n_fft / 2 + 1;
+    // bins of a band: lo <= f_k <= hi with f_k = k * (1 / (n_fft * (1 / fs))) as scipy.fft.rfftfreq builds it
+    BandDesc bd{};
+    bd.n_bands = n_bands;
+    const double val = 1.0 / ((double)n_fft * (1.0 / (double)sample_rate));
+    int64_t band_bins = 0;
+    for (int b = 0; b < n_bands; ++b) {
+        int lo = -1, cnt = 0;
+        for (int k = 0; k < F; ++k) {
+            const double f = (double)k * val;
+            if (f >= h_lo_hz[b] && f <= h_hi_hz[b]) {
+                if (lo < 0) lo = k;
+                ++cnt;
+            }
+        }
+        bd.k_lo[b] = lo < 0 ? 0 : lo;
+        bd.n_bins[b] = cnt;
+        bd.bin_prefix[b] = band_bins;
+        band_bins += cnt;
+    }
+    bd.bin_prefix[n_bands] = band_bins;
+    const int64_t Tmax = stft_frames(max_len, n_fft, hop, padded);
+    const int64_t Ts = row_stride(Tmax);
+    const size_t nS = (size_t)n_sig * F * Ts, nB = (size_t)n_sig * band_bins * Tmax, nseg = (size_t)n_sig * n_bands;
+    int64_t max_seg = 1;
+    for (int b = 0; b < n_bands; ++b) max_seg = std::max<int64_t>(max_seg, (int64_t)bd.n_bins[b] * Tmax);
+    ADN_TRY(ws_reserve(c, ws_need(nS, sizeof(T)) + ws_need(nB, sizeof(T)) + ws_need(n_sig, 8) + 3 * ws_need(nseg, 8) +
+                              (size_t)n_perc * select_ws_bytes((int64_t)nseg, max_seg) + 256));
+    T *S = ws_take<T>(c, nS);
+    T *B = ws_take<T>(c, nB);
+    int64_t *Tn = ws_take<int64_t>(c, n_sig);
+    int64_t *seg_off = ws_take<int64_t>(c, nseg), *seg_len = ws_take<int64_t>(c, nseg);
+    double *sum = ws_take<double>(c, nseg);
+    Signals sg{d_off, d_len, n_ch, n_fft, hop, padded};
+    hipLaunchKernelGGL(k_frame_counts, dim3((unsigned)ceil_div(n_sig, 256)), dim3(256), 0, c->stream, sg, n_sig, Tn);
+    ADN_TRY(rows_dispatch<T>(c, d_x, sg, tb, n_sig, Ts, 0, S, nullptr));
+    if (d_time_mean)
+        hipLaunchKernelGGL((k_time_mean<T>), dim3((unsigned)ceil_div(Tmax, 256), (unsigned)n_sig), dim3(256), 0, c->stream,
+                           S, F, Ts, Tmax, Tn, d_time_mean);
+    if (d_mag)      // the magnitude matrix itself (for the host-side plots), rows of T_max frames
+        ADN_HIP(hipMemcpy2DAsync(d_mag, (size_t)Tmax * sizeof(T), S, (size_t)Ts * sizeof(T), (size_t)Tmax * sizeof(T),
+                                 (size_t)n_sig * F, hipMemcpyDeviceToDevice, c->stream));
+    if (n_bands > 0) {
+        ADN_HIP(hipMemsetAsync(sum, 0, sizeof(double) * nseg, c->stream));
+        hipLaunchKernelGGL(k_band_segments, dim3((unsigned)ceil_div((int64_t)nseg, 256)), dim3(256), 0, c->stream, bd, Tn,
+                           n_sig, Tmax, seg_off, seg_len);
+        const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(max_seg, 256 * 8), 1024);
+        hipLaunchKernelGGL((k_band_gather<T>), dim3(gx, (unsigned)n_bands, (unsigned)n_sig), dim3(256), 0, c->stream, S, F,
+                           Ts, bd, Tn, seg_off, B, sum);
+        hipLaunchKernelGGL(k_band_mean, dim3((unsigned)ceil_div((int64_t)nseg, 256)), dim3(256), 0, c->stream, sum, seg_len,
+                           (int64_t)nseg, d_mean_mag);
+        for (int p = 0; p < n_perc; ++p) {
+            SelectArgs sa;
+            sa.n_seg = (int64_t)nseg;
+            sa.d_seg_off = seg_off;
+            sa.d_seg_len = seg_len;
+            sa.max_len = max_seg;
+            sa.mode = SEL_PERCENTILE_DB20;
+            sa.q = h_perc[p];
+            sa.d_out = d_perc_db + (size_t)p * nseg;
+            ADN_TRY(launch_select<T>(c, B, sa));
+        }
+    }
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
+
 #define ADN_INST(T)                                                                                    \
     template int noise_psd<T>(Ctx *, const T *, int64_t, const int64_t *, const int64_t *, int64_t,   \
                               int, int, int, int, double, double, int, int, T *);                     \
@@ -878,7 +1037,10 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
                                       int64_t, int, const T *, int64_t, int, int, double, double,     \
                                       int, int, T *, const int64_t *);                                \
     template int wiener<T>(Ctx *, const T *, int64_t, const int64_t *, const int64_t *, int64_t, int, \
-                           int, int, int, double, int, int, T *, const int64_t *, T *);
+                           int, int, int, double, int, int, T *, const int64_t *, T *);               \
+    template int band_summary<T>(Ctx *, const T *, int64_t, const int64_t *, const int64_t *, int64_t, \
+                                 int, int, int, int, int, int, const double *, const double *, int,   \
+                                 const double *, double *, double *, T *, T *);
 ADN_INST(float)
 ADN_INST(double)
 

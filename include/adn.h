@@ -159,6 +159,28 @@ int adn_noise_psd_f64(adn_ctx *ctx, const double *d_x, int64_t n_sig, const int6
                       int padded, double percentile, double spectral_floor, int freq_bins,
                       int time_frames, double *d_baseline);
 
+/* Phase-1 analysis summaries (src/analyze_audio.py:24-26 compute_spectrogram, :50-62
+ * summarize_band_energy, :161 noise_profile_time_mean_mag): |STFT| as above, then for signal s
+ * and band b (the bins k with h_lo_hz[b] <= k * sample_rate / n_fft <= h_hi_hz[b], both ends
+ * inclusive, frequencies built like scipy's rfftfreq):
+ *   d_mean_mag[s * n_bands + b]                    = mean of |Z| over the band's bins and all frames
+ *   d_perc_db[(p * n_sig + s) * n_bands + b]       = h_perc[p]-th percentile (linear interpolation) of
+ *                                                    20*log10(|Z| + 1e-12) over the same values
+ *   d_time_mean[s * T_max + t]                     = mean over all bins of |Z[:, t]|  (NULL: skipped)
+ *   d_mag[(s * (n_fft/2+1) + k) * T_max + t]       = |Z[k, t]| itself, for the host-side plots (NULL: skipped)
+ * with T_max = adn_stft_num_frames(max_len, n_fft, hop, padded).  At most 16 bands and 16
+ * percentiles per call; an empty band gives NaN.  h_* arrays are host memory. */
+int adn_band_summary_f32(adn_ctx *ctx, const float *d_x, int64_t n_sig, const int64_t *d_off,
+                         const int64_t *d_len, int64_t max_len, int n_ch, int sample_rate, int n_fft,
+                         int hop, int padded, int n_bands, const double *h_lo_hz,
+                         const double *h_hi_hz, int n_perc, const double *h_perc, double *d_mean_mag,
+                         double *d_perc_db, float *d_time_mean, float *d_mag);
+int adn_band_summary_f64(adn_ctx *ctx, const double *d_x, int64_t n_sig, const int64_t *d_off,
+                         const int64_t *d_len, int64_t max_len, int n_ch, int sample_rate, int n_fft,
+                         int hop, int padded, int n_bands, const double *h_lo_hz,
+                         const double *h_hi_hz, int n_perc, const double *h_perc, double *d_mean_mag,
+                         double *d_perc_db, double *d_time_mean, double *d_mag);
+
 /* Phase 2b (src/spectral_subtract.py:29-46, 79-109): STFT -> max(|Z|-alpha*n,
  * beta*|Z|) -> box filter (smooth_freq x smooth_time, edge replicated) -> keep
  * the phase -> ISTFT (drops n_fft/2 at both ends) -> clip to [-1, 1].

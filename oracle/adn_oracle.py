@@ -451,6 +451,34 @@ def wiener(x, sr, n_fft=2048, hop=512, update_ms=20, kernel_bins=5, vad_guided=T
 # --------------------------------------------------------------------------
 # RMS-window noise profiler (lib/noiseProfiler.py, lib/windowBundle.py, lib/linkedList.py)
 # --------------------------------------------------------------------------
+def band_summary(f, Z, bands):
+    """src/analyze_audio.py:50-62 summarize_band_energy: per band (inclusive frequency range) the dB of
+    the mean magnitude and the 95th / 50th percentile of the dB magnitudes."""
+    mag = np.abs(Z)
+    out = {}
+    for name, (lb, ub) in bands.items():
+        band = mag[(f >= lb) & (f <= ub), :]
+        db = 20 * np.log10(band + 1e-12)
+        out[name] = {"mean_db": float(20 * np.log10(np.mean(band) + 1e-12)),
+                     "p95_db": float(np.percentile(db, 95)), "p50_db": float(np.percentile(db, 50))}
+    return out
+
+
+def analysis_report(x, sr_x, noise, sr_n, bands, n_fft=2048, hop=512, padded=True, seed=42,
+                    vad_enabled=True, frame_ms=30):
+    """The JSON report of src/analyze_audio.py:113-135, 160-170 (plots excluded)."""
+    x, noise = fold_mono(np.asarray(x, dtype=np.float64)), fold_mono(np.asarray(noise, dtype=np.float64))
+    Zx, Zn = stft(x, n_fft, hop, padded=padded), stft(noise, n_fft, hop, padded=padded)
+    fx = stft_axes(len(x), sr_x, n_fft, hop, padded)[0]
+    fn = stft_axes(len(noise), sr_n, n_fft, hop, padded)[0]
+    frame_len = max(int(sr_x * frame_ms / 1000), 1)
+    return {"seed": seed, "samplerate_interview": sr_x, "samplerate_noise": sr_n,
+            "child_band_summary_interview_db": band_summary(fx, Zx, bands),
+            "child_band_summary_noise_db": band_summary(fn, Zn, bands),
+            "noise_profile_time_mean_mag": np.mean(np.abs(Zn), axis=0).tolist(),
+            "vad_frames": int(len(x) / frame_len) if vad_enabled else 0}
+
+
 def window_rms(x, win):
     """Per-window sqrt(sum(x^2)/rows) (lib/windowBundle.py:67-74); the sum runs over
     every channel of the window's rows, the divisor is the row count."""

@@ -382,9 +382,43 @@ def gen_noise_profiler(tmp):
     save("noise_profiler", **out)
 
 
+def gen_analysis(tmp):
+    """src/analyze_audio.py run unmodified (plots go to a temp dir, matplotlib Agg): band summaries,
+    frame-wise mean noise magnitude, VAD frame count, for a stereo input and a mono noise sample."""
+    sr = 16000
+    x = synth.stereo_noisy_speech(48000, sr, 42, 60)
+    noise = synth.white_noise(24000, seed=42, stream=1001)
+    px, pn = os.path.join(tmp, "ana_x.wav"), os.path.join(tmp, "ana_noise.wav")
+    sf.write(px, x, sr)
+    sf.write(pn, noise, sr)
+    cfg = base_config(os.path.join(tmp, "ana"), px, pn)
+    bands = {"crying": [300, 600], "screaming": [1000, 3000], "harmonics": [3000, 4000]}
+    cfg["seed"] = 42
+    cfg["analysis"].update({"samplerate": 44100, "spectrogram": {"cmap": "magma", "dynamic_range_db": 80},
+                            "child_bands_hz": bands,
+                            "vad": {"enabled": True, "frame_ms": 30, "energy_threshold_db": -40, "hangover_frames": 5}})
+    pc = os.path.join(tmp, "ana_cfg.yaml")
+    with open(pc, "w") as fh:
+        yaml.safe_dump(cfg, fh)
+    run_stage("analyze_audio.py", ["--config", pc])
+    report = json.load(open(os.path.join(cfg["paths"]["logs_dir"], "phase1_analysis.json")))
+    plots = sorted(os.listdir(cfg["paths"]["reports_dir"]))
+    meta = {"sr": sr, "n": 48000, "stream": 60, "noise_n": 24000, "noise_stream": 1001, "bands": bands,
+            "n_fft": 2048, "hop": 512, "padded": True, "frame_ms": 30, "plots": plots,
+            "report_keys": sorted(report.keys())}
+    save("analysis", report_json=np.array(json.dumps(report)), meta_json=np.array(json.dumps(meta)),
+         x_bits=np.array(synth.bits_checksum(x)), noise_bits=np.array(synth.bits_checksum(noise)),
+         noise_profile_time=np.array(report["noise_profile_time_mean_mag"]))
+
+
 if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":
+        with tempfile.TemporaryDirectory() as tmp:
+            globals()["gen_" + sys.argv[2]](tmp)
+        sys.exit(0)
     with tempfile.TemporaryDirectory() as tmp:
+        gen_analysis(tmp)
         gen_dwt_primitives()
         gen_denoise_files(tmp)
         gen_block_stats()

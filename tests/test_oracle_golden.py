@@ -220,3 +220,23 @@ def test_noise_profiler(golden):
     ps, _, _ = orc.noise_profiler_predict(xs)
     assert list(ps.shape) == list(g["stereo_pred_shape"])
     _close(ps[::5], g["stereo_pred_strided"], 0)
+
+
+def test_analysis_report_matches_reference(golden):
+    """src/analyze_audio.py run by the fixture generator vs the restatement: band summaries (dB),
+    frame-wise mean noise magnitude, VAD frame count."""
+    g = golden("analysis")
+    m = json.loads(str(g["meta_json"]))
+    ref = json.loads(str(g["report_json"]))
+    x = synth.stereo_noisy_speech(m["n"], m["sr"], 42, m["stream"])
+    noise = synth.white_noise(m["noise_n"], seed=42, stream=m["noise_stream"])
+    assert synth.bits_checksum(x) == int(g["x_bits"]) and synth.bits_checksum(noise) == int(g["noise_bits"])
+    got = orc.analysis_report(x, m["sr"], noise, m["sr"], m["bands"], m["n_fft"], m["hop"], m["padded"])
+    assert sorted(got.keys()) == m["report_keys"]
+    assert got["vad_frames"] == ref["vad_frames"] and got["seed"] == ref["seed"]
+    for key in ("child_band_summary_interview_db", "child_band_summary_noise_db"):
+        for band, vals in ref[key].items():
+            for k, v in vals.items():
+                assert abs(got[key][band][k] - v) <= 1e-9, (key, band, k)
+    a, b = np.array(got["noise_profile_time_mean_mag"]), np.array(ref["noise_profile_time_mean_mag"])
+    assert a.shape == b.shape and np.max(np.abs(a - b)) <= 1e-12
