@@ -479,6 +479,102 @@ def analysis_report(x, sr_x, noise, sr_n, bands, n_fft=2048, hop=512, padded=Tru
             "vad_frames": int(len(x) / frame_len) if vad_enabled else 0}
 
 
+def median_filter_reflect(S, size, axis):
+    """scipy.ndimage.median_filter(S, size=(1, size)) / ((size, 1)), mode='reflect' (edge sample
+    repeated: d c b a | a b c d | d c b a), odd size.  src/hpss_separate.py:54, 57."""
+    S = np.asarray(S, dtype=np.float64)
+    h = size // 2
+    M = np.moveaxis(S, axis, -1)
+    n = M.shape[-1]
+    idx = np.arange(-h, n + h)
+    period = 2 * n
+    idx = np.mod(idx, period)
+    idx = np.where(idx >= n, period - 1 - idx, idx)
+    ext = M[..., idx]
+    win = np.lib.stride_tricks.sliding_window_view(ext, size, axis=-1)
+    out = np.median(win, axis=-1)
+    return np.moveaxis(out, -1, axis)
+
+
+def hpss_masks(S, margin_h=1.0, margin_p=5.0, kernel_size=31, power=2.0):
+    """src/hpss_separate.py:41-67 median_filtering_hpss."""
+    Sh = median_filter_reflect(S, kernel_size, 1)
+    Sp = median_filter_reflect(S, kernel_size, 0)
+    mh = (Sh * margin_h) ** power
+    mp = (Sp * margin_p) ** power
+    total = mh + mp + 1e-10
+    return mh / total, mp / total
+
+
+def hpss_multiband_masks(S, f, bands, margin_h=1.0, margin_p=5.0, kernel_size=31):
+    """src/hpss_separate.py:86-113 multiband_hpss (power stays at its default 2.0 there)."""
+    mask_h, mask_p = np.zeros_like(S), np.zeros_like(S)
+    for lo, hi in bands:
+        bm = (f >= lo) & (f <= hi)
+        if not np.any(bm):
+            continue
+        a, b = hpss_masks(S[bm, :], margin_h, margin_p, kernel_size)
+        mask_h[bm, :] = a
+        mask_p[bm, :] = b
+    return mask_h, mask_p
+
+
+def hpss_apply_mask_type(mask_h, mask_p, mask_type="soft"):
+    """src/hpss_separate.py:126-135."""
+    if mask_type == "binary":
+        return (mask_h > 0.5).astype(float), (mask_p > 0.5).astype(float)
+    if mask_type == "hard":
+        mh = (mask_h > mask_p).astype(float)
+        return mh, 1.0 - mh
+    return mask_h, mask_p
+
+
+def hpss_local_energy(sig, window_size=2048, hop=512):
+    """src/hpss_separate.py:156-161."""
+    return np.array([np.sqrt(np.mean(sig[i:i + window_size] ** 2)) for i in range(0, len(sig) - window_size, hop)])
+
+
+def hpss_preserve_transients(y_h, y_p, y_orig, threshold=0.3, blend=0.7, window_size=2048, hop=512):
+    """src/hpss_separate.py:142-190.  The original is NOT shifted by the n_fft/2 the ISTFT drops."""
+    m = min(len(y_h), len(y_p), len(y_orig))
+    y_h, y_orig = y_h[:m], y_orig[:m]
+    eo, eh = hpss_local_energy(y_orig, window_size, hop), hpss_local_energy(y_h, window_size, hop)
+    k = min(len(eo), len(eh))
+    eo, eh = eo[:k], eh[:k]
+    out = y_h.copy()
+    if k == 0:
+        return out
+    tr = (eo - eh) > threshold * np.max(eo)
+    for i in np.nonzero(tr)[0]:
+        s, e = i * hop, min(i * hop + window_size, m)
+        out[s:e] = blend * y_orig[s:e] + (1 - blend) * y_h[s:e]
+    return out
+
+
+def hpss(x, sr, n_fft=2048, hop=512, margin_h=1.0, margin_p=5.0, kernel_size=31, power=2.0, mask_type="soft",
+         bands=None, preserve_transients=True):
+    """src/hpss_separate.py:233-283: (y_harmonic, y_percussive, metrics) as written to the files / log."""
+    x = fold_mono(np.asarray(x, dtype=np.float64))
+    Z = stft(x, n_fft, hop)
+    S = np.abs(Z)
+    if bands is not None:
+        f = stft_axes(len(x), sr, n_fft, hop)[0]
+        mh, mp = hpss_multiband_masks(S, f, bands, margin_h, margin_p, kernel_size)
+    else:
+        mh, mp = hpss_masks(S, margin_h, margin_p, kernel_size, power)
+    mh, mp = hpss_apply_mask_type(mh, mp, mask_type)
+    y_h, y_p = istft(Z * mh, n_fft, hop), istft(Z * mp, n_fft, hop)
+    if preserve_transients:
+        y_h = hpss_preserve_transients(y_h, y_p, x)
+    mx = max(np.max(np.abs(y_h)), np.max(np.abs(y_p)))
+    if mx > 0.95:
+        y_h, y_p = y_h * (0.95 / mx), y_p * (0.95 / mx)
+    rms = lambda v: float(np.sqrt(np.mean(v ** 2)))
+    met = {"harmonic_rms": rms(y_h), "percussive_rms": rms(y_p), "total_rms": rms(x)}
+    met["harmonic_ratio"] = met["harmonic_rms"] / (met["total_rms"] + 1e-10)
+    return y_h, y_p, met
+
+
 def window_rms(x, win):
     """Per-window sqrt(sum(x^2)/rows) (lib/windowBundle.py:67-74); the sum runs over
     every channel of the window's rows, the divisor is the row count."""

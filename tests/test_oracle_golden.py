@@ -240,3 +240,24 @@ def test_analysis_report_matches_reference(golden):
                 assert abs(got[key][band][k] - v) <= 1e-9, (key, band, k)
     a, b = np.array(got["noise_profile_time_mean_mag"]), np.array(ref["noise_profile_time_mean_mag"])
     assert a.shape == b.shape and np.max(np.abs(a - b)) <= 1e-12
+
+
+def _hpss_kwargs(hp):
+    mb = hp.get("multiband", {})
+    return dict(margin_h=hp["margin_harmonic"], margin_p=hp["margin_percussive"], kernel_size=hp["kernel_size"],
+                power=hp["power"], mask_type=hp["mask_type"], preserve_transients=hp["preserve_transients"],
+                bands=mb.get("bands") if mb.get("enabled", False) else None)
+
+
+@pytest.mark.parametrize("tag", ["default", "multiband_hard", "binary_scaled"])
+def test_hpss_matches_reference(golden, tag):
+    """src/hpss_separate.py (median filtering HPSS, masks, transient preservation, normalisation)."""
+    g = golden("hpss")
+    m = json.loads(str(g["meta_json"]))
+    c = m["cases"][tag]
+    yh, yp, met = orc.hpss(g["x"], m["sr"], **_hpss_kwargs(c["hpss"]))
+    assert yh.shape == g[tag + "_yh"].shape and yp.shape == g[tag + "_yp"].shape
+    assert np.max(np.abs(yh - g[tag + "_yh"])) <= 1e-12
+    assert np.max(np.abs(yp - g[tag + "_yp"])) <= 1e-12
+    for k, v in c["energy"].items():
+        assert abs(met[k] - v) <= 1e-12, k
