@@ -13,6 +13,7 @@ OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM, ERR_SHORT = 0, -1, -2, -3, -4,
 WAVELET = {"db4": 0, "db8": 1}
 EXT = {"per": 0, "periodization": 0, "sym": 1, "symmetric": 1}
 THR = {"soft": 0, "hard": 1}
+MASK = {"soft": 0, "hard": 1, "binary": 2}
 
 _vp, _i, _i64, _d, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_uint64
 
@@ -38,6 +39,8 @@ _TYPED = {
     "adn_wavedec": [_vp, _vp, _i64, _i, _i, _i, _vp, _i64, C.POINTER(_i64)],
     "adn_waverec": [_vp, _vp, C.POINTER(_i64), _i, _i, _i, _vp, _i64, C.POINTER(_i64)],
     "adn_noise_psd": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _d, _d, _i, _i, _vp],
+    "adn_hpss": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _d, _d, _d, _i, _i, C.POINTER(_d), C.POINTER(_d),
+                 _i, _d, _d, _vp, _vp, _vp, _vp],
     "adn_band_summary": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, C.POINTER(_d), C.POINTER(_d), _i,
                          C.POINTER(_d), _vp, _vp, _vp, _vp],
     "adn_spectral_subtract": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _i, _i, _d, _d, _i, _i, _vp, _vp],

@@ -220,6 +220,32 @@ class Engine:
                    _ptr(perc), _ptr(tmean), _ptr(mag))
         return (mean, perc, tmean, mag) if want_mag else (mean, perc, tmean)
 
+    def hpss(self, x, lens, sample_rate, n_ch=1, n_fft=2048, hop=512, kernel_size=31, margin_h=1.0, margin_p=5.0,
+             power=2.0, mask_type="soft", bands=None, preserve_transients=True, threshold=0.3, blend=0.7,
+             offsets=None):
+        """Phase 3 (src/hpss_separate.py) on a batch.  Returns (y_harmonic, y_percussive, out_lens, stats) with
+        the outputs back to back; stats[n_sig, 5] = harmonic RMS, percussive RMS, input RMS, max|y| before
+        scaling, transient frames (float64 device tensor)."""
+        import ctypes as C
+        from ._capi import MASK
+        starts, lens = self._signals(lens, n_ch, n_fft)
+        if offsets is not None:
+            starts = np.asarray(offsets, dtype=np.int64)
+        out_lens = np.array([self.istft_out_samples(n, n_fft, hop) for n in lens], dtype=np.int64)
+        out_off = np.concatenate([[0], np.cumsum(out_lens)[:-1]]).astype(np.int64)
+        yh = torch.empty(int(out_lens.sum()), dtype=x.dtype, device=x.device)
+        yp = torch.empty_like(yh)
+        stats = torch.empty((len(lens), 5), dtype=torch.float64, device=x.device)
+        bands = list(bands) if bands else []
+        lo = (C.c_double * max(len(bands), 1))(*[float(b[0]) for b in bands])
+        hi = (C.c_double * max(len(bands), 1))(*[float(b[1]) for b in bands])
+        d_off, d_len, d_yoff = self._i64(starts), self._i64(lens), self._i64(out_off)
+        self._call("adn_hpss", x.dtype, _ptr(x), len(lens), _ptr(d_off), _ptr(d_len), int(lens.max()), int(n_ch),
+                   int(sample_rate), int(n_fft), int(hop), int(kernel_size), float(margin_h), float(margin_p),
+                   float(power), MASK[mask_type], len(bands), lo, hi, int(bool(preserve_transients)),
+                   float(threshold), float(blend), _ptr(yh), _ptr(yp), _ptr(d_yoff), _ptr(stats))
+        return yh, yp, out_lens, stats
+
     def spectral_subtract(self, x, lens, noise_mag, n_ch=1, n_fft=2048, hop=512, alpha=2.2, beta=0.1,
                           smooth_time=3, smooth_freq=5, offsets=None, out=None, out_offsets=None):
         """Phase 2b on a batch.  noise_mag: (F,) shared or (n_sig, F).  Returns (y, out_lens)

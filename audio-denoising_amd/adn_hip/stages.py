@@ -308,6 +308,83 @@ def wiener_filter_main(argv=None):
 
 
 # ------------------------------------------------------------- orchestrator
+# ------------------------------------------------------------------ phase 3
+def hpss_separate_main(argv=None):
+    """src/hpss_separate.py: harmonic / percussive separation by median filtering of the spectrogram."""
+    ap = argparse.ArgumentParser(description="Phase 3: HPSS Separation")
+    ap.add_argument("--config", required=True, help="Path to config file")
+    ap.add_argument("--input", default=None, help="Input audio (defaults to Phase 2 output)")
+    ap.add_argument("--output_harmonic", default=None)
+    ap.add_argument("--output_percussive", default=None)
+    ap.add_argument("--output_combined", default=None)
+    args = ap.parse_args(argv)
+    cfg = _load_config(args.config)
+    if not cfg.get("phases", {}).get("phase3", {}).get("enabled", True):
+        print("[INFO] Phase 3 (HPSS) is disabled in config, skipping")
+        return
+    seed = cfg.get("hpss", {}).get("seed", cfg.get("global", {}).get("seed", 42))
+    outputs_dir, logs_dir = cfg["paths"]["outputs_dir"], cfg["paths"]["logs_dir"]
+    _mkdirs(outputs_dir, logs_dir)
+    prefer = [os.path.join(outputs_dir, "phase2c_wiener.wav"), os.path.join(outputs_dir, "phase2b_spectral_subtract.wav"),
+              os.path.join(outputs_dir, "phase2_wavelet.wav"), cfg["paths"]["input"]]
+    in_path = args.input or next((p for p in prefer if os.path.exists(p)), cfg["paths"]["input"])
+    out_harmonic = args.output_harmonic or os.path.join(outputs_dir, "phase3_harmonic.wav")
+    out_percussive = args.output_percussive or os.path.join(outputs_dir, "phase3_percussive.wav")
+    out_combined = args.output_combined or os.path.join(outputs_dir, "phase3_hpss.wav")
+    print(f"[INFO] Loading input from {in_path}")
+    x, sr = wavio.read(in_path)
+    n_ch = 1 if x.ndim == 1 else x.shape[1]
+    hp = cfg.get("hpss", {})
+    method = hp.get("method", "median")
+    margin_h, margin_p = hp.get("margin_harmonic", 1.0), hp.get("margin_percussive", 5.0)
+    kernel_size, power = hp.get("kernel_size", 31), hp.get("power", 2.0)
+    mask_type = hp.get("mask_type", "soft")
+    multiband = hp.get("multiband", {}).get("enabled", False)
+    preserve, reversible = hp.get("preserve_transients", True), hp.get("reversible", True)
+    t0 = time.time()
+    print("[INFO] Computing STFT...")
+    print(f"[INFO] Applying HPSS (method={method})...")
+    bands = None
+    if multiband:
+        bands = hp.get("multiband", {}).get("bands", [[0, 250], [250, 2000], [2000, 8000], [8000, 22050]])
+        power = 2.0                 # multiband_hpss never forwards `power` (src/hpss_separate.py:103-105)
+    elif method == "librosa":
+        print("[WARN] librosa not available, using fallback median filtering")
+    e = _engine()
+    yh, yp, _, stats = e.hpss(_to_device(x).reshape(-1), [x.shape[0]], sr, n_ch=n_ch, kernel_size=kernel_size,
+                              margin_h=margin_h, margin_p=margin_p, power=power,
+                              mask_type=mask_type if mask_type in ("hard", "binary") else "soft", bands=bands,
+                              preserve_transients=preserve)
+    print("[INFO] Reconstructing audio...")
+    if preserve:
+        print("[INFO] Preserving transients...")
+    y_harmonic, y_percussive = yh.double().cpu().numpy(), yp.double().cpu().numpy()
+    st = stats.cpu().numpy()[0]
+    print("[INFO] Saving outputs...")
+    if reversible:
+        wavio.write(out_harmonic, y_harmonic, sr)
+        wavio.write(out_percussive, y_percussive, sr)
+        print(f"  - Harmonic: {out_harmonic}")
+        print(f"  - Percussive: {out_percussive}")
+    wavio.write(out_combined, y_harmonic, sr)
+    print(f"  - Combined: {out_combined}")
+    dt = time.time() - t0
+    energy_harmonic, energy_percussive, energy_total = float(st[0]), float(st[1]), float(st[2])
+    _dump(os.path.join(logs_dir, "phase3_hpss.json"), {
+        "phase": "3_hpss", "timestamp": time.strftime("%Y-%m-%d %H:%M:%S"), "seed": seed, "input": in_path,
+        "outputs": {"harmonic": out_harmonic if reversible else None,
+                    "percussive": out_percussive if reversible else None, "combined": out_combined},
+        "parameters": {"method": method, "margin_harmonic": margin_h, "margin_percussive": margin_p,
+                       "kernel_size": kernel_size, "power": hp.get("power", 2.0), "mask_type": mask_type,
+                       "multiband": multiband, "preserve_transients": preserve},
+        "metrics": {"processing_time_sec": dt,
+                    "energy_distribution": {"harmonic_rms": energy_harmonic, "percussive_rms": energy_percussive,
+                                            "total_rms": energy_total,
+                                            "harmonic_ratio": float(energy_harmonic / (energy_total + 1e-10))}}})
+    print(f"[INFO] Phase 3 complete in {dt:.1f}s")
+    print(f"[INFO] Energy distribution: H={energy_harmonic:.3f}, P={energy_percussive:.3f}")
+
+
 def run_step(cmd, log_path):
     """One stage as a subprocess; same log format as src/core_pipeline.py:26-39."""
     log_path = Path(log_path)

@@ -176,6 +176,17 @@ int64_t adn_istft_out_samples(int64_t n, int n_fft, int hop) {
         return adn::noise_psd<T>(c, d_x, n_sig, d_off, d_len, max_len, n_ch, n_fft, hop, padded,    \
                                  percentile, spectral_floor, freq_bins, time_frames, d_baseline);   \
     }                                                                                               \
+    int adn_hpss_##SUF(adn_ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off,               \
+                       const int64_t *d_len, int64_t max_len, int n_ch, int sample_rate, int n_fft,  \
+                       int hop, int kernel_size, double margin_h, double margin_p, double power,     \
+                       int mask_type, int n_bands, const double *h_lo_hz, const double *h_hi_hz,     \
+                       int preserve_transients, double threshold, double blend, T *d_yh, T *d_yp,    \
+                       const int64_t *d_y_off, double *d_stats) {                                    \
+        return adn::hpss_separate<T>(c, d_x, n_sig, d_off, d_len, max_len, n_ch, sample_rate, n_fft, \
+                                     hop, kernel_size, margin_h, margin_p, power, mask_type, n_bands, \
+                                     h_lo_hz, h_hi_hz, preserve_transients, threshold, blend, d_yh,  \
+                                     d_yp, d_y_off, d_stats);                                        \
+    }                                                                                               \
     int adn_band_summary_##SUF(adn_ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off,       \
                                const int64_t *d_len, int64_t max_len, int n_ch, int sample_rate,    \
                                int n_fft, int hop, int padded, int n_bands, const double *h_lo_hz,  \

@@ -72,6 +72,13 @@ int band_summary(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, cons
                  const double *h_lo_hz, const double *h_hi_hz, int n_perc, const double *h_perc,
                  double *d_mean_mag, double *d_perc_db, T *d_time_mean, T *d_mag);
 
+template <typename T>
+int hpss_separate(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int64_t *d_len, int64_t max_len,
+                  int n_ch, int sample_rate, int n_fft, int hop, int kernel_size, double margin_h, double margin_p,
+                  double power, int mask_type, int n_bands, const double *h_lo_hz, const double *h_hi_hz,
+                  int preserve_transients, double threshold, double blend, T *d_yh, T *d_yp,
+                  const int64_t *d_y_off, double *d_stats);
+
 // ------------------------------------------------------------------ misc
 template <typename T>
 int window_rms(Ctx *c, const T *d_x, int64_t n_rows, int n_ch, int64_t win, double *d_rms);

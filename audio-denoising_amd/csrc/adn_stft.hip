@@ -26,6 +26,7 @@
 
 #include "adn_kernels.hpp"
 #include "adn_stft_shared.hpp"
+#include "adn_sortnet30.hpp"
 
 namespace adn {
 
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
                 for (int k = lane; k <= Nc; k += 64) {
                     const int pk = k == Nc ? Nc : brev(k, logc);
                     const V z = buf[pk];
-                    const T gk = row[k];
+                    const T gk = row[k + (int64_t)t * a.row_t_stride];
                     buf[pk] = V{z.x * gk, z.y * gk};
                 }
             }
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
                             norm += w * w;
                         }
                         T o = v / (norm > (T)1e-10 ? norm : (T)1);
-                        o = o < (T)-1 ? (T)-1 : (o > (T)1 ? (T)1 : o);      // np.clip keeps NaN
+                        if (!a.no_clip) o = o < (T)-1 ? (T)-1 : (o > (T)1 ? (T)1 : o);      // np.clip keeps NaN
                         ys[(j - R / 2) * H + i] = o;
                     }
                     *slot = 0;
@@ -1030,6 +1031,8 @@ int band_summary(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, cons
     return ADN_OK;
 }
 
+#include "adn_hpss.hpp"
+
 #define ADN_INST(T)                                                                                    \
     template int noise_psd<T>(Ctx *, const T *, int64_t, const int64_t *, const int64_t *, int64_t,   \
                               int, int, int, int, double, double, int, int, T *);                     \
@@ -1038,6 +1041,9 @@ int band_summary(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, cons
                                       int, int, T *, const int64_t *);                                \
     template int wiener<T>(Ctx *, const T *, int64_t, const int64_t *, const int64_t *, int64_t, int, \
                            int, int, int, double, int, int, T *, const int64_t *, T *);               \
+    template int hpss_separate<T>(Ctx *, const T *, int64_t, const int64_t *, const int64_t *, int64_t, int, int, \
+                                  int, int, int, double, double, double, int, int, const double *,     \
+                                  const double *, int, double, double, T *, T *, const int64_t *, double *); \
     template int band_summary<T>(Ctx *, const T *, int64_t, const int64_t *, const int64_t *, int64_t, \
                                  int, int, int, int, int, int, const double *, const double *, int,   \
                                  const double *, double *, double *, T *, T *);

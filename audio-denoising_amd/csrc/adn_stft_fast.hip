@@ -530,14 +530,15 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                 }
                 s.mid = rephase(s.mid, smooth(512));
             } else {
+                const float *grow = row + (int64_t)t * a.row_t_stride;     // per-frame gain rows (masks) or one row
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int k = lane + 64 * j;
-                    const float g0v = row[k], g1v = row[1024 - k];
+                    const float g0v = grow[k], g1v = grow[1024 - k];
                     s.lo[j] = c2{s.lo[j].x * g0v, s.lo[j].y * g0v};
                     s.hi[j] = c2{s.hi[j].x * g1v, s.hi[j].y * g1v};
                 }
-                const float gm = row[512];
+                const float gm = grow[512];
                 s.mid = c2{s.mid.x * gm, s.mid.y * gm};
             }
             tick(9);
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                             }
                             o = v / (norm > 1e-10f ? norm : 1.0f);
                         }
-                        o = o < -1.0f ? -1.0f : (o > 1.0f ? 1.0f : o);
+                        if (!a.no_clip) o = o < -1.0f ? -1.0f : (o > 1.0f ? 1.0f : o);
                         ys[(int64_t)(j - R / 2) * H + i] = o;
                     }
                     *slot = 0.0f;
@@ -668,10 +669,12 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                                 o = float4{v.x / (nrm[0] > 1e-10f ? nrm[0] : 1.0f), v.y / (nrm[1] > 1e-10f ? nrm[1] : 1.0f),
                                            v.z / (nrm[2] > 1e-10f ? nrm[2] : 1.0f), v.w / (nrm[3] > 1e-10f ? nrm[3] : 1.0f)};
                             }
-                            o.x = o.x < -1.0f ? -1.0f : (o.x > 1.0f ? 1.0f : o.x);
-                            o.y = o.y < -1.0f ? -1.0f : (o.y > 1.0f ? 1.0f : o.y);
-                            o.z = o.z < -1.0f ? -1.0f : (o.z > 1.0f ? 1.0f : o.z);
-                            o.w = o.w < -1.0f ? -1.0f : (o.w > 1.0f ? 1.0f : o.w);
+                            if (!a.no_clip) {
+                                o.x = o.x < -1.0f ? -1.0f : (o.x > 1.0f ? 1.0f : o.x);
+                                o.y = o.y < -1.0f ? -1.0f : (o.y > 1.0f ? 1.0f : o.y);
+                                o.z = o.z < -1.0f ? -1.0f : (o.z > 1.0f ? 1.0f : o.z);
+                                o.w = o.w < -1.0f ? -1.0f : (o.w > 1.0f ? 1.0f : o.w);
+                            }
                             float *yp = ys + (int64_t)(j - R / 2) * H + i;
                             if (y_vec) {
                                 *reinterpret_cast<float4 *>(yp) = o;

@@ -86,6 +86,8 @@ struct ApplyArgs {
     Tables<T> tb;
     const T *row;        // noise magnitude (SUBTRACT) or gain (GAIN), F per signal
     int64_t row_stride;  // elements between signals (0 = shared)
+    int64_t row_t_stride;  // GAIN mode: elements between the gain rows of consecutive frames (0 = one row for all)
+    int no_clip;         // 1: the output is not clipped to [-1, 1] (HPSS writes the ISTFT as it is)
     T alpha, beta;
     int st, sf;          // box sizes along time / frequency
     int64_t segs_per_sig;

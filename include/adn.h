@@ -181,6 +181,36 @@ int adn_band_summary_f64(adn_ctx *ctx, const double *d_x, int64_t n_sig, const i
                          const double *h_hi_hz, int n_perc, const double *h_perc, double *d_mean_mag,
                          double *d_perc_db, double *d_time_mean, double *d_mag);
 
+/* Phase 3, harmonic-percussive separation (src/hpss_separate.py:41-67 median_filtering_hpss,
+ * :86-113 multiband_hpss, :115-140 apply_masks, :142-190 preserve_transients, :233-283 main):
+ * |STFT| (n_fft window, padded) -> median over kernel_size frames (harmonic) and over kernel_size
+ * bins (percussive), edges reflected like scipy.ndimage mode='reflect' -> masks
+ * ((S*margin)^power, normalised with 1e-10; ADN_MASK_HARD: winner takes all; ADN_MASK_BINARY:
+ * > 0.5) -> ISTFT of Z*mask_h and Z*mask_p (not clipped) -> optional transient preservation
+ * (frames of 2048 / hop 512 whose original RMS exceeds the harmonic RMS by more than
+ * threshold * max(original RMS) are blended: blend*x + (1-blend)*y_h, x NOT shifted by the
+ * n_fft/2 samples the ISTFT drops, as in the reference) -> both outputs scaled by 0.95 / max|y|
+ * when that maximum exceeds 0.95.
+ * n_bands > 0: multiband mode, the bins of band b (h_lo_hz[b] <= f <= h_hi_hz[b]) are filtered
+ * with the reflection at the band's own edges, a bin listed in several bands belongs to the
+ * last one, bins in no band get zero masks.  kernel_size odd, <= 31.
+ * d_yh / d_yp: outputs of adn_istft_out_samples(len[s], n_fft, hop) samples at d_y_off[s].
+ * d_stats (may be NULL): 5 doubles per signal: harmonic RMS, percussive RMS, RMS of the mono
+ * input, max|y| before scaling, number of transient frames. */
+enum { ADN_MASK_SOFT = 0, ADN_MASK_HARD = 1, ADN_MASK_BINARY = 2 };
+int adn_hpss_f32(adn_ctx *ctx, const float *d_x, int64_t n_sig, const int64_t *d_off,
+                 const int64_t *d_len, int64_t max_len, int n_ch, int sample_rate, int n_fft, int hop,
+                 int kernel_size, double margin_h, double margin_p, double power, int mask_type,
+                 int n_bands, const double *h_lo_hz, const double *h_hi_hz, int preserve_transients,
+                 double threshold, double blend, float *d_yh, float *d_yp, const int64_t *d_y_off,
+                 double *d_stats);
+int adn_hpss_f64(adn_ctx *ctx, const double *d_x, int64_t n_sig, const int64_t *d_off,
+                 const int64_t *d_len, int64_t max_len, int n_ch, int sample_rate, int n_fft, int hop,
+                 int kernel_size, double margin_h, double margin_p, double power, int mask_type,
+                 int n_bands, const double *h_lo_hz, const double *h_hi_hz, int preserve_transients,
+                 double threshold, double blend, double *d_yh, double *d_yp, const int64_t *d_y_off,
+                 double *d_stats);
+
 /* Phase 2b (src/spectral_subtract.py:29-46, 79-109): STFT -> max(|Z|-alpha*n,
  * beta*|Z|) -> box filter (smooth_freq x smooth_time, edge replicated) -> keep
  * the phase -> ISTFT (drops n_fft/2 at both ends) -> clip to [-1, 1].

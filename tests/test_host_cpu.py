@@ -157,7 +157,7 @@ def test_stage_cli_error_behaviour(tmp_path):
 
 def test_stage_scripts_exist_with_reference_names():
     for name in ("noise_profile", "wavelet_denoise", "spectral_subtract", "wiener_filter", "core_pipeline",
-                 "analyze_audio"):
+                 "analyze_audio", "hpss_separate"):
         assert os.path.exists(os.path.join(REPO, "audio-denoising_amd", "src", name + ".py"))
     import denoise
     assert hasattr(denoise, "AudioDeNoise") and hasattr(denoise, "mad")
