@@ -915,12 +915,33 @@ __global__ void k_big_finish(const BigState *__restrict__ st, const int64_t *__r
 // bracket holds too many keys, e.g. a constant segment) the radix passes above run instead.
 static constexpr int BIG_SAMPLE = 4096;
 
+// Where the wanted ranks of a list come from.  Level 1 works on the segment itself (all null);
+// deeper levels work on the keys gathered by the previous level: the ranks are those of the
+// ORIGINAL segment minus the keys already known to lie below the list.
+struct RankSrc {
+    const int64_t *orig_len;              // per (seg / orig_div), or null: orig_uniform; 0 / null / 0: the list itself
+    int64_t orig_div, orig_uniform;
+    const unsigned long long *below;      // null: 0
+    const int *valid;                     // null, or 0: an earlier level failed, skip the segment
+};
+__device__ __forceinline__ bool list_ranks(const RankSrc &rs, int64_t seg, int64_t n, int mode, double q,
+                                           int64_t *r0, int64_t *r1, double *frac) {
+    if (rs.valid && !rs.valid[seg]) return false;
+    const int64_t nr = rs.below ? (rs.orig_len ? rs.orig_len[seg / rs.orig_div] : rs.orig_uniform) : n;
+    big_ranks(nr, mode, q, r0, r1, frac);
+    if (rs.below) {
+        *r0 -= (int64_t)rs.below[seg];
+        *r1 -= (int64_t)rs.below[seg];
+    }
+    return true;
+}
+
 template <typename T, int XF>
 __global__ __launch_bounds__(256) void k_big_sample(const T *__restrict__ vals, const int64_t *__restrict__ seg_off,
                                                     int64_t seg_stride, const int64_t *__restrict__ seg_len,
                                                     int64_t len_div, int64_t uniform_len,
                                                     const double *__restrict__ center, BigState *__restrict__ st,
-                                                    int mode, double q) {
+                                                    int mode, double q, RankSrc rsrc) {
     using K = typename KeyT<T>::type;
     __shared__ K sk[BIG_SAMPLE];
     __shared__ unsigned int hist[256];
@@ -928,10 +949,16 @@ __global__ __launch_bounds__(256) void k_big_sample(const T *__restrict__ vals, 
     const int64_t seg = blockIdx.x;
     const int64_t n = seg_len ? seg_len[seg / len_div] : uniform_len;
     const int tid = threadIdx.x;
-    if (n < 2 * BIG_SAMPLE) {                       // too short to be worth it: radix passes
+    int64_t r0, r1;
+    double frac;
+    const bool live = n > 0 && list_ranks(rsrc, seg, n, mode, q, &r0, &r1, &frac) && r0 >= 0 && r1 < n;
+    if (!live || n < 2 * BIG_SAMPLE) {
+        // an earlier level failed: empty bracket (nothing gathered, segment unresolved).
+        // A short list of a deeper level passes through whole: bracket = every key.
         if (tid == 0) {
-            st[seg].lo = 1;
-            st[seg].hi = 0;                         // empty bracket -> nothing gathered, unresolved
+            const bool pass = live && rsrc.below != nullptr;
+            st[seg].lo = pass ? 0ull : 1ull;
+            st[seg].hi = pass ? ~0ull : 0ull;
         }
         return;
     }
@@ -948,9 +975,6 @@ __global__ __launch_bounds__(256) void k_big_sample(const T *__restrict__ vals, 
         if (XF == XF_ABSDEV) x = fabs(x - c);
         sk[j] = x != x ? ~(K)0 : key_of(x);
     }
-    int64_t r0, r1;
-    double frac;
-    big_ranks(n, mode, q, &r0, &r1, &frac);
     const double p = (double)r0 / (double)n;
     const int delta = (int)(4.5 * sqrt((double)BIG_SAMPLE * p * (1.0 - p))) + 3;
     const int rs = (int)((double)r0 * (double)BIG_SAMPLE / (double)n);
@@ -1097,8 +1121,8 @@ __global__ __launch_bounds__(256) void k_big_gather(const T *__restrict__ vals, 
 
 // per segment: did the bracket catch both order statistics?
 __global__ void k_big_check(BigState *st, const int64_t *seg_len, int64_t len_div, int64_t uniform_len,
-                            int64_t n_seg, int mode, double q, int64_t cap, int64_t *cand_len, int *valid,
-                            unsigned long long *below, unsigned long long *lohi) {
+                            int64_t n_seg, int mode, double q, int64_t cap, RankSrc rsrc, int64_t *cand_len,
+                            int *valid, unsigned long long *below, unsigned long long *lohi) {
     const int64_t seg = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (seg >= n_seg) return;
     const int64_t n = seg_len ? seg_len[seg / len_div] : uniform_len;
@@ -1107,15 +1131,29 @@ __global__ void k_big_check(BigState *st, const int64_t *seg_len, int64_t len_di
     if (n > 0 && s.lo <= s.hi && !s.overflow && (int64_t)s.n_cand <= cap && !s.has_nan) {
         int64_t r0, r1;
         double frac;
-        big_ranks(n, mode, q, &r0, &r1, &frac);
-        ok = (unsigned long long)r0 >= s.below && (unsigned long long)r1 < s.below + s.n_cand;
+        if (list_ranks(rsrc, seg, n, mode, q, &r0, &r1, &frac))
+            ok = r0 >= 0 && (unsigned long long)r0 >= s.below && (unsigned long long)r1 < s.below + s.n_cand;
     }
     st[seg].resolved = ok;
     valid[seg] = ok;
     cand_len[seg] = ok ? (int64_t)s.n_cand : 0;
-    below[seg] = s.below;
+    below[seg] = s.below + (rsrc.below ? rsrc.below[seg] : 0ull);   // keys of the ORIGINAL segment below this list
     lohi[2 * seg] = s.lo;
     lohi[2 * seg + 1] = s.hi;
+}
+
+// level >= 2 state: empty counters
+__global__ void k_big_init_level(BigState *st, int64_t n_seg) {
+    const int64_t seg = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (seg >= n_seg) return;
+    BigState s{};
+    s.min_gt = ~0ull;
+    st[seg] = s;
+}
+// the radix passes (on the original segment) must run for everything the last level left open
+__global__ void k_big_resolve(BigState *st, const int *valid, int64_t n_seg) {
+    const int64_t seg = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (seg < n_seg) st[seg].resolved = valid[seg];
 }
 
 int64_t select_short_limit() { return BIG_THRESHOLD; }
@@ -1133,24 +1171,55 @@ static int64_t big_cand_cap(int64_t max_len, size_t key_bytes) {
     return c < 16384 ? 16384 : c;
 }
 
+// Candidate capacities of the bracket levels: a level whose list would not fit the lean LDS
+// kernel is bracketed again (sample -> gather) on the gathered keys, about 14x shorter each time.
+static constexpr int BIG_MAX_LEVELS = 7;
+static int big_level_caps(int64_t max_len, size_t key_bytes, int64_t *caps) {
+    int n = 0;
+    int64_t len = max_len;
+    while (n < BIG_MAX_LEVELS) {
+        int64_t cap = big_cand_cap(len, key_bytes);
+        if (cap < 2 * BIG_SAMPLE) cap = 2 * BIG_SAMPLE;      // a short list passes through a level whole
+        caps[n++] = cap;
+        if ((size_t)cap * key_bytes <= SEL_LDS_MAX_BYTES) break;
+        len = cap;
+    }
+    return n;
+}
+
 size_t select_ws_bytes(int64_t n_seg, int64_t max_len) {
     if (max_len <= BIG_THRESHOLD) return 0;
-    return ws_need((size_t)n_seg, sizeof(BigState)) + ws_need((size_t)n_seg * BIG_BINS, sizeof(uint32_t)) +
-           ws_need((size_t)n_seg * std::max(big_cand_cap(max_len, 4), big_cand_cap(max_len, 8)), 8) + 4 * ws_need((size_t)n_seg, 8) +
-           ws_need((size_t)n_seg, 4);
+    int64_t c4[BIG_MAX_LEVELS], c8[BIG_MAX_LEVELS];
+    const int n4 = big_level_caps(max_len, 4, c4), n8 = big_level_caps(max_len, 8, c8);
+    size_t cand = 0;
+    const int nl = std::max(n4, n8);
+    for (int l = 0; l < nl; ++l)
+        cand += ws_need((size_t)n_seg * std::max(l < n4 ? c4[l] : 0, l < n8 ? c8[l] : 0), 8);
+    return ws_need((size_t)n_seg * BIG_BINS, sizeof(uint32_t)) + cand +
+           (size_t)nl * (ws_need((size_t)n_seg, sizeof(BigState)) + 4 * ws_need((size_t)n_seg, 8) + ws_need((size_t)n_seg, 4));
 }
 
 template <typename T, int XF>
 static int launch_select_big(Ctx *c, const T *d_vals, const SelectArgs &a) {
     constexpr int BITS = KeyT<T>::bits;
-    BigState *st = ws_take<BigState>(c, (size_t)a.n_seg);
+    using K = typename KeyT<T>::type;
+    int64_t caps[BIG_MAX_LEVELS];
+    const int n_levels = big_level_caps(a.max_len, sizeof(K), caps);
     uint32_t *ghist = ws_take<uint32_t>(c, (size_t)a.n_seg * BIG_BINS);
-    const int64_t cap = big_cand_cap(a.max_len, sizeof(typename KeyT<T>::type));
-    T *cand = reinterpret_cast<T *>(ws_take<double>(c, (size_t)a.n_seg * cap));
-    int64_t *cand_len = ws_take<int64_t>(c, (size_t)a.n_seg);
-    unsigned long long *below = ws_take<unsigned long long>(c, (size_t)a.n_seg);
-    int *valid = ws_take<int>(c, (size_t)a.n_seg);
-    unsigned long long *lohi = ws_take<unsigned long long>(c, 2 * (size_t)a.n_seg);
+    BigState *st_l[BIG_MAX_LEVELS];
+    T *cand_l[BIG_MAX_LEVELS];
+    int64_t *len_l[BIG_MAX_LEVELS];
+    unsigned long long *below_l[BIG_MAX_LEVELS], *lohi_l[BIG_MAX_LEVELS];
+    int *valid_l[BIG_MAX_LEVELS];
+    for (int l = 0; l < n_levels; ++l) {
+        st_l[l] = ws_take<BigState>(c, (size_t)a.n_seg);
+        cand_l[l] = reinterpret_cast<T *>(ws_take<double>(c, (size_t)a.n_seg * caps[l]));
+        len_l[l] = ws_take<int64_t>(c, (size_t)a.n_seg);
+        below_l[l] = ws_take<unsigned long long>(c, (size_t)a.n_seg);
+        valid_l[l] = ws_take<int>(c, (size_t)a.n_seg);
+        lohi_l[l] = ws_take<unsigned long long>(c, 2 * (size_t)a.n_seg);
+    }
+    BigState *st = st_l[0];
     if (c->ws_used > c->ws_bytes) {
         set_error("internal: workspace not reserved for the long-segment select");
         return ADN_ERR_NOMEM;
@@ -1161,24 +1230,45 @@ static int launch_select_big(Ctx *c, const T *d_vals, const SelectArgs &a) {
     ADN_HIP(hipMemsetAsync(ghist, 0, sizeof(uint32_t) * a.n_seg * BIG_BINS, c->stream));
     hipLaunchKernelGGL(k_big_init, dim3(nb), dim3(256), 0, c->stream, st, a.d_seg_len, a.len_div, a.uniform_len,
                        a.n_seg, a.mode, a.q);
-    // ---- bracket fast path: sample, count + gather, exact selection over the gathered keys
-    hipLaunchKernelGGL((k_big_sample<T, XF>), dim3((unsigned)a.n_seg), dim3(256), 0, c->stream, d_vals, a.d_seg_off,
-                       a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len, a.d_center, st, a.mode, a.q);
-    hipLaunchKernelGGL((k_big_gather<T, XF>), dim3((unsigned)(a.n_seg * tiles)), dim3(256), 0, c->stream, d_vals,
-                       a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len, a.d_center, st, cand, cap,
-                       tiles);
-    hipLaunchKernelGGL(k_big_check, dim3(nb), dim3(256), 0, c->stream, st, a.d_seg_len, a.len_div, a.uniform_len,
-                       a.n_seg, a.mode, a.q, cap, cand_len, valid, below, lohi);
+    // ---- bracket fast path: sample, count + gather (repeated on the gathered keys while they do
+    // not fit LDS), then the exact selection over the last list
     {
-        using K = typename KeyT<T>::type;
+        const RankSrc none{nullptr, 1, 0, nullptr, nullptr};
+        hipLaunchKernelGGL((k_big_sample<T, XF>), dim3((unsigned)a.n_seg), dim3(256), 0, c->stream, d_vals, a.d_seg_off,
+                           a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len, a.d_center, st, a.mode, a.q, none);
+        hipLaunchKernelGGL((k_big_gather<T, XF>), dim3((unsigned)(a.n_seg * tiles)), dim3(256), 0, c->stream, d_vals,
+                           a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len, a.d_center, st, cand_l[0],
+                           caps[0], tiles);
+        hipLaunchKernelGGL(k_big_check, dim3(nb), dim3(256), 0, c->stream, st, a.d_seg_len, a.len_div, a.uniform_len,
+                           a.n_seg, a.mode, a.q, caps[0], none, len_l[0], valid_l[0], below_l[0], lohi_l[0]);
+    }
+    for (int l = 1; l < n_levels; ++l) {
+        const RankSrc rs{a.d_seg_len, a.len_div, a.uniform_len, below_l[l - 1], valid_l[l - 1]};
+        const int64_t ltiles = ceil_div(caps[l - 1], BIG_TILE);
+        ADN_REQUIRE(a.n_seg * ltiles < (int64_t)0x7FFFFFFF, "select batch too large for one launch");
+        hipLaunchKernelGGL(k_big_init_level, dim3(nb), dim3(256), 0, c->stream, st_l[l], a.n_seg);
+        hipLaunchKernelGGL((k_big_sample<T, XF_NONE>), dim3((unsigned)a.n_seg), dim3(256), 0, c->stream, cand_l[l - 1],
+                           (const int64_t *)nullptr, caps[l - 1], len_l[l - 1], (int64_t)1, (int64_t)0,
+                           (const double *)nullptr, st_l[l], a.mode, a.q, rs);
+        hipLaunchKernelGGL((k_big_gather<T, XF_NONE>), dim3((unsigned)(a.n_seg * ltiles)), dim3(256), 0, c->stream,
+                           cand_l[l - 1], (const int64_t *)nullptr, caps[l - 1], len_l[l - 1], (int64_t)1, (int64_t)0,
+                           (const double *)nullptr, st_l[l], cand_l[l], caps[l], ltiles);
+        hipLaunchKernelGGL(k_big_check, dim3(nb), dim3(256), 0, c->stream, st_l[l], len_l[l - 1], (int64_t)1, (int64_t)0,
+                           a.n_seg, a.mode, a.q, caps[l], rs, len_l[l], valid_l[l], below_l[l], lohi_l[l]);
+    }
+    const int L = n_levels - 1;
+    if (L > 0) hipLaunchKernelGGL(k_big_resolve, dim3(nb), dim3(256), 0, c->stream, st, valid_l[L], a.n_seg);
+    {
+        const int64_t cap = caps[L];
+        T *cand = cand_l[L];
         MaskedMean mm{nullptr, 1, 0, nullptr};
-        SubsetRanks sub{a.d_seg_len, a.len_div, a.uniform_len, below, valid, lohi};
+        SubsetRanks sub{a.d_seg_len, a.len_div, a.uniform_len, below_l[L], valid_l[L], lohi_l[L]};
         if ((size_t)cap * sizeof(K) <= SEL_LDS_MAX_BYTES) {
             const size_t dyn = (size_t)cap * sizeof(K);
             auto kern = k_select_lds<T, XF_NONE, false>;
             ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
             hipLaunchKernelGGL(kern, dim3((unsigned)a.n_seg), dim3(SEL_THREADS), dyn, c->stream, cand,
-                               (const int64_t *)nullptr, cap, cand_len, (int64_t)1, (int64_t)0, a.mode, a.q,
+                               (const int64_t *)nullptr, cap, len_l[L], (int64_t)1, (int64_t)0, a.mode, a.q,
                                (const double *)nullptr, a.d_out, mm, sub);
         } else {
             int lds_keys = (int)(SEL_LDS_BYTES / sizeof(K));
@@ -1186,7 +1276,7 @@ static int launch_select_big(Ctx *c, const T *d_vals, const SelectArgs &a) {
             auto kern = k_select<T, XF_NONE>;
             ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
             hipLaunchKernelGGL(kern, dim3((unsigned)a.n_seg), dim3(SEL_THREADS), dyn, c->stream, cand,
-                               (const int64_t *)nullptr, cap, cand_len, (int64_t)1, (int64_t)0, a.mode, a.q,
+                               (const int64_t *)nullptr, cap, len_l[L], (int64_t)1, (int64_t)0, a.mode, a.q,
                                (const double *)nullptr, a.d_out, lds_keys, mm, sub);
         }
     }

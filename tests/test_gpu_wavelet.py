@@ -187,6 +187,27 @@ def test_mad_long_segments_exact():
     assert got[0] == orc.mad(parts[0]) and got[2] == orc.mad(parts[2])
 
 
+def test_mad_multi_level_bracket_exact():
+    """Segments whose first candidate list does not fit LDS are bracketed again on the gathered
+    keys (three levels at 3.3 M fp64 keys); a list that turns out short passes through a level."""
+    e = engine()
+    rng = np.random.default_rng(11)
+    big = rng.standard_normal(3_300_001)
+    skew = np.exp(2.0 * rng.standard_normal(1_500_000))
+    # second segment far shorter than the first: its lists pass through the deeper levels whole
+    mixed = [rng.standard_normal(2_000_000), rng.standard_normal(40_000), np.full(300_000, -1.5)]
+    for dt in (torch.float64, torch.float32):
+        npdt = np.float32 if dt == torch.float32 else np.float64
+        for a in (big, skew):
+            x = a.astype(npdt)
+            want = float(np.median(np.abs(x - np.median(x))))
+            assert float(e.mad(dev(x))) == want
+        xs = [m.astype(npdt) for m in mixed]
+        got = host(e.mad(dev(np.concatenate(xs)), [m.size for m in xs]))
+        want = [float(np.median(np.abs(m - np.median(m)))) for m in xs]
+        assert list(got) == want
+
+
 def _batch_denoise(e, xs, dt, wavelet, level, thr_mode):
     """All blocks of `xs` (list of 1-D arrays) in one C-ABI call; returns outputs + stats."""
     lens = np.array([len(x) for x in xs], dtype=np.int64)
