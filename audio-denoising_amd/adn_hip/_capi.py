@@ -43,9 +43,10 @@ _TYPED = {
                  _i, _d, _d, _vp, _vp, _vp, _vp],
     "adn_band_summary": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, C.POINTER(_d), C.POINTER(_d), _i,
                          C.POINTER(_d), _vp, _vp, _vp, _vp],
-    "adn_spectral_subtract": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _i, _i, _d, _d, _i, _i, _vp, _vp],
-    "adn_wiener": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _d, _i, _i, _vp, _vp, _vp],
+    "adn_spectral_subtract": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _i, _i, _d, _d, _i, _i, _vp, _vp, _vp],
+    "adn_wiener": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _d, _i, _i, _vp, _vp, _vp, _vp],
     "adn_window_rms": [_vp, _vp, _i64, _i, _i64, _vp],
+    "adn_pcm_encode": [_vp, _vp, _i64, _i, _vp, _vp],
     "adn_synth_noisy_speech": [_vp, _vp, _i64, _i64, _i, _u64, _u64, _d, _d],
 }
 

@@ -247,9 +247,11 @@ class Engine:
         return yh, yp, out_lens, stats
 
     def spectral_subtract(self, x, lens, noise_mag, n_ch=1, n_fft=2048, hop=512, alpha=2.2, beta=0.1,
-                          smooth_time=3, smooth_freq=5, offsets=None, out=None, out_offsets=None):
+                          smooth_time=3, smooth_freq=5, offsets=None, out=None, out_offsets=None, pcm16=None):
         """Phase 2b on a batch.  noise_mag: (F,) shared or (n_sig, F).  Returns (y, out_lens)
-        with the outputs back to back in y (or at `out_offsets` of `out`)."""
+        with the outputs back to back in y (or at `out_offsets` of `out`).  `pcm16`: optional int16
+        tensor laid out like y; it receives the 16-bit PCM file samples and y then holds the
+        values read back from such a file."""
         starts, lens = self._signals(lens, n_ch, n_fft)
         if offsets is not None:
             starts = np.asarray(offsets, dtype=np.int64)
@@ -266,12 +268,12 @@ class Engine:
         self._call("adn_spectral_subtract", x.dtype, _ptr(x), len(lens), _ptr(d_off),
                    _ptr(d_len), int(lens.max()), int(n_ch), _ptr(noise_mag), int(stride), int(n_fft),
                    int(hop), float(alpha), float(beta), int(smooth_time), int(smooth_freq), _ptr(out),
-                   _ptr(d_yoff))
+                   _ptr(d_yoff), _ptr(self._pcm_arg(pcm16, out)))
         return out, out_lens
 
     def wiener(self, x, lens, sample_rate, n_ch=1, n_fft=2048, hop=512, update_ms=20, kernel_bins=5,
-               vad_guided=True, offsets=None, out=None, out_offsets=None, want_gain=False):
-        """Phase 2c on a batch.  Returns (y, out_lens[, gain])."""
+               vad_guided=True, offsets=None, out=None, out_offsets=None, want_gain=False, pcm16=None):
+        """Phase 2c on a batch.  Returns (y, out_lens[, gain]).  `pcm16` as for spectral_subtract."""
         starts, lens = self._signals(lens, n_ch, n_fft)
         if offsets is not None:
             starts = np.asarray(offsets, dtype=np.int64)
@@ -284,8 +286,18 @@ class Engine:
         d_off, d_len, d_yoff = self._i64(starts), self._i64(lens), self._i64(out_offsets)
         self._call("adn_wiener", x.dtype, _ptr(x), len(lens), _ptr(d_off), _ptr(d_len),
                    int(lens.max()), int(n_ch), int(sample_rate), int(n_fft), int(hop), float(update_ms),
-                   int(kernel_bins), int(bool(vad_guided)), _ptr(out), _ptr(d_yoff), _ptr(gain))
+                   int(kernel_bins), int(bool(vad_guided)), _ptr(out), _ptr(d_yoff), _ptr(gain),
+                   _ptr(self._pcm_arg(pcm16, out)))
         return (out, out_lens, gain) if want_gain else (out, out_lens)
+
+    @staticmethod
+    def _pcm_arg(pcm16, out):
+        if pcm16 is None:
+            return None
+        if pcm16.dtype != torch.int16 or pcm16.numel() < out.numel() or not pcm16.is_contiguous() \
+                or pcm16.device != out.device:
+            raise ValueError("pcm16 must be a contiguous int16 device tensor at least as long as the output")
+        return pcm16
 
     def mad(self, x, lens=None):
         """median(|x - median(x)|) per segment of a flat device tensor (one segment when
@@ -306,6 +318,16 @@ class Engine:
         out = torch.empty(n_win, dtype=torch.float64, device=x.device)
         self._call("adn_window_rms", x.dtype, _ptr(x.contiguous()), n_rows, n_ch, int(win), _ptr(out))
         return out
+
+    def pcm_encode(self, x, bits=16, dequantize=False):
+        """Integer PCM sample values of `x` (int16 for 16 bits, int32 for 24 / 32) as the stage
+        files hold them; with `dequantize` also the values a reader of the file gets back
+        (True: a new tensor, "inplace": written over `x`).  Returns q or (q, xq)."""
+        x = x.contiguous()
+        q = torch.empty(x.shape, dtype=torch.int16 if bits == 16 else torch.int32, device=x.device)
+        xq = x if dequantize == "inplace" else (torch.empty_like(x) if dequantize else None)
+        self._call("adn_pcm_encode", x.dtype, _ptr(x), x.numel(), int(bits), _ptr(q), _ptr(xq))
+        return (q, xq) if dequantize else q
 
     def synth_noisy_speech(self, n, sample_rate, seed=42, stream=0, sigma=0.05, speech_gain=1.0,
                            start=0, dtype=torch.float64, out=None):

@@ -7,8 +7,12 @@ src/*.py sf.read / sf.write).  Like libsndfile, a ``.wav`` written without an ex
 subtype is 16-bit PCM; samples are read back as float64.
 
 PCM conversion (parity unpinned: libsndfile is absent from the build container, so the
-rule below restates its documented behaviour for normalised doubles): write
-int16 = rint(x * 32767) clipped to [-32768, 32767]; read x = int16 / 32768.
+rule below restates the conversion libsndfile applies to normalised doubles when clipping
+is switched on, which python-soundfile does for every file it opens): the sample is scaled
+by 2^31, rounded to the nearest integer (ties to even), saturated to the int32 range, and
+the top `bits` bits are kept (an arithmetic shift, i.e. rounding towards minus infinity on
+the 16-bit grid: int16 = floor(rint(x * 2^31) / 2^16)); NaN is written as 0.  Reading
+divides by 2^(bits-1).  ``adn_pcm_encode_*`` applies the same rule on the GPU.
 Set ``ADN_WAV_SUBTYPE=DOUBLE`` (or pass ``subtype=``) to keep inter-stage files lossless.
 """
 import os
@@ -120,18 +124,23 @@ def _encode(data, subtype):
     x = np.ascontiguousarray(data, dtype=np.float64)
     if code == _FMT_FLOAT:
         return x.astype("<f4" if bits == 32 else "<f8").tobytes()
-    full = float(2 ** (bits - 1) - 1)
-    q = np.rint(np.nan_to_num(x, nan=0.0) * full)
-    q = np.clip(q, -full - 1.0, full)
+    q = pcm_quantize(x, bits)
     if bits == 16:
         return q.astype("<i2").tobytes()
     if bits == 32:
         return q.astype("<i4").tobytes()
-    v = q.astype(np.int32) & 0xFFFFFF
+    v = q & 0xFFFFFF
     out = np.empty((v.size, 3), dtype=np.uint8)
     fl = v.ravel()
     out[:, 0], out[:, 1], out[:, 2] = fl & 0xFF, (fl >> 8) & 0xFF, (fl >> 16) & 0xFF
     return out.tobytes()
+
+
+def pcm_quantize(x, bits):
+    """Integer sample values (int32 array) of normalised floating-point samples."""
+    x = np.clip(np.nan_to_num(np.asarray(x, dtype=np.float64), nan=0.0), -2.0, 2.0)   # saturates anyway
+    q = np.clip(np.rint(x * 2147483648.0), -2147483648.0, 2147483647.0).astype(np.int64)
+    return (q >> (32 - bits)).astype(np.int32)
 
 
 def _header(samplerate, channels, subtype, data_bytes):

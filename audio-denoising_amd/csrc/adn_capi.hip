@@ -200,21 +200,24 @@ int64_t adn_istft_out_samples(int64_t n, int n_fft, int hop) {
                                     const int64_t *d_len, int64_t max_len, int n_ch,                \
                                     const T *d_noise, int64_t noise_stride, int n_fft, int hop,     \
                                     double alpha, double beta, int smooth_time, int smooth_freq,    \
-                                    T *d_y, const int64_t *d_y_off) {                               \
+                                    T *d_y, const int64_t *d_y_off, int16_t *d_pcm16) {             \
         return adn::spectral_subtract<T>(c, d_x, n_sig, d_off, d_len, max_len, n_ch, d_noise,       \
                                          noise_stride, n_fft, hop, alpha, beta, smooth_time,        \
-                                         smooth_freq, d_y, d_y_off);                                \
+                                         smooth_freq, d_y, d_y_off, d_pcm16);                       \
     }                                                                                               \
     int adn_wiener_##SUF(adn_ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off,             \
                          const int64_t *d_len, int64_t max_len, int n_ch, int sample_rate,          \
                          int n_fft, int hop, double update_ms, int kernel_bins, int vad_guided,     \
-                         T *d_y, const int64_t *d_y_off, T *d_gain) {                               \
+                         T *d_y, const int64_t *d_y_off, T *d_gain, int16_t *d_pcm16) {             \
         return adn::wiener<T>(c, d_x, n_sig, d_off, d_len, max_len, n_ch, sample_rate, n_fft, hop,  \
-                              update_ms, kernel_bins, vad_guided, d_y, d_y_off, d_gain);            \
+                              update_ms, kernel_bins, vad_guided, d_y, d_y_off, d_gain, d_pcm16);   \
     }                                                                                               \
     int adn_window_rms_##SUF(adn_ctx *c, const T *d_x, int64_t n_rows, int n_ch, int64_t win,       \
                              double *d_rms) {                                                       \
         return adn::window_rms<T>(c, d_x, n_rows, n_ch, win, d_rms);                                \
+    }                                                                                               \
+    int adn_pcm_encode_##SUF(adn_ctx *c, const T *d_x, int64_t n, int bits, void *d_q, T *d_xq) {   \
+        return adn::pcm_encode<T>(c, d_x, n, bits, d_q, d_xq);                                      \
     }                                                                                               \
     int adn_synth_noisy_speech_##SUF(adn_ctx *c, T *d_x, int64_t n, int64_t start, int sample_rate, \
                                      uint64_t seed, uint64_t stream, double sigma,                  \

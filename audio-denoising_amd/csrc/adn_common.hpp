@@ -108,6 +108,22 @@ template <typename T> struct KeyT;
 template <> struct KeyT<float> { using type = uint32_t; static constexpr int bits = 32; };
 template <> struct KeyT<double> { using type = uint64_t; static constexpr int bits = 64; };
 
+// ------------------------------------------------------- PCM file samples
+// Integer value of a normalised sample in a 16/24/32-bit PCM file, the way libsndfile converts
+// with clipping enabled: scale by 2^31 (exact), round to nearest even, saturate to int32, keep
+// the top `bits` bits with an arithmetic shift.  NaN becomes 0.  The float version is exact too:
+// the scaling is a power of two and the rounding is that of the same real number.
+__device__ __forceinline__ int pcm_int32(float v) {
+    const float s = rintf(v * 2147483648.0f);
+    const int k = (int)fminf(fmaxf(s, -2147483648.0f), 2147483520.0f);   // largest float below 2^31
+    return v != v ? 0 : (s >= 2147483648.0f ? 0x7FFFFFFF : k);
+}
+__device__ __forceinline__ int pcm_int32(double v) {
+    double s = rint(v * 2147483648.0);
+    s = fmin(fmax(s, -2147483648.0), 2147483647.0);
+    return v != v ? 0 : (int)s;
+}
+
 // --------------------------------------------------------- filter banks
 // Decomposition low-pass taps; the other three filters follow from them.
 struct FilterBank {

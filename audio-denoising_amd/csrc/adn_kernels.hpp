@@ -60,11 +60,11 @@ template <typename T>
 int spectral_subtract(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off,
                       const int64_t *d_len, int64_t max_len, int n_ch, const T *d_noise,
                       int64_t noise_stride, int n_fft, int hop, double alpha, double beta,
-                      int smooth_time, int smooth_freq, T *d_y, const int64_t *d_y_off);
+                      int smooth_time, int smooth_freq, T *d_y, const int64_t *d_y_off, int16_t *d_pcm16);
 template <typename T>
 int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int64_t *d_len,
            int64_t max_len, int n_ch, int sample_rate, int n_fft, int hop, double update_ms,
-           int kernel_bins, int vad_guided, T *d_y, const int64_t *d_y_off, T *d_gain);
+           int kernel_bins, int vad_guided, T *d_y, const int64_t *d_y_off, T *d_gain, int16_t *d_pcm16);
 
 template <typename T>
 int band_summary(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int64_t *d_len,
@@ -82,6 +82,8 @@ int hpss_separate(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, con
 // ------------------------------------------------------------------ misc
 template <typename T>
 int window_rms(Ctx *c, const T *d_x, int64_t n_rows, int n_ch, int64_t win, double *d_rms);
+template <typename T>
+int pcm_encode(Ctx *c, const T *d_x, int64_t n, int bits, void *d_q, T *d_xq);
 template <typename T>
 int synth_noisy_speech(Ctx *c, T *d_x, int64_t n, int64_t start, int sample_rate, uint64_t seed,
                        uint64_t stream, double sigma, double speech_gain);

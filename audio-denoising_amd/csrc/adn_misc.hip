@@ -38,6 +38,62 @@ int window_rms(Ctx *c, const T *d_x, int64_t n_rows, int n_ch, int64_t win, doub
     return ADN_OK;
 }
 
+// ------------------------------------------------------------ PCM samples
+// q[i] = PCM value of x[i]; xq[i] (optional, may alias x) = the value a reader of the file
+// gets back, q / 2^(bits-1).  16-bit values are stored as int16, 24- and 32-bit ones as int32.
+template <typename T, typename Q>
+__global__ __launch_bounds__(256) void k_pcm_encode(const T *x, int64_t n, int bits,
+                                                    Q *__restrict__ q, T *xq) {
+    constexpr int V = 16 / (int)sizeof(T);                 // 16-byte loads
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * V;
+    if (i0 >= n) return;
+    const int shift = 32 - bits;
+    const T inv = (T)1 / (T)(1u << (bits - 1));
+    if (i0 + V <= n) {
+        T v[V];
+        Q o[V];
+        *reinterpret_cast<float4 *>(v) = *reinterpret_cast<const float4 *>(x + i0);
+#pragma unroll
+        for (int u = 0; u < V; ++u) {
+            const int k = pcm_int32(v[u]) >> shift;
+            o[u] = (Q)k;
+            v[u] = (T)k * inv;
+        }
+        if (sizeof(Q) * V == 8) *reinterpret_cast<float2 *>(q + i0) = *reinterpret_cast<float2 *>(o);
+        else if (sizeof(Q) * V == 4) *reinterpret_cast<float *>(q + i0) = *reinterpret_cast<float *>(o);
+        else *reinterpret_cast<float4 *>(q + i0) = *reinterpret_cast<float4 *>(o);
+        if (xq) *reinterpret_cast<float4 *>(xq + i0) = *reinterpret_cast<float4 *>(v);
+    } else {
+        for (int64_t i = i0; i < n; ++i) {
+            const int k = pcm_int32(x[i]) >> shift;
+            q[i] = (Q)k;
+            if (xq) xq[i] = (T)k * inv;
+        }
+    }
+}
+
+template <typename T>
+int pcm_encode(Ctx *c, const T *d_x, int64_t n, int bits, void *d_q, T *d_xq) {
+    ADN_REQUIRE(c, "null context");
+    ADN_REQUIRE(n >= 0, "n must be >= 0");
+    ADN_REQUIRE(bits == 16 || bits == 24 || bits == 32, "bits must be 16, 24 or 32");
+    if (n == 0) return ADN_OK;
+    ADN_REQUIRE(d_x && d_q, "null pointer argument");
+    ADN_REQUIRE(((uintptr_t)d_x & 15) == 0 && ((uintptr_t)d_q & 15) == 0 && ((uintptr_t)d_xq & 15) == 0,
+                "sample buffers must be 16-byte aligned");
+    DeviceGuard dg(c->device);
+    constexpr int V = 16 / (int)sizeof(T);
+    const unsigned nb = (unsigned)ceil_div(n, (int64_t)256 * V);
+    if (bits == 16)
+        hipLaunchKernelGGL((k_pcm_encode<T, int16_t>), dim3(nb), dim3(256), 0, c->stream, d_x, n, bits,
+                           static_cast<int16_t *>(d_q), d_xq);
+    else
+        hipLaunchKernelGGL((k_pcm_encode<T, int32_t>), dim3(nb), dim3(256), 0, c->stream, d_x, n, bits,
+                           static_cast<int32_t *>(d_q), d_xq);
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
+
 // ------------------------------------------------------ synthetic signal
 // Every operation below is an exactly rounded IEEE double operation and FP
 // contraction is off, so the host generator (same formulas) produces the same bits.
@@ -96,6 +152,8 @@ int synth_noisy_speech(Ctx *c, T *d_x, int64_t n, int64_t start, int sample_rate
     return ADN_OK;
 }
 
+template int pcm_encode<float>(Ctx *, const float *, int64_t, int, void *, float *);
+template int pcm_encode<double>(Ctx *, const double *, int64_t, int, void *, double *);
 template int window_rms<float>(Ctx *, const float *, int64_t, int, int64_t, double *);
 template int window_rms<double>(Ctx *, const double *, int64_t, int, int64_t, double *);
 template int synth_noisy_speech<float>(Ctx *, float *, int64_t, int64_t, int, uint64_t, uint64_t, double, double);

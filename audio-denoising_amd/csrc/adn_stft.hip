@@ -498,6 +498,7 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
     const int hr = MODE == APPLY_SUBTRACT ? a.st - h - 1 : 0;
     const T *xs = a.x + a.sg.off[sig];
     T *ys = a.y + a.y_off[sig];
+    int16_t *ps = a.pcm ? a.pcm + a.y_off[sig] : nullptr;
     const T *row = a.row + sig * a.row_stride;
     const T fscale = (T)(1.0 / tb.wsum);
     const T iscale = (T)(tb.wsum / (double)Nc);
@@ -598,6 +599,11 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
                         }
                         T o = v / (norm > (T)1e-10 ? norm : (T)1);
                         if (!a.no_clip) o = o < (T)-1 ? (T)-1 : (o > (T)1 ? (T)1 : o);      // np.clip keeps NaN
+                        if (ps) {
+                            const int k = pcm_int32(o) >> 16;
+                            ps[(j - R / 2) * H + i] = (int16_t)k;
+                            o = (T)k * (T)(1.0 / 32768.0);
+                        }
                         ys[(j - R / 2) * H + i] = o;
                     }
                     *slot = 0;
@@ -760,7 +766,7 @@ template <typename T>
 int spectral_subtract(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off,
                       const int64_t *d_len, int64_t max_len, int n_ch, const T *d_noise,
                       int64_t noise_stride, int n_fft, int hop, double alpha, double beta,
-                      int smooth_time, int smooth_freq, T *d_y, const int64_t *d_y_off) {
+                      int smooth_time, int smooth_freq, T *d_y, const int64_t *d_y_off, int16_t *d_pcm16) {
     ADN_REQUIRE(c && d_x && d_off && d_len && d_noise && d_y && d_y_off, "null pointer argument");
     ADN_TRY(check_stft_args(n_fft, hop, n_ch));
     ADN_REQUIRE(smooth_time >= 1 && smooth_time <= 7 && smooth_freq >= 1, "smoothing sizes out of range");
@@ -779,6 +785,7 @@ int spectral_subtract(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off,
     a.y_off = d_y_off;
     a.sg = Signals{d_off, d_len, n_ch, n_fft, hop, 1};
     a.tb = tb;
+    a.pcm = d_pcm16;
     a.row = d_noise;
     a.row_stride = noise_stride;
     a.alpha = (T)alpha;
@@ -791,7 +798,7 @@ int spectral_subtract(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off,
 template <typename T>
 int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int64_t *d_len,
            int64_t max_len, int n_ch, int sample_rate, int n_fft, int hop, double update_ms,
-           int kernel_bins, int vad_guided, T *d_y, const int64_t *d_y_off, T *d_gain) {
+           int kernel_bins, int vad_guided, T *d_y, const int64_t *d_y_off, T *d_gain, int16_t *d_pcm16) {
     ADN_REQUIRE(c && d_x && d_off && d_len && d_y && d_y_off, "null pointer argument");
     ADN_TRY(check_stft_args(n_fft, hop, n_ch));
     ADN_REQUIRE(kernel_bins >= 1 && kernel_bins <= 31 && (kernel_bins & 1), "median kernel must be odd and <= 31");
@@ -867,6 +874,7 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     a.y_off = d_y_off;
     a.sg = sg;
     a.tb = tb;
+    a.pcm = d_pcm16;
     a.row = gain;
     a.row_stride = F;
     a.st = 1;
@@ -1038,9 +1046,9 @@ int band_summary(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, cons
                               int, int, int, int, double, double, int, int, T *);                     \
     template int spectral_subtract<T>(Ctx *, const T *, int64_t, const int64_t *, const int64_t *,    \
                                       int64_t, int, const T *, int64_t, int, int, double, double,     \
-                                      int, int, T *, const int64_t *);                                \
+                                      int, int, T *, const int64_t *, int16_t *);                     \
     template int wiener<T>(Ctx *, const T *, int64_t, const int64_t *, const int64_t *, int64_t, int, \
-                           int, int, int, double, int, int, T *, const int64_t *, T *);               \
+                           int, int, int, double, int, int, T *, const int64_t *, T *, int16_t *);    \
     template int hpss_separate<T>(Ctx *, const T *, int64_t, const int64_t *, const int64_t *, int64_t, int, int, \
                                   int, int, int, double, double, double, int, int, const double *,     \
                                   const double *, int, double, double, T *, T *, const int64_t *, double *); \

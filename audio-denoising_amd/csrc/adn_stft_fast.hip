@@ -370,6 +370,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
     const int hr = MODE == APPLY_SUBTRACT ? a.st - h - 1 : 0;
     const float *xs = a.x + a.sg.off[sig];
     float *ys = a.y + a.y_off[sig];
+    int16_t *ps = a.pcm ? a.pcm + a.y_off[sig] : nullptr;
     const float *row = a.row + sig * a.row_stride;
     const float fscale = (float)(1.0 / tb.wsum);
     const float iscale = (float)(tb.wsum / 1024.0);
@@ -603,6 +604,11 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                             o = v / (norm > 1e-10f ? norm : 1.0f);
                         }
                         if (!a.no_clip) o = o < -1.0f ? -1.0f : (o > 1.0f ? 1.0f : o);
+                        if (ps) {
+                            const int k = pcm_int32(o) >> 16;
+                            ps[(int64_t)(j - R / 2) * H + i] = (int16_t)k;
+                            o = (float)k * (1.0f / 32768.0f);
+                        }
                         ys[(int64_t)(j - R / 2) * H + i] = o;
                     }
                     *slot = 0.0f;
@@ -674,6 +680,22 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                                 o.y = o.y < -1.0f ? -1.0f : (o.y > 1.0f ? 1.0f : o.y);
                                 o.z = o.z < -1.0f ? -1.0f : (o.z > 1.0f ? 1.0f : o.z);
                                 o.w = o.w < -1.0f ? -1.0f : (o.w > 1.0f ? 1.0f : o.w);
+                            }
+                            if (ps) {
+                                const int k0 = pcm_int32(o.x) >> 16, k1 = pcm_int32(o.y) >> 16;
+                                const int k2 = pcm_int32(o.z) >> 16, k3 = pcm_int32(o.w) >> 16;
+                                int16_t *pp = ps + (int64_t)(j - R / 2) * H + i;
+                                if ((reinterpret_cast<uintptr_t>(ps) & 7) == 0) {
+                                    *reinterpret_cast<uint2 *>(pp) = uint2{(unsigned)(k0 & 0xFFFF) | ((unsigned)k1 << 16),
+                                                                          (unsigned)(k2 & 0xFFFF) | ((unsigned)k3 << 16)};
+                                } else {
+                                    pp[0] = (int16_t)k0;
+                                    pp[1] = (int16_t)k1;
+                                    pp[2] = (int16_t)k2;
+                                    pp[3] = (int16_t)k3;
+                                }
+                                o = float4{(float)k0 * (1.0f / 32768.0f), (float)k1 * (1.0f / 32768.0f),
+                                           (float)k2 * (1.0f / 32768.0f), (float)k3 * (1.0f / 32768.0f)};
                             }
                             float *yp = ys + (int64_t)(j - R / 2) * H + i;
                             if (y_vec) {

@@ -216,17 +216,22 @@ int adn_hpss_f64(adn_ctx *ctx, const double *d_x, int64_t n_sig, const int64_t *
  * the phase -> ISTFT (drops n_fft/2 at both ends) -> clip to [-1, 1].
  * d_noise: noise magnitude per bin, n_fft/2+1 values per signal at
  * d_noise[s*noise_stride] (noise_stride = 0 shares one profile).
- * Signal s writes adn_istft_out_samples(len[s]) samples at d_y[d_y_off[s]]. */
+ * Signal s writes adn_istft_out_samples(len[s]) samples at d_y[d_y_off[s]].
+ * d_pcm16 (may be NULL): the stage file of the reference is 16-bit PCM
+ * (src/spectral_subtract.py:109-110); when given, the kernel's store also writes
+ * the file's sample values there (same offsets as d_y, rule of adn_pcm_encode_*)
+ * and d_y holds what a reader of that file gets, pcm / 32768. */
 int adn_spectral_subtract_f32(adn_ctx *ctx, const float *d_x, int64_t n_sig, const int64_t *d_off,
                               const int64_t *d_len, int64_t max_len, int n_ch,
                               const float *d_noise, int64_t noise_stride, int n_fft, int hop,
                               double alpha, double beta, int smooth_time, int smooth_freq,
-                              float *d_y, const int64_t *d_y_off);
+                              float *d_y, const int64_t *d_y_off, int16_t *d_pcm16);
 int adn_spectral_subtract_f64(adn_ctx *ctx, const double *d_x, int64_t n_sig,
                               const int64_t *d_off, const int64_t *d_len, int64_t max_len,
                               int n_ch, const double *d_noise, int64_t noise_stride, int n_fft,
                               int hop, double alpha, double beta, int smooth_time,
-                              int smooth_freq, double *d_y, const int64_t *d_y_off);
+                              int smooth_freq, double *d_y, const int64_t *d_y_off,
+                              int16_t *d_pcm16);
 
 /* Phase 2c (src/wiener_filter.py:12-39, 72-129): |Z|^2, 10th percentile over
  * time per bin -> medfilt -> floor 1e-12; energy VAD (frame = int(sr*update_ms/
@@ -234,15 +239,16 @@ int adn_spectral_subtract_f64(adn_ctx *ctx, const double *d_x, int64_t n_sig,
  * (or the median when vad_guided == 0) -> medfilt -> max(., noise); gain =
  * medfilt(clip(snr/(1+snr), 0, 1)); Z*gain -> ISTFT -> clip.  The reference's
  * attack/release loop never executes, so the gain is constant in time.
- * d_gain (n_sig rows of n_fft/2+1, may be NULL) receives the per-bin gain. */
+ * d_gain (n_sig rows of n_fft/2+1, may be NULL) receives the per-bin gain.
+ * d_pcm16 (may be NULL): as for adn_spectral_subtract_*. */
 int adn_wiener_f32(adn_ctx *ctx, const float *d_x, int64_t n_sig, const int64_t *d_off,
                    const int64_t *d_len, int64_t max_len, int n_ch, int sample_rate, int n_fft,
                    int hop, double update_ms, int kernel_bins, int vad_guided, float *d_y,
-                   const int64_t *d_y_off, float *d_gain);
+                   const int64_t *d_y_off, float *d_gain, int16_t *d_pcm16);
 int adn_wiener_f64(adn_ctx *ctx, const double *d_x, int64_t n_sig, const int64_t *d_off,
                    const int64_t *d_len, int64_t max_len, int n_ch, int sample_rate, int n_fft,
                    int hop, double update_ms, int kernel_bins, int vad_guided, double *d_y,
-                   const int64_t *d_y_off, double *d_gain);
+                   const int64_t *d_y_off, double *d_gain, int16_t *d_pcm16);
 
 /* ------------------------------------------------- RMS-window profiler
  * Per-window sum of squares over all channels divided by the window's row
@@ -253,6 +259,18 @@ int adn_window_rms_f32(adn_ctx *ctx, const float *d_x, int64_t n_rows, int n_ch,
                        double *d_rms);
 int adn_window_rms_f64(adn_ctx *ctx, const double *d_x, int64_t n_rows, int n_ch, int64_t win,
                        double *d_rms);
+
+/* ---------------------------------------------------- PCM file samples
+ * The stage files between the phases are 16-bit PCM (denoise.py:75,90; sf.write in
+ * src/wavelet_denoise.py, src/spectral_subtract.py:109-110, src/wiener_filter.py): the next
+ * stage reads quantised samples.  d_q receives the integer sample values of d_x[0..n)
+ * (bits = 16: int16_t; bits = 24 or 32: int32_t) by libsndfile's rule with clipping enabled:
+ * rint(x * 2^31) saturated to int32, arithmetic shift right by 32 - bits; NaN -> 0.
+ * d_xq (may be null, may be d_x itself) receives q / 2^(bits-1), the value a reader of the
+ * file gets, so that stages can be chained on the device while the files are still written
+ * from d_q.  All three buffers must be 16-byte aligned. */
+int adn_pcm_encode_f32(adn_ctx *ctx, const float *d_x, int64_t n, int bits, void *d_q, float *d_xq);
+int adn_pcm_encode_f64(adn_ctx *ctx, const double *d_x, int64_t n, int bits, void *d_q, double *d_xq);
 
 /* ------------------------------------------------ synthetic test signal
  * Fills d_x with n samples of the bit-reproducible "noisy speech" generator

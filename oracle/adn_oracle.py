@@ -654,3 +654,30 @@ def noise_profiler_predict(x, sample_rate=44100, time_window=0.1, percentile_lev
     thr, is_noise = noise_windows(rms, percentile_level)
     order = predicted_noise_order(is_noise)
     return np.concatenate([x[i * win:(i + 1) * win] for i in order], axis=0), thr, is_noise
+
+
+# ---------------------------------------------------------------------------------------------
+# PCM file samples (the stage files between the phases are 16-bit PCM: denoise.py:75,90 and the
+# sf.write calls of src/*.py go through libsndfile with clipping enabled).  libsndfile is not
+# available to this build, so this restates its conversion and is NOT pinned by a reference run.
+def pcm_encode(x, bits=16):
+    """One sample at a time, integer arithmetic after the rounding: scale by 2^31, round half to
+    even, saturate to int32, keep the top `bits` bits.  NaN -> 0."""
+    out = np.empty(np.size(x), dtype=np.int64)
+    for i, v in enumerate(np.asarray(x, dtype=np.float64).ravel()):
+        if v != v:
+            out[i] = 0
+            continue
+        s = v * 2147483648.0
+        if s >= 2147483647.0:
+            n = 2147483647
+        elif s <= -2147483648.0:
+            n = -2147483648
+        else:
+            n = int(round(s))               # Python's round() is round-half-to-even
+        out[i] = n >> (32 - bits)           # arithmetic shift
+    return out.reshape(np.shape(x))
+
+
+def pcm_decode(q, bits=16):
+    return np.asarray(q, dtype=np.float64) / float(1 << (bits - 1))

@@ -259,3 +259,26 @@ def test_pipeline_v1_passes_overrides(tmp_path, capsys):
         f.unlink()
     orc_.pipeline_main(["--config", cfg, "--phases", "1"], src_dir=src)
     assert not list(logs.glob("phase2*"))
+
+
+def test_pcm_rule_matches_oracle(tmp_path):
+    """The WAV writer's vectorised PCM conversion equals the sample-at-a-time restatement,
+    including saturation, ties, negative values (rounding towards minus infinity) and NaN."""
+    import adn_oracle as orc
+    from adn_hip import wavio
+    rng = np.random.default_rng(5)
+    edge = np.array([0.0, -0.0, 1.0, -1.0, 1.5, -1.5, 0.999999999, -0.999999999, 1 - 2.0 ** -16, 2.0 ** -16,
+                     -2.0 ** -16, 2.0 ** -15, -2.0 ** -15, 3 * 2.0 ** -17, -3 * 2.0 ** -17, 0.5 * 2.0 ** -31,
+                     1.5 * 2.0 ** -31, 2.5 * 2.0 ** -31, -0.5 * 2.0 ** -31, np.nan, np.inf, -np.inf,
+                     (65536 * 7 - 0.5) / 2.0 ** 31, (65536 * 7 - 0.49) / 2.0 ** 31, -(65536 * 7 + 0.5) / 2.0 ** 31])
+    x = np.concatenate([edge, rng.uniform(-1.1, 1.1, 3000), rng.standard_normal(1000) * 1e-4])
+    for bits in (16, 24, 32):
+        assert np.array_equal(wavio.pcm_quantize(x, bits), orc.pcm_encode(x, bits))
+    q = orc.pcm_encode(x, 16)
+    assert q.min() == -32768 and q.max() == 32767 and q[19] == 0
+    fin = np.isfinite(x) & (np.abs(x) < 1)
+    assert np.all(q[fin] == np.floor(np.rint(x[fin] * 2.0 ** 31) / 65536.0))
+    # file round trip: read(write(x)) == decode(encode(x))
+    p = str(tmp_path / "q.wav")
+    wavio.write(p, x[fin], 8000)
+    assert np.array_equal(wavio.read(p)[0], orc.pcm_decode(q[fin], 16))
