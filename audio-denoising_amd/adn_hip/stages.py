@@ -21,7 +21,7 @@ from pathlib import Path
 
 import numpy as np
 
-from . import wavio
+from . import devfiles, wavio
 
 
 def _torch_dtype():
@@ -41,6 +41,14 @@ def _to_device(a):
     import torch
     e = _engine()
     return torch.as_tensor(np.ascontiguousarray(a), device=e.torch_device).to(_torch_dtype())
+
+
+def _pcm_buffer(e, frames, n_fft, hop):
+    """int16 buffer for the fused PCM store of an STFT stage, None when the files are not 16-bit PCM."""
+    import torch
+    if wavio.default_subtype() != "PCM_16" or frames < n_fft:
+        return None
+    return torch.empty(e.istft_out_samples(frames, n_fft, hop), dtype=torch.int16, device=e.torch_device)
 
 
 def _load_config(path):
@@ -253,8 +261,8 @@ def spectral_subtract_main(argv=None):
         raise SystemExit("Noise profile npz not found. Run src/noise_profile.py first.")
     out_path = args.output or os.path.join(outputs_dir, "phase2b_spectral_subtract.wav")
 
-    x, sr = wavio.read(in_path)
-    n_ch = 1 if x.ndim == 1 else x.shape[1]
+    e = _engine()
+    x, sr, n_ch, frames = devfiles.read_wav(in_path, e, _torch_dtype())
     sc = cfg["spectral_subtraction"]
     n_fft, hop = int(sc["n_fft"]), int(sc["hop_length"])
     prof = load_noise_profile(noise_npz)
@@ -264,11 +272,11 @@ def spectral_subtract_main(argv=None):
     F = n_fft // 2 + 1
     if nf.shape[0] != F:
         nf = np.interp(np.linspace(0, len(nf) - 1, F), np.arange(len(nf)), nf)
-    e = _engine()
-    y, lens = e.spectral_subtract(_to_device(x).reshape(-1), [x.shape[0]], _to_device(nf), n_ch=n_ch, n_fft=n_fft,
+    pcm = _pcm_buffer(e, frames, n_fft, hop)
+    y, lens = e.spectral_subtract(x, [frames], _to_device(nf), n_ch=n_ch, n_fft=n_fft,
                                   hop=hop, alpha=sc["alpha"], beta=sc["beta"],
-                                  smooth_time=sc["smoothing"]["time"], smooth_freq=sc["smoothing"]["freq"])
-    wavio.write(out_path, y.double().cpu().numpy(), sr)
+                                  smooth_time=sc["smoothing"]["time"], smooth_freq=sc["smoothing"]["freq"], pcm16=pcm)
+    devfiles.write_wav(out_path, y, sr, 1, e, pcm16=pcm)
     _dump(os.path.join(logs_dir, "phase2b_spectral_subtract.json"),
           {"input": in_path, "output": out_path, "noise_profile": noise_npz, "alpha": sc["alpha"],
            "beta": sc["beta"], "n_fft": n_fft, "hop_length": hop, "smoothing": sc["smoothing"]})
@@ -290,17 +298,17 @@ def wiener_filter_main(argv=None):
     in_path = args.input or next((p for p in prefer if os.path.exists(p)), cfg["paths"]["input"])
     out_path = args.output or os.path.join(outputs_dir, "phase2c_wiener.wav")
 
-    x, sr = wavio.read(in_path)
-    n_ch = 1 if x.ndim == 1 else x.shape[1]
+    e = _engine()
+    x, sr, n_ch, frames = devfiles.read_wav(in_path, e, _torch_dtype())
     sc, wc = cfg["spectral_subtraction"], cfg["wiener"]
     n_fft, hop = int(sc["n_fft"]), int(sc["hop_length"])
     update_ms = wc.get("update_ms", 20)
     kernel_bins = wc.get("median_kernel_bins", 5)
     vad_guided = wc.get("vad_guided", True)
-    e = _engine()
-    y, _ = e.wiener(_to_device(x).reshape(-1), [x.shape[0]], sr, n_ch=n_ch, n_fft=n_fft, hop=hop,
-                    update_ms=update_ms, kernel_bins=kernel_bins, vad_guided=vad_guided)
-    wavio.write(out_path, y.double().cpu().numpy(), sr)
+    pcm = _pcm_buffer(e, frames, n_fft, hop)
+    y, _ = e.wiener(x, [frames], sr, n_ch=n_ch, n_fft=n_fft, hop=hop,
+                    update_ms=update_ms, kernel_bins=kernel_bins, vad_guided=vad_guided, pcm16=pcm)
+    devfiles.write_wav(out_path, y, sr, 1, e, pcm16=pcm)
     _dump(os.path.join(logs_dir, "phase2c_wiener.json"),
           {"input": in_path, "output": out_path, "n_fft": n_fft, "hop_length": hop,
            "median_kernel_bins": kernel_bins, "vad_guided": vad_guided, "attack_ms": 5, "release_ms": 50})
@@ -332,8 +340,8 @@ def hpss_separate_main(argv=None):
     out_percussive = args.output_percussive or os.path.join(outputs_dir, "phase3_percussive.wav")
     out_combined = args.output_combined or os.path.join(outputs_dir, "phase3_hpss.wav")
     print(f"[INFO] Loading input from {in_path}")
-    x, sr = wavio.read(in_path)
-    n_ch = 1 if x.ndim == 1 else x.shape[1]
+    e = _engine()
+    x, sr, n_ch, frames = devfiles.read_wav(in_path, e, _torch_dtype())
     hp = cfg.get("hpss", {})
     method = hp.get("method", "median")
     margin_h, margin_p = hp.get("margin_harmonic", 1.0), hp.get("margin_percussive", 5.0)
@@ -350,23 +358,21 @@ def hpss_separate_main(argv=None):
         power = 2.0                 # multiband_hpss never forwards `power` (src/hpss_separate.py:103-105)
     elif method == "librosa":
         print("[WARN] librosa not available, using fallback median filtering")
-    e = _engine()
-    yh, yp, _, stats = e.hpss(_to_device(x).reshape(-1), [x.shape[0]], sr, n_ch=n_ch, kernel_size=kernel_size,
+    yh, yp, _, stats = e.hpss(x, [frames], sr, n_ch=n_ch, kernel_size=kernel_size,
                               margin_h=margin_h, margin_p=margin_p, power=power,
                               mask_type=mask_type if mask_type in ("hard", "binary") else "soft", bands=bands,
                               preserve_transients=preserve)
     print("[INFO] Reconstructing audio...")
     if preserve:
         print("[INFO] Preserving transients...")
-    y_harmonic, y_percussive = yh.double().cpu().numpy(), yp.double().cpu().numpy()
     st = stats.cpu().numpy()[0]
     print("[INFO] Saving outputs...")
     if reversible:
-        wavio.write(out_harmonic, y_harmonic, sr)
-        wavio.write(out_percussive, y_percussive, sr)
+        devfiles.write_wav(out_harmonic, yh, sr, 1, e)
+        devfiles.write_wav(out_percussive, yp, sr, 1, e)
         print(f"  - Harmonic: {out_harmonic}")
         print(f"  - Percussive: {out_percussive}")
-    wavio.write(out_combined, y_harmonic, sr)
+    devfiles.write_wav(out_combined, yh, sr, 1, e)
     print(f"  - Combined: {out_combined}")
     dt = time.time() - t0
     energy_harmonic, energy_percussive, energy_total = float(st[0]), float(st[1]), float(st[2])
@@ -403,7 +409,46 @@ def run_step(cmd, log_path):
     print(f"[OK] ({dt:.1f}s) -> {log_path}")
 
 
+def run_step_inprocess(label, fn, argv, log_path):
+    """One stage as a function call in this process: the stage's prints and any traceback go to the
+    same log file, in the same format, as a subprocess run would leave (src/core_pipeline.py:26-39).
+    The GPU context, the kernels' tables and the device-resident stage files are shared by the
+    stages that follow."""
+    import contextlib
+    import io
+    import traceback
+    log_path = Path(log_path)
+    log_path.parent.mkdir(parents=True, exist_ok=True)
+    print(f"[RUN] {label} {' '.join(argv)}")
+    buf = io.StringIO()
+    rc = 0
+    t0 = time.time()
+    with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(buf):
+        try:
+            fn(argv)
+        except SystemExit as ex:
+            if ex.code not in (None, 0):
+                rc = ex.code if isinstance(ex.code, int) else 1
+                if not isinstance(ex.code, int):
+                    print(ex.code)
+        except BaseException:  # noqa: BLE001 - a stage failure of any kind ends the run like a non-zero exit
+            traceback.print_exc(file=buf)
+            rc = 1
+    dt = time.time() - t0
+    with open(log_path, "w", encoding="utf-8") as fh:
+        fh.write(buf.getvalue())
+        fh.write(f"\n[elapsed_sec]: {dt:.3f}\n")
+        fh.write(f"[returncode]: {rc}\n")
+    if rc != 0:
+        print(buf.getvalue())
+        raise SystemExit(f"Step failed: {label} {' '.join(argv)} (see {log_path})")
+    print(f"[OK] ({dt:.1f}s) -> {log_path}")
+
+
 def core_pipeline_main(argv=None, src_dir=None):
+    """src/core_pipeline.py:42-101.  ``ADN_CHAIN=process`` starts one interpreter per stage like the
+    reference; the default runs the four stages in this process (one GPU context, stage outputs
+    handed over on the device) with the same files and logs."""
     ap = argparse.ArgumentParser(description="Core DSP pipeline (no analysis, no AI)")
     ap.add_argument("--config", required=True)
     ap.add_argument("--input", required=True, help="Interview/input WAV path")
@@ -419,13 +464,19 @@ def core_pipeline_main(argv=None, src_dir=None):
     _mkdirs(logs_dir, outputs_dir)
     _dump(logs_dir / "resolved_config_core.json", cfg)
     src = Path(src_dir) if src_dir else Path(__file__).resolve().parents[1] / "src"
+    mode = os.environ.get("ADN_CHAIN", "inprocess").lower()
+    if mode not in ("inprocess", "process"):
+        raise ValueError("ADN_CHAIN must be inprocess or process")
     py = sys.executable
-    plan = [("noise_profile.py", ["--noise", args.noise], "core_phase1_noise_profile_stdout.log"),
-            ("wavelet_denoise.py", ["--input", args.input], "core_phase2_wavelet_stdout.log"),
-            ("spectral_subtract.py", [], "core_phase2b_spectral_subtract_stdout.log"),
-            ("wiener_filter.py", [], "core_phase2c_wiener_stdout.log")]
-    for script, extra, log in plan:
-        run_step([py, str(src / script), "--config", args.config] + extra, logs_dir / log)
+    plan = [("noise_profile.py", noise_profile_main, ["--noise", args.noise], "core_phase1_noise_profile_stdout.log"),
+            ("wavelet_denoise.py", wavelet_denoise_main, ["--input", args.input], "core_phase2_wavelet_stdout.log"),
+            ("spectral_subtract.py", spectral_subtract_main, [], "core_phase2b_spectral_subtract_stdout.log"),
+            ("wiener_filter.py", wiener_filter_main, [], "core_phase2c_wiener_stdout.log")]
+    for script, fn, extra, log in plan:
+        if mode == "process":
+            run_step([py, str(src / script), "--config", args.config] + extra, logs_dir / log)
+        else:
+            run_step_inprocess(str(src / script), fn, ["--config", args.config] + extra, logs_dir / log)
     print("\n[COMPLETE] Core DSP pipeline finished")
     print(f"Wavelet output: {outputs_dir / 'phase2_wavelet.wav'}")
     print(f"Spectral subtract output: {outputs_dir / 'phase2b_spectral_subtract.wav'}")

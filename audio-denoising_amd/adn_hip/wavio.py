@@ -161,6 +161,14 @@ def write(path, data, samplerate, subtype=None):
         fh.write(data)
 
 
+def write_pcm16(path, q, samplerate, channels=1):
+    """16-bit PCM file from integer sample values (interleaved int16, e.g. made on the GPU)."""
+    raw = np.ascontiguousarray(q, dtype="<i2").tobytes()
+    with open(path, "wb") as fh:
+        fh.write(_header(int(samplerate), int(channels), "PCM_16", len(raw)))
+        fh.write(raw)
+
+
 class SoundFile:
     """Write-mode file that accepts successive blocks (denoise.py:75,90)."""
 

@@ -45,15 +45,12 @@ class AudioDeNoise:
         """Reads the input file, de-noises every 10 % block independently on the GPU and
         writes the blocks back to back (same sample rate and channel count).  Blocks of
         odd length come back one sample longer, exactly like the reference."""
-        import torch
-        info = wavio.info(self.__inputFile)
-        rate = info.samplerate
-        data, _ = wavio.read(self.__inputFile)
+        from adn_hip import devfiles
         e = _engine()
-        x = torch.as_tensor(np.ascontiguousarray(data), device=e.torch_device).to(_dtype())
-        y = e.denoise_signal(x, rate, wavelet="db4", level=2, thr_mode="soft")
-        with wavio.SoundFile(outputFile, "w", samplerate=rate, channels=info.channels) as of:
-            of.write(y.double().cpu().numpy())
+        x, rate, channels, frames = devfiles.read_wav(self.__inputFile, e, _dtype())
+        y = e.denoise_signal(x if channels == 1 else x.reshape(frames, channels), rate, wavelet="db4", level=2,
+                             thr_mode="soft")
+        devfiles.write_wav(outputFile, y.reshape(-1), rate, channels, e)
 
     def generateNoiseProfile(self, noiseFile):
         """Reads `noiseFile`, keeps its quiet 0.1 s windows (filling the gaps with

@@ -9,9 +9,11 @@ import sys
 
 import numpy as np
 import pytest
+import torch
 
 import synth
-from gpu_util import check64
+
+from gpu_util import check64, dev, engine, host
 from test_oracle_golden import _denoise_input, _profiler_input
 
 pytestmark = pytest.mark.gpu
@@ -181,3 +183,53 @@ def test_pcm16_default_files(tmp_path, monkeypatch):
     AudioDeNoise(pin).deNoise(pout)
     inf = wavio.info(pout)
     assert (inf.subtype, inf.channels, inf.samplerate, inf.frames) == ("PCM_16", 1, 8000, 20000)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_core_pipeline_chain_modes_write_identical_files(tmp_path, dtype):
+    """16-bit PCM stage files (the reference's default): one interpreter per stage reading the files
+    back from disk, one process with the stage outputs handed over on the device, and one process
+    with that residency switched off must write byte-identical files; the quantised samples come
+    from the kernels' fused store and from adn_pcm_encode."""
+    import hashlib
+    from adn_hip import wavio
+    tmp = str(tmp_path)
+    px, pn = os.path.join(tmp, "in.wav"), os.path.join(tmp, "noise.wav")
+    wavio.write(px, synth.stereo_noisy_speech(60001, SR, 42, 31), SR, "DOUBLE")
+    wavio.write(pn, synth.white_noise(48000, 42, 1002), SR, "DOUBLE")
+    digests = {}
+    for mode, resident in (("process", "1"), ("inprocess", "1"), ("inprocess", "0")):
+        work = os.path.join(tmp, mode + resident)
+        os.makedirs(work)
+        pc, cfg = _config(work, px, pn)
+        env = dict(os.environ, ADN_DTYPE=dtype, ADN_CHAIN=mode, ADN_DEVICE_FILES=resident)
+        env.pop("ADN_WAV_SUBTYPE", None)
+        r = subprocess.run([sys.executable, os.path.join(PKG, "src", "core_pipeline.py"), "--config", pc,
+                            "--input", px, "--noise", pn], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, env=env, cwd=work, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:]
+        odir, ldir = cfg["paths"]["outputs_dir"], cfg["paths"]["logs_dir"]
+        names = ["phase2_wavelet.wav", "phase2b_spectral_subtract.wav", "phase2c_wiener.wav"]
+        for n in names:
+            assert wavio.info(os.path.join(odir, n)).subtype == "PCM_16"
+        digests[(mode, resident)] = [hashlib.sha256(open(os.path.join(odir, n), "rb").read()).hexdigest()
+                                     for n in names]
+        log = open(os.path.join(ldir, "core_phase2b_spectral_subtract_stdout.log")).read()
+        assert "Phase 2b (Spectral Subtraction) complete -> " in log and "[returncode]: 0" in log
+        side = json.load(open(os.path.join(ldir, "phase2c_wiener.json")))
+        assert side["input"].endswith("phase2b_spectral_subtract.wav")
+    assert digests[("process", "1")] == digests[("inprocess", "1")] == digests[("inprocess", "0")]
+    # the wavelet file holds the writer's conversion of the kernel output
+    e = engine()
+    x, _ = wavio.read(px)
+    tdt = torch.float32 if dtype == "f32" else torch.float64
+    y = host(e.denoise_signal(dev(x, tdt), SR)).astype(np.float64)
+    q = np.frombuffer(open(os.path.join(tmp, "process1", "out", "phase2_wavelet.wav"), "rb").read()[44:], dtype="<i2")
+    assert np.array_equal(q, wavio.pcm_quantize(y, 16).ravel())
+    # in-process failure: same "Step failed" exit and log as with subprocesses
+    env = dict(os.environ, ADN_DTYPE=dtype)
+    r2 = subprocess.run([sys.executable, os.path.join(PKG, "src", "core_pipeline.py"), "--config", pc,
+                         "--input", "/nonexistent/in.wav", "--noise", pn], stdout=subprocess.PIPE,
+                        stderr=subprocess.STDOUT, text=True, env=env, cwd=work, timeout=600)
+    assert r2.returncode != 0 and "Step failed" in r2.stdout
+    assert "[returncode]: 1" in open(os.path.join(cfg["paths"]["logs_dir"], "core_phase2_wavelet_stdout.log")).read()
