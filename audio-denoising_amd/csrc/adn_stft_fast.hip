@@ -177,20 +177,31 @@ __device__ __noinline__ void stage_frame_generic(c2 *buf, const float *__restric
 __device__ __forceinline__ void load_frame(c2 (&r)[16], c2 *buf, const float *__restrict__ xs, int64_t n,
                                            int n_ch, int64_t p0, const float *__restrict__ window, int lane) {
     const c2 *wv = reinterpret_cast<const c2 *>(window);
+    // All loads of the frame are issued before anything uses them (the scheduling barriers keep
+    // the compiler from sinking a load next to its use, which serialises sixteen round trips).
     if (p0 + 2048 <= n && n_ch == 1 && (reinterpret_cast<uintptr_t>(xs + p0) & 7) == 0) {
         const c2 *xv = reinterpret_cast<const c2 *>(xs + p0) + lane;
+        c2 a[16];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = xv[64 * j];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const c2 a = xv[64 * j], w = wv[lane + 64 * j];
-            r[j] = c2{a.x * w.x, a.y * w.y};
+            const c2 w = wv[lane + 64 * j];
+            r[j] = c2{a[j].x * w.x, a[j].y * w.y};
         }
     } else if (p0 + 2048 <= n && n_ch == 2 && (reinterpret_cast<uintptr_t>(xs + 2 * p0) & 15) == 0) {
         const float4 *xv = reinterpret_cast<const float4 *>(xs + 2 * p0) + lane;
+        float4 a[16];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = xv[64 * j];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const float4 a = xv[64 * j];
             const c2 w = wv[lane + 64 * j];
-            r[j] = c2{(a.x + a.y) / 2.0f * w.x, (a.z + a.w) / 2.0f * w.y};
+            r[j] = c2{(a[j].x + a[j].y) / 2.0f * w.x, (a[j].z + a[j].w) / 2.0f * w.y};
         }
     } else {
         stage_frame_generic(buf, xs, n, n_ch, p0, window, lane);
@@ -262,6 +273,7 @@ __global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ 
     c2 *bufs = reinterpret_cast<c2 *>(smem);
     float *tile = reinterpret_cast<float *>(bufs + (size_t)W * WBUF);      // [1025][FT + 1]
     c2 *twtab = reinterpret_cast<c2 *>(tile + 1025 * (FT + 1) + ((1025 * (FT + 1)) & 1));
+    float *wtab = reinterpret_cast<float *>(twtab + TWTAB);                // [2048] window
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t sig = blockIdx.x / groups_per_sig, grp = blockIdx.x % groups_per_sig;
     const int64_t n = sg.len[sig];
@@ -271,6 +283,7 @@ __global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ 
     const float *xs = x + sg.off[sig];
     c2 *buf = bufs + (size_t)wave * WBUF;
     fill_tw_table(twtab, tb.fast_tw, threadIdx.x, W * 64);
+    for (int i = threadIdx.x; i < 2048; i += W * 64) wtab[i] = tb.window[i];
     __syncthreads();
     const LaneTw tw = lane_tw(twtab, lane);
     c2 rtw[8];
@@ -283,7 +296,7 @@ __global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ 
         const int64_t t = t0 + ft;
         if (t < Tn) {
             c2 r[16];
-            load_frame(r, buf, xs, n, sg.n_ch, t * sg.hop, tb.window, lane);
+            load_frame(r, buf, xs, n, sg.n_ch, t * sg.hop, wtab, lane);
             wave_fft1024<false>(r, buf, tw, lane);
             store_natural(r, buf, lane);
             wave_sync();
@@ -350,8 +363,8 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
     float *acc = mags + (MODE == APPLY_SUBTRACT ? (size_t)W * MROW : 0);              // [RING][H]
     float *wsq = acc + (size_t)RING * H;                                              // [H] full-overlap norm
     c2 *twtab = reinterpret_cast<c2 *>(wsq + H);
-    // GAIN mode has LDS to spare: the window lives there (analysis and synthesis reads)
-    float *wtab = reinterpret_cast<float *>(twtab + TWTAB);                           // [2048], GAIN only
+    // the window lives in LDS (analysis and synthesis reads)
+    float *wtab = reinterpret_cast<float *>(twtab + TWTAB);                           // [2048]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
     const int64_t sig = blockIdx.x / a.segs_per_sig, seg = blockIdx.x % a.segs_per_sig;
     const int64_t n = a.sg.len[sig];
@@ -386,8 +399,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
     c2 rtw[8];
     load_rtw(rtw, tb.rtw, lane);
 
-    if (MODE == APPLY_GAIN)
-        for (int i = tid; i < 2048; i += W * 64) wtab[i] = tb.window[i];
+    for (int i = tid; i < 2048; i += W * 64) wtab[i] = tb.window[i];
     for (int i = tid; i < RING * H; i += W * 64) acc[i] = 0.0f;
     for (int i = tid; i < H; i += W * 64) {
         float s = 0.0f;
@@ -420,8 +432,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
         // ---- stage A: spectrum of frame t
         if (t <= a_last && !(a.ablate & 1)) {
             c2 r[16];
-            if (MODE == APPLY_GAIN) load_frame(r, buf, xs, n, a.sg.n_ch, (int64_t)t * H, wtab, lane);
-            else load_frame(r, buf, xs, n, a.sg.n_ch, (int64_t)t * H, tb.window, lane);
+            load_frame(r, buf, xs, n, a.sg.n_ch, (int64_t)t * H, wtab, lane);
             if (prof) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             tick(6);
             wave_fft1024<false>(r, buf, tw, lane);
@@ -555,7 +566,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
             if (!win_in_ola) {
                 // time samples of this lane: n = k1 + 16 c + 256 d; apply the synthesis window
                 const int b = lane & 3, d = ((b >> 1) | ((b & 1) << 1));
-                const c2 *wv = reinterpret_cast<const c2 *>(tb.window) + (lane >> 2) + 256 * d;
+                const c2 *wv = reinterpret_cast<const c2 *>(wtab) + (lane >> 2) + 256 * d;
 #pragma unroll
                 for (int c = 0; c < 16; ++c) {
                     const c2 w = wv[16 * c];
@@ -629,8 +640,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                 float4 wsyn[4];                                  // synthesis window * scale at (qq * H + i ..)
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
-                    const float4 w = MODE == APPLY_GAIN ? *reinterpret_cast<const float4 *>(wtab + (qq << LOGH) + i)
-                                                        : *reinterpret_cast<const float4 *>(tb.window + (qq << LOGH) + i);
+                    const float4 w = *reinterpret_cast<const float4 *>(wtab + (qq << LOGH) + i);
                     wsyn[qq] = float4{w.x * iscale, w.y * iscale, w.z * iscale, w.w * iscale};
                 }
                 const bool y_vec = (reinterpret_cast<uintptr_t>(ys) & 15) == 0;
@@ -745,7 +755,7 @@ static size_t apply_lds(int W, int mode, int hop) {
     const int R = 2048 / hop;
     return (size_t)W * WBUF * sizeof(c2) + (mode == APPLY_SUBTRACT ? (size_t)W * MROW * sizeof(float) : 0) +
            (size_t)(W + R) * hop * sizeof(float) + (size_t)hop * sizeof(float) + (size_t)TWTAB * sizeof(c2) +
-           (mode == APPLY_GAIN ? 2048 * sizeof(float) : 0);
+           2048 * sizeof(float);
 }
 
 }  // namespace fast
@@ -790,14 +800,14 @@ int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
 
 bool apply_fast_ok(int n_fft, int hop, int st, int sf) {
     if (n_fft != 2048 || hop < 64 || (st != fast::FAST_ST && st != 1) || sf > 2 * fast::RAWPAD) return false;
-    return fast::apply_lds(8, APPLY_SUBTRACT, hop) <= 156 * 1024;
+    return fast::apply_lds(8, APPLY_SUBTRACT, hop) <= 160 * 1024;
 }
 
 int rows_fast(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &tb, int64_t n_sig,
               int64_t Tmax, int power, float *S, unsigned long long *sig_max) {
     constexpr int W = 8, FT = 16;
     const size_t lds = (size_t)W * fast::WBUF * sizeof(float2) + (size_t)(1025 * (FT + 1) + 1) * sizeof(float) +
-                       (size_t)fast::TWTAB * sizeof(float2);
+                       (size_t)fast::TWTAB * sizeof(float2) + 2048 * sizeof(float);
     const int64_t groups = ceil_div(Tmax, FT);
     auto kern = fast::k_rows_fast<W>;
     ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
