@@ -104,35 +104,68 @@ static int get_tables(Ctx *c, int n_fft, Tables<T> *out) {
 }
 
 // ------------------------------------------------------- wave-level FFTs
+// Position of complex point i in a wave's LDS buffer.  One spare slot after every 16 and every 64
+// points keeps the strided sweeps of the transforms and the bit-reversed spectrum accesses spread
+// over the banks (unpadded, the 64 lanes of a bit-reversed access all hit one bank).
+__device__ __forceinline__ int lp(int i) { return i + (i >> 4) + (i >> 6); }
+__host__ __device__ constexpr int lp_size(int Nc) { return Nc + (Nc >> 4) + (Nc >> 6) + 2; }
+
 // In-place complex FFT of Nc = 2^logn points in LDS, natural order in, bit-reversed
 // order out (decimation in frequency, two radix-2 stages fused per sweep).
+// Every sweep handles the butterflies of a lane in batches of four: all LDS reads and twiddle
+// loads of a batch are issued before the first result is needed, and the batch is written back
+// afterwards (the butterflies of one sweep touch disjoint elements).
 template <typename V>
-__device__ void fft_dif(V *buf, const V *__restrict__ tw, int logn, int lane) {
-    const int Nc = 1 << logn;
+__device__ void fft_dif(V *buf, const V *tw, int logn, int lane) {
+    const int Nc = 1 << logn, Q = Nc >> 2;
+    constexpr int U = 4;
     int s = logn;
     while (s >= 2) {
         const int m = 1 << (s - 1), hm = m >> 1, twstep = Nc >> s;
-        for (int q = lane; q < Nc / 4; q += 64) {
-            const int j = q & (hm - 1);
-            const int i0 = ((q >> (s - 2)) << s) + j;
-            const V a0 = buf[i0], a1 = buf[i0 + hm], a2 = buf[i0 + m], a3 = buf[i0 + m + hm];
-            const V w1 = tw[j * twstep], w2 = tw[2 * j * twstep];
-            const V b0 = cadd(a0, a2), b2 = cmul(csub(a0, a2), w1);
-            const V b1 = cadd(a1, a3), d = csub(a1, a3);
-            const V b3 = cmul(V{d.y, -d.x}, w1);                 // (a1 - a3) * (-i) * w1
-            buf[i0] = cadd(b0, b1);
-            buf[i0 + hm] = cmul(csub(b0, b1), w2);
-            buf[i0 + m] = cadd(b2, b3);
-            buf[i0 + m + hm] = cmul(csub(b2, b3), w2);
+#pragma unroll 1
+        for (int q0 = lane; q0 < Q; q0 += 64 * U) {
+            V a0[U], a1[U], a2[U], a3[U], w1[U], w2[U];
+            int i0[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = q0 + 64 * u < Q ? q0 + 64 * u : q0;         // out of range: repeat the first one
+                const int j = q & (hm - 1);
+                i0[u] = ((q >> (s - 2)) << s) + j;
+                a0[u] = buf[lp(i0[u])];
+                a1[u] = buf[lp(i0[u] + hm)];
+                a2[u] = buf[lp(i0[u] + m)];
+                a3[u] = buf[lp(i0[u] + m + hm)];
+                w1[u] = tw[j * twstep];
+                w2[u] = tw[2 * j * twstep];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const V b0 = cadd(a0[u], a2[u]), b2 = cmul(csub(a0[u], a2[u]), w1[u]);
+                const V b1 = cadd(a1[u], a3[u]), d = csub(a1[u], a3[u]);
+                const V b3 = cmul(V{d.y, -d.x}, w1[u]);                 // (a1 - a3) * (-i) * w1
+                a0[u] = cadd(b0, b1);
+                a1[u] = cmul(csub(b0, b1), w2[u]);
+                a2[u] = cadd(b2, b3);
+                a3[u] = cmul(csub(b2, b3), w2[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (u == 0 || q0 + 64 * u < Q) {
+                    buf[lp(i0[u])] = a0[u];
+                    buf[lp(i0[u] + hm)] = a1[u];
+                    buf[lp(i0[u] + m)] = a2[u];
+                    buf[lp(i0[u] + m + hm)] = a3[u];
+                }
         }
         wave_sync();
         s -= 2;
     }
     if (s == 1) {
         for (int q = lane; q < Nc / 2; q += 64) {
-            const V a = buf[2 * q], b = buf[2 * q + 1];
-            buf[2 * q] = cadd(a, b);
-            buf[2 * q + 1] = csub(a, b);
+            const V a = buf[lp(2 * q)], b = buf[lp(2 * q + 1)];
+            buf[lp(2 * q)] = cadd(a, b);
+            buf[lp(2 * q + 1)] = csub(a, b);
         }
         wave_sync();
     }
@@ -140,33 +173,57 @@ __device__ void fft_dif(V *buf, const V *__restrict__ tw, int logn, int lane) {
 
 // Inverse network: bit-reversed order in, natural order out, conjugate twiddles, no scaling.
 template <typename V>
-__device__ void fft_dit_inv(V *buf, const V *__restrict__ tw, int logn, int lane) {
-    const int Nc = 1 << logn;
+__device__ void fft_dit_inv(V *buf, const V *tw, int logn, int lane) {
+    const int Nc = 1 << logn, Q = Nc >> 2;
+    constexpr int U = 4;
     int s = 1;
     if (logn & 1) {
         for (int q = lane; q < Nc / 2; q += 64) {
-            const V a = buf[2 * q], b = buf[2 * q + 1];
-            buf[2 * q] = cadd(a, b);
-            buf[2 * q + 1] = csub(a, b);
+            const V a = buf[lp(2 * q)], b = buf[lp(2 * q + 1)];
+            buf[lp(2 * q)] = cadd(a, b);
+            buf[lp(2 * q + 1)] = csub(a, b);
         }
         wave_sync();
         s = 2;
     }
     while (s + 1 <= logn) {
         const int m = 1 << (s - 1);
-        for (int q = lane; q < Nc / 4; q += 64) {
-            const int j = q & (m - 1);
-            const int i0 = ((q >> (s - 1)) << (s + 1)) + j;
-            const V a0 = buf[i0], a1 = buf[i0 + m], a2 = buf[i0 + 2 * m], a3 = buf[i0 + 3 * m];
-            const V w1 = tw[j * (Nc >> s)], w2 = tw[j * (Nc >> (s + 1))];
-            const V t1 = cmulc(a1, w1), t3 = cmulc(a3, w1);
-            const V b0 = cadd(a0, t1), b1 = csub(a0, t1), b2 = cadd(a2, t3), b3 = csub(a2, t3);
-            const V u2 = cmulc(b2, w2), v3 = cmulc(b3, w2);
-            const V u3 = V{-v3.y, v3.x};                          // * (+i)
-            buf[i0] = cadd(b0, u2);
-            buf[i0 + 2 * m] = csub(b0, u2);
-            buf[i0 + m] = cadd(b1, u3);
-            buf[i0 + 3 * m] = csub(b1, u3);
+#pragma unroll 1
+        for (int q0 = lane; q0 < Q; q0 += 64 * U) {
+            V a0[U], a1[U], a2[U], a3[U], w1[U], w2[U];
+            int i0[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int q = q0 + 64 * u < Q ? q0 + 64 * u : q0;
+                const int j = q & (m - 1);
+                i0[u] = ((q >> (s - 1)) << (s + 1)) + j;
+                a0[u] = buf[lp(i0[u])];
+                a1[u] = buf[lp(i0[u] + m)];
+                a2[u] = buf[lp(i0[u] + 2 * m)];
+                a3[u] = buf[lp(i0[u] + 3 * m)];
+                w1[u] = tw[j * (Nc >> s)];
+                w2[u] = tw[j * (Nc >> (s + 1))];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const V t1 = cmulc(a1[u], w1[u]), t3 = cmulc(a3[u], w1[u]);
+                const V b0 = cadd(a0[u], t1), b1 = csub(a0[u], t1), b2 = cadd(a2[u], t3), b3 = csub(a2[u], t3);
+                const V u2 = cmulc(b2, w2[u]), v3 = cmulc(b3, w2[u]);
+                const V u3 = V{-v3.y, v3.x};                          // * (+i)
+                a0[u] = cadd(b0, u2);
+                a2[u] = csub(b0, u2);
+                a1[u] = cadd(b1, u3);
+                a3[u] = csub(b1, u3);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (u == 0 || q0 + 64 * u < Q) {
+                    buf[lp(i0[u])] = a0[u];
+                    buf[lp(i0[u] + 2 * m)] = a2[u];
+                    buf[lp(i0[u] + m)] = a1[u];
+                    buf[lp(i0[u] + 3 * m)] = a3[u];
+                }
         }
         wave_sync();
         s += 2;
@@ -180,40 +237,87 @@ __device__ void wave_rfft_frame(V *buf, const T *__restrict__ x, int64_t n, int 
                                 const Tables<T> &tb, int hop, T scale, int lane) {
     const int Nc = tb.n_fft / 2, logc = tb.logc;
     const int64_t p0 = t * hop;
+    constexpr int LB = 8;                                    // loads in flight per lane and batch
+    const V *wv = reinterpret_cast<const V *>(tb.window);
     if (n_ch == 1 && p0 + tb.n_fft <= n && (reinterpret_cast<uintptr_t>(x + p0) % sizeof(V)) == 0) {
         const V *xv = reinterpret_cast<const V *>(x + p0);
-        const V *wv = reinterpret_cast<const V *>(tb.window);
-        for (int i = lane; i < Nc; i += 64) {
-            const V a = xv[i], w = wv[i];
-            buf[i] = V{a.x * w.x, a.y * w.y};
+#pragma unroll 1
+        for (int i0 = lane; i0 < Nc; i0 += 64 * LB) {
+            V a[LB], w[LB];
+#pragma unroll
+            for (int u = 0; u < LB; ++u) {
+                const int i = i0 + 64 * u < Nc ? i0 + 64 * u : i0;
+                a[u] = xv[i];
+                w[u] = wv[i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < LB; ++u)
+                if (u == 0 || i0 + 64 * u < Nc) buf[lp(i0 + 64 * u)] = V{a[u].x * w[u].x, a[u].y * w[u].y};
+        }
+    } else if (n_ch == 2 && p0 + tb.n_fft <= n && (reinterpret_cast<uintptr_t>(x + 2 * p0) % sizeof(V)) == 0) {
+        const V *xv = reinterpret_cast<const V *>(x + 2 * p0);   // (left, right) pairs
+#pragma unroll 1
+        for (int i0 = lane; i0 < Nc; i0 += 64 * LB) {
+            V a[LB], b[LB], w[LB];
+#pragma unroll
+            for (int u = 0; u < LB; ++u) {
+                const int i = i0 + 64 * u < Nc ? i0 + 64 * u : i0;
+                a[u] = xv[2 * i];
+                b[u] = xv[2 * i + 1];
+                w[u] = wv[i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < LB; ++u)
+                if (u == 0 || i0 + 64 * u < Nc)
+                    buf[lp(i0 + 64 * u)] = V{(a[u].x + a[u].y) / (T)2 * w[u].x, (b[u].x + b[u].y) / (T)2 * w[u].y};
         }
     } else {
         for (int i = lane; i < Nc; i += 64) {
             const T a = fold_sample(x, p0 + 2 * i, n, n_ch), b = fold_sample(x, p0 + 2 * i + 1, n, n_ch);
-            buf[i] = V{a * tb.window[2 * i], b * tb.window[2 * i + 1]};
+            buf[lp(i)] = V{a * tb.window[2 * i], b * tb.window[2 * i + 1]};
         }
     }
     wave_sync();
     fft_dif(buf, tb.tw, logc, lane);
-    // split the packed transform into the real-signal spectrum, in place (pairs k <-> Nc-k)
-    for (int k = lane; k <= Nc / 2; k += 64) {
-        if (k == 0) {
-            const V z = buf[0];
-            buf[0] = V{(z.x + z.y) * scale, (T)0};
-            buf[Nc] = V{(z.x - z.y) * scale, (T)0};
-        } else if (k == Nc / 2) {
-            const int pk = brev(k, logc);
-            const V z = buf[pk];
-            buf[pk] = V{z.x * scale, -z.y * scale};
-        } else {
-            const int pk = brev(k, logc), pm = brev(Nc - k, logc);
-            const V zk = buf[pk], zm = buf[pm], w = tb.rtw[k];
-            const V e = V{(zk.x + zm.x) * (T)0.5, (zk.y - zm.y) * (T)0.5};
-            const V o = V{(zk.y + zm.y) * (T)0.5, (zm.x - zk.x) * (T)0.5};   // -i/2 (zk - conj zm)
-            const V wo = cmul(w, o);
-            buf[pk] = V{(e.x + wo.x) * scale, (e.y + wo.y) * scale};
-            buf[pm] = V{(e.x - wo.x) * scale, -(e.y - wo.y) * scale};
+    // split the packed transform into the real-signal spectrum, in place (pairs k <-> Nc-k),
+    // four pairs per lane and batch; lane 0 then handles the two self-paired bins
+    constexpr int U = 4;
+#pragma unroll 1
+    for (int k0 = lane; k0 < Nc / 2; k0 += 64 * U) {
+        V zk[U], zm[U], w[U];
+        int pk[U], pm[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = k0 + 64 * u;
+            const int k = (kk > 0 && kk < Nc / 2) ? kk : 1;
+            pk[u] = lp(brev(k, logc));
+            pm[u] = lp(brev(Nc - k, logc));
+            zk[u] = buf[pk[u]];
+            zm[u] = buf[pm[u]];
+            w[u] = tb.rtw[k];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = k0 + 64 * u;
+            if (kk > 0 && kk < Nc / 2) {
+                const V e = V{(zk[u].x + zm[u].x) * (T)0.5, (zk[u].y - zm[u].y) * (T)0.5};
+                const V o = V{(zk[u].y + zm[u].y) * (T)0.5, (zm[u].x - zk[u].x) * (T)0.5};   // -i/2 (zk - conj zm)
+                const V wo = cmul(w[u], o);
+                buf[pk[u]] = V{(e.x + wo.x) * scale, (e.y + wo.y) * scale};
+                buf[pm[u]] = V{(e.x - wo.x) * scale, -(e.y - wo.y) * scale};
+            }
+        }
+    }
+    if (lane == 0) {
+        const V z = buf[0];
+        buf[0] = V{(z.x + z.y) * scale, (T)0};
+        buf[lp(Nc)] = V{(z.x - z.y) * scale, (T)0};
+        const int ph = lp(brev(Nc / 2, logc));
+        const V zh = buf[ph];
+        buf[ph] = V{zh.x * scale, -zh.y * scale};
     }
     wave_sync();
 }
@@ -223,23 +327,40 @@ __device__ void wave_rfft_frame(V *buf, const T *__restrict__ x, int64_t n, int 
 template <typename T, typename V>
 __device__ void wave_irfft_frame(V *buf, const Tables<T> &tb, int lane) {
     const int Nc = tb.n_fft / 2, logc = tb.logc;
-    for (int k = lane; k <= Nc / 2; k += 64) {
-        if (k == 0) {
-            const T a = buf[0].x, b = buf[Nc].x;          // imaginary parts are ignored (irfft)
-            buf[0] = V{(a + b) * (T)0.5, (a - b) * (T)0.5};
-        } else if (k == Nc / 2) {
-            const int pk = brev(k, logc);
-            const V z = buf[pk];
-            buf[pk] = V{z.x, -z.y};
-        } else {
-            const int pk = brev(k, logc), pm = brev(Nc - k, logc);
-            const V xk = buf[pk], xm = buf[pm], w = tb.rtw[k];
-            const V e = V{(xk.x + xm.x) * (T)0.5, (xk.y - xm.y) * (T)0.5};
-            const V d = V{(xk.x - xm.x) * (T)0.5, (xk.y + xm.y) * (T)0.5};   // (xk - conj xm)/2
-            const V o = cmulc(d, w);                                       // conj(w) * d
-            buf[pk] = V{e.x - o.y, e.y + o.x};                             // e + i o
-            buf[pm] = V{e.x + o.y, -(e.y - o.x)};                          // conj(e - i o)
+    constexpr int U = 4;
+#pragma unroll 1
+    for (int k0 = lane; k0 < Nc / 2; k0 += 64 * U) {
+        V xk[U], xm[U], w[U];
+        int pk[U], pm[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = k0 + 64 * u;
+            const int k = (kk > 0 && kk < Nc / 2) ? kk : 1;
+            pk[u] = lp(brev(k, logc));
+            pm[u] = lp(brev(Nc - k, logc));
+            xk[u] = buf[pk[u]];
+            xm[u] = buf[pm[u]];
+            w[u] = tb.rtw[k];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = k0 + 64 * u;
+            if (kk > 0 && kk < Nc / 2) {
+                const V e = V{(xk[u].x + xm[u].x) * (T)0.5, (xk[u].y - xm[u].y) * (T)0.5};
+                const V d = V{(xk[u].x - xm[u].x) * (T)0.5, (xk[u].y + xm[u].y) * (T)0.5};   // (xk - conj xm)/2
+                const V o = cmulc(d, w[u]);                                      // conj(w) * d
+                buf[pk[u]] = V{e.x - o.y, e.y + o.x};                            // e + i o
+                buf[pm[u]] = V{e.x + o.y, -(e.y - o.x)};                         // conj(e - i o)
+            }
+        }
+    }
+    if (lane == 0) {
+        const T a = buf[0].x, b = buf[lp(Nc)].x;              // imaginary parts are ignored (irfft)
+        buf[0] = V{(a + b) * (T)0.5, (a - b) * (T)0.5};
+        const int ph = lp(brev(Nc / 2, logc));
+        const V z = buf[ph];
+        buf[ph] = V{z.x, -z.y};
     }
     wave_sync();
     fft_dit_inv(buf, tb.tw, logc, lane);
@@ -258,7 +379,7 @@ __global__ __launch_bounds__(W * 64) void k_stft_rows(const T *__restrict__ x, S
     using V = typename Vec2<T>::type;
     extern __shared__ __align__(16) unsigned char smem[];
     const int Nc = tb.n_fft / 2, F = Nc + 1, logc = tb.logc;
-    const int bstride = Nc + 2;
+    const int bstride = lp_size(Nc);
     V *bufs = reinterpret_cast<V *>(smem);
     T *tile = reinterpret_cast<T *>(bufs + (size_t)W * bstride);       // [F][ROW_FT + 1]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -277,7 +398,7 @@ __global__ __launch_bounds__(W * 64) void k_stft_rows(const T *__restrict__ x, S
         if (t < Tn) {
             wave_rfft_frame<T, V>(buf, xs, n, sg.n_ch, t, tb, sg.hop, scale, lane);
             for (int k = lane; k <= Nc; k += 64) {
-                const V z = buf[k == Nc ? Nc : brev(k, logc)];
+                const V z = buf[lp(k == Nc ? Nc : brev(k, logc))];
                 const T p2 = z.x * z.x + z.y * z.y;
                 const T v = power ? p2 : sqrt(p2);
                 tile[k * (ROW_FT + 1) + ft] = v;
@@ -468,7 +589,20 @@ __global__ __launch_bounds__(256) void k_wiener_gain(const double *__restrict__ 
     for (int k = threadIdx.x; k < F; k += 256) gain[sig * F + k] = (T)medfilt_at(g, F, k, ksz);
 }
 
+// 1 / sqrt(x) for x > 0 to within a few ulp: hardware estimate (about 2^-26 relative) refined by
+// two Newton steps; replaces the far longer correctly rounded sqrt and division sequences in the
+// per-bin magnitude arithmetic of the binary64 kernels.  x = 0 gives +inf (callers select).
+__device__ __forceinline__ double inv_sqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    r = r * (1.5 - hx * r * r);
+    r = r * (1.5 - hx * r * r);
+    return r;
+}
+__device__ __forceinline__ float inv_sqrt(float x) { return 1.0f / sqrtf(x); }
+
 // ---------------------------------------- fused STFT -> modify -> ISTFT overlap-add
+static constexpr int MAG_PAD = 16;     // replicated bins kept beyond both ends of a magnitude row (box <= 33 bins)
 template <typename T, int W, int MODE>
 __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
     using V = typename Vec2<T>::type;
@@ -477,10 +611,12 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
     const int N = tb.n_fft, Nc = N / 2, F = Nc + 1, logc = tb.logc;
     const int H = a.sg.hop, R = N / H;
     const int RING = W + R;
-    const int bstride = Nc + 2, mstride = F + 1;
+    const int bstride = lp_size(Nc), mstride = F + 1 + 2 * MAG_PAD;
     V *bufs = reinterpret_cast<V *>(smem);
-    T *mags = reinterpret_cast<T *>(bufs + (size_t)W * bstride);          // [W][mstride]
-    T *acc = mags + (MODE == APPLY_SUBTRACT ? (size_t)W * mstride : 0);   // [RING][H]
+    // [W][mstride]: row w holds bins 0..Nc at offset MAG_PAD, with replicated edge bins on both sides
+    T *mags = reinterpret_cast<T *>(bufs + (size_t)W * bstride) + MAG_PAD;
+    T *acc = mags - MAG_PAD + (MODE == APPLY_SUBTRACT ? (size_t)W * mstride : 0);   // [RING][H]
+    T *wsq = acc + (size_t)RING * H;                                      // [H] norm of a fully overlapped hop
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
     const int64_t sig = blockIdx.x / a.segs_per_sig, seg = blockIdx.x % a.segs_per_sig;
     const int64_t n = a.sg.len[sig];
@@ -505,6 +641,14 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
     V *buf = bufs + (size_t)wave * bstride;
 
     for (int i = tid; i < RING * H; i += W * 64) acc[i] = 0;
+    for (int i = tid; i < H; i += W * 64) {
+        T norm = 0;
+        for (int r = R - 1; r >= 0; --r) {                 // same order as the edge loop below
+            const T w = tb.window[r * H + i];
+            norm += w * w;
+        }
+        wsq[i] = norm;
+    }
     __syncthreads();
 
     while (next_u <= last_u) {
@@ -514,16 +658,56 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
         int64_t a_last = last_u + hr;
         a_last = a_last > Tn - 1 ? Tn - 1 : a_last;
         // ---- stage A: spectrum of frame t (and its clean magnitudes)
-        if (t <= a_last) {
+        if (t <= a_last && !(a.ablate & 1)) {
             wave_rfft_frame<T, V>(buf, xs, n, a.sg.n_ch, t, tb, H, fscale, lane);
-            if (MODE == APPLY_SUBTRACT) {
+            if (MODE == APPLY_SUBTRACT && !(a.ablate & 32)) {
+                // clean magnitudes of the frame, then their box mean along frequency (edge
+                // replicated), in place: every lane reads the neighbourhoods of its bins before any
+                // lane overwrites a bin.  The time mean over the neighbouring frames follows in
+                // stage B, in the same order as the two 1-D passes of scipy's uniform_filter.
                 T *mrow = mags + (size_t)wave * mstride;
                 for (int k = lane; k <= Nc; k += 64) {
-                    const V z = buf[k == Nc ? Nc : brev(k, logc)];
-                    const T mag = sqrt(z.x * z.x + z.y * z.y);
+                    const V z = buf[lp(k == Nc ? Nc : brev(k, logc))];
+                    const T p2 = z.x * z.x + z.y * z.y;
+                    const T mag = p2 > (T)0 ? p2 * inv_sqrt(p2) : (T)0;
                     const T c1 = mag - a.alpha * row[k], c2 = a.beta * mag;
                     mrow[k] = c1 > c2 ? c1 : c2;
                 }
+                const int fl = a.sf / 2, fr = a.sf - fl - 1;
+                wave_sync();
+                if (lane < MAG_PAD) {                            // edge replication
+                    mrow[-1 - lane] = mrow[0];
+                    mrow[Nc + 1 + lane] = mrow[Nc];
+                }
+                wave_sync();
+                const T inv_sf = (T)1 / (T)a.sf;
+                constexpr int KB = 33;                           // bins per lane: ceil((4096 / 2 + 1) / 64)
+                T box[KB];
+                if (a.sf == 5) {                                 // the reference's box: all reads in flight together
+#pragma unroll
+                    for (int u = 0; u < KB; ++u) {
+                        const int k = lane + 64 * u;
+                        T fs = 0;
+                        if (k <= Nc) {
+                            const T v0 = mrow[k - 2], v1 = mrow[k - 1], v2 = mrow[k], v3 = mrow[k + 1], v4 = mrow[k + 2];
+                            fs = (((((T)0 + v0) + v1) + v2) + v3) + v4;
+                        }
+                        box[u] = fs * inv_sf;
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < KB; ++u) {
+                        const int k = lane + 64 * u;
+                        T fs = 0;
+                        if (k <= Nc)
+                            for (int df = -fl; df <= fr; ++df) fs += mrow[k + df];
+                        box[u] = fs * inv_sf;
+                    }
+                }
+                wave_sync();
+#pragma unroll
+                for (int u = 0; u < KB; ++u)
+                    if (lane + 64 * u <= Nc) mrow[lane + 64 * u] = box[u];
             }
         }
         __syncthreads();
@@ -533,34 +717,28 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
         if (base + W - 1 >= Tn - 1) ue = Tn - 1;           // the right neighbours are clamped at Tn-1
         ue = ue > last_u ? last_u : ue;
         // ---- stage B: modify the spectrum, inverse transform
-        if (t >= ub && t <= ue) {
-            if (MODE == APPLY_SUBTRACT) {
-                const T inv_sf = (T)1 / (T)a.sf, inv_st = (T)1 / (T)a.st;
-                const int fl = a.sf / 2, fr = a.sf - fl - 1;
+        if (t >= ub && t <= ue && !(a.ablate & 2)) {
+            if (a.ablate & 64) {
+            } else if (MODE == APPLY_SUBTRACT) {
+                const T inv_st = (T)1 / (T)a.st;
                 for (int k = lane; k <= Nc; k += 64) {
                     T tsum = 0;
                     for (int dt = -h; dt <= hr; ++dt) {
                         int64_t tt = t + dt;
                         tt = tt < 0 ? 0 : (tt > Tn - 1 ? Tn - 1 : tt);
-                        const T *mrow = mags + (size_t)(tt - base) * mstride;
-                        T fs = 0;
-                        for (int df = -fl; df <= fr; ++df) {
-                            int kk = k + df;
-                            kk = kk < 0 ? 0 : (kk > Nc ? Nc : kk);
-                            fs += mrow[kk];
-                        }
-                        tsum += fs * inv_sf;
+                        tsum += mags[(size_t)(tt - base) * mstride + k];
                     }
                     const T sm = tsum * inv_st;
-                    const int pk = k == Nc ? Nc : brev(k, logc);
+                    const int pk = lp(k == Nc ? Nc : brev(k, logc));
                     const V z = buf[pk];
-                    const T mag = sqrt(z.x * z.x + z.y * z.y);
-                    // clean * exp(i*angle(Z)); angle(0) = 0
-                    buf[pk] = mag > (T)0 ? V{sm * (z.x / mag), sm * (z.y / mag)} : V{sm, (T)0};
+                    const T p2 = z.x * z.x + z.y * z.y;
+                    // clean * exp(i*angle(Z)) = clean * Z / |Z|; angle(0) = 0
+                    const T g = sm * inv_sqrt(p2);
+                    buf[pk] = p2 > (T)0 ? V{z.x * g, z.y * g} : V{sm, (T)0};
                 }
             } else {
                 for (int k = lane; k <= Nc; k += 64) {
-                    const int pk = k == Nc ? Nc : brev(k, logc);
+                    const int pk = lp(k == Nc ? Nc : brev(k, logc));
                     const V z = buf[pk];
                     const T gk = row[k + (int64_t)t * a.row_t_stride];
                     buf[pk] = V{z.x * gk, z.y * gk};
@@ -571,40 +749,49 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
         }
         __syncthreads();
         // ---- overlap-add of frames [ub, ue] into padded hops [ub, ue + R - 1]
-        if (ue >= ub) {
+        if (ue >= ub && !(a.ablate & 4)) {
             const bool final_group = (ue == Tn - 1);
-            const int64_t nj = ue - ub + R;
-            for (int64_t idx = tid; idx < nj * H; idx += W * 64) {
-                const int64_t j = ub + idx / H;
-                const int i = (int)(idx % H);
-                T *slot = acc + (size_t)(j % RING) * H + i;
+            const int nj = (int)(ue - ub) + R;              // hops touched, < RING
+            const int LOGH = 31 - __clz(H);                 // the hop is a power of two
+            const int slot0 = (int)(ub % RING);
+            const T *frames = reinterpret_cast<const T *>(bufs) + (size_t)(ub - base) * (2 * bstride);
+#pragma unroll 1
+            for (int idx = tid; idx < (nj << LOGH); idx += W * 64) {
+                const int jj = idx >> LOGH, i = idx & (H - 1);
+                const int64_t j = ub + jj;
+                int sl = slot0 + jj;
+                sl = sl >= RING ? sl - RING : sl;
+                T *slot = acc + ((size_t)sl << LOGH) + i;
                 T v = *slot;
-                int64_t u_lo = j - R + 1;
-                u_lo = u_lo < ub ? ub : u_lo;
-                const int64_t u_hi = j < ue ? j : ue;
-                for (int64_t u = u_lo; u <= u_hi; ++u) {
-                    const int pos = (int)(j - u) * H + i;
-                    const T *fr = reinterpret_cast<const T *>(bufs + (size_t)(u - base) * bstride);
-                    v += fr[pos] * iscale * tb.window[pos];
+                // frames ub + f, f in [f_lo, f_hi], overlap hop j
+                const int f_lo = jj - R + 1 > 0 ? jj - R + 1 : 0;
+                const int f_hi = jj < (int)(ue - ub) ? jj : (int)(ue - ub);
+                for (int f = f_lo; f <= f_hi; ++f) {
+                    const int pos = ((jj - f) << LOGH) + i;
+                    v += frames[(size_t)f * (2 * bstride) + 2 * lp(pos >> 1) + (pos & 1)] * iscale * tb.window[pos];
                 }
                 if (j <= ue || final_group) {
                     if (j >= ph0 && j < ph1) {
-                        T norm = 0;
-                        int64_t t_lo = j - R + 1;
-                        t_lo = t_lo < 0 ? 0 : t_lo;
-                        const int64_t t_hi = j < Tn - 1 ? j : Tn - 1;
-                        for (int64_t tt = t_lo; tt <= t_hi; ++tt) {
-                            const T w = tb.window[(int)(j - tt) * H + i];
-                            norm += w * w;
+                        T norm = wsq[i];
+                        if (j - R + 1 < 0 || j > Tn - 1) {            // first / last hops: fewer frames overlap
+                            norm = 0;
+                            int64_t t_lo = j - R + 1;
+                            t_lo = t_lo < 0 ? 0 : t_lo;
+                            const int64_t t_hi = j < Tn - 1 ? j : Tn - 1;
+                            for (int64_t tt = t_lo; tt <= t_hi; ++tt) {
+                                const T w = tb.window[((int)(j - tt) << LOGH) + i];
+                                norm += w * w;
+                            }
                         }
                         T o = v / (norm > (T)1e-10 ? norm : (T)1);
                         if (!a.no_clip) o = o < (T)-1 ? (T)-1 : (o > (T)1 ? (T)1 : o);      // np.clip keeps NaN
+                        const int64_t yo = ((j - R / 2) << LOGH) + i;
                         if (ps) {
                             const int k = pcm_int32(o) >> 16;
-                            ps[(j - R / 2) * H + i] = (int16_t)k;
+                            ps[yo] = (int16_t)k;
                             o = (T)k * (T)(1.0 / 32768.0);
                         }
-                        ys[(j - R / 2) * H + i] = o;
+                        ys[yo] = o;
                     }
                     *slot = 0;
                 } else {
@@ -635,7 +822,7 @@ static int launch_rows(Ctx *c, const T *d_x, const Signals &sg, const Tables<T> 
                        int ROW_FT, int64_t Tmax, int power, T *S, unsigned long long *sig_max) {
     using V = typename Vec2<T>::type;
     const int Nc = tb.n_fft / 2;
-    const size_t lds = (size_t)W * (Nc + 2) * sizeof(V) + (size_t)(Nc + 1) * (ROW_FT + 1) * sizeof(T);
+    const size_t lds = (size_t)W * lp_size(Nc) * sizeof(V) + (size_t)(Nc + 1) * (ROW_FT + 1) * sizeof(T);
     const int64_t groups = ceil_div(Tmax, ROW_FT);
     auto kern = k_stft_rows<T, W>;
     ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -658,7 +845,7 @@ static int rows_dispatch(Ctx *c, const T *d_x, const Signals &sg, const Tables<T
     if constexpr (std::is_same<T, float>::value) {
         if (tb.n_fft == 2048 && !c->force_generic) return rows_fast(c, d_x, sg, tb, n_sig, Tmax, power, S, sig_max);
     }
-    const size_t per_wave = (size_t)(Nc + 2) * sizeof(V);
+    const size_t per_wave = (size_t)lp_size(Nc) * sizeof(V);
     // widest transposed tile (frames per workgroup) and most waves that fit the CU's LDS
     for (int ft = 16; ft >= 2; ft >>= 1) {
         const size_t tile = (size_t)(Nc + 1) * (ft + 1) * sizeof(T);
@@ -675,9 +862,9 @@ template <typename T, int W, int MODE>
 static int launch_apply(Ctx *c, ApplyArgs<T> a, int64_t n_sig, int64_t Tmax) {
     using V = typename Vec2<T>::type;
     const int N = a.tb.n_fft, Nc = N / 2, R = N / a.sg.hop;
-    const size_t lds = (size_t)W * (Nc + 2) * sizeof(V) +
-                       (MODE == APPLY_SUBTRACT ? (size_t)W * (Nc + 2) * sizeof(T) : 0) +
-                       (size_t)(W + R) * a.sg.hop * sizeof(T);
+    const size_t lds = (size_t)W * lp_size(Nc) * sizeof(V) +
+                       (MODE == APPLY_SUBTRACT ? (size_t)W * (Nc + 2 + 2 * MAG_PAD) * sizeof(T) : 0) +
+                       (size_t)(W + R + 1) * a.sg.hop * sizeof(T);
     const int64_t out_hops = Tmax - 1;
     if (out_hops <= 0) return ADN_OK;
     // enough workgroups to fill the chip several times, but long enough segments to
@@ -686,6 +873,7 @@ static int launch_apply(Ctx *c, ApplyArgs<T> a, int64_t n_sig, int64_t Tmax) {
     seg = seg < 16 ? 16 : (seg > 128 ? 128 : seg);
     a.seg_hops = (int)seg;
     a.segs_per_sig = ceil_div(out_hops, seg);
+    a.ablate = c->ablate;
     auto kern = k_stft_apply<T, W, MODE>;
     ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -699,8 +887,9 @@ static int apply_dispatch(Ctx *c, const ApplyArgs<T> &a, int64_t n_sig, int64_t 
     using V = typename Vec2<T>::type;
     const int N = a.tb.n_fft, Nc = N / 2, R = N / a.sg.hop;
     auto need = [&](int W) {
-        return (size_t)W * (Nc + 2) * sizeof(V) + (MODE == APPLY_SUBTRACT ? (size_t)W * (Nc + 2) * sizeof(T) : 0) +
-               (size_t)(W + R) * a.sg.hop * sizeof(T);
+        return (size_t)W * lp_size(Nc) * sizeof(V) +
+               (MODE == APPLY_SUBTRACT ? (size_t)W * (Nc + 2 + 2 * MAG_PAD) * sizeof(T) : 0) +
+               (size_t)(W + R + 1) * a.sg.hop * sizeof(T);
     };
     const int min_w = MODE == APPLY_SUBTRACT ? a.st : 1;
     if constexpr (std::is_same<T, float>::value) {
@@ -708,9 +897,9 @@ static int apply_dispatch(Ctx *c, const ApplyArgs<T> &a, int64_t n_sig, int64_t 
         const bool st_ok = MODE == APPLY_GAIN || a.st == 3;
         if (!c->force_generic && st_ok && apply_fast_ok(N, a.sg.hop, a.st, a.sf)) return apply_fast<MODE>(c, a, n_sig, Tmax);
     }
-    if (need(8) <= 156 * 1024) return launch_apply<T, 8, MODE>(c, a, n_sig, Tmax);
-    if (need(4) <= 156 * 1024 && min_w <= 4) return launch_apply<T, 4, MODE>(c, a, n_sig, Tmax);
-    if (need(2) <= 156 * 1024 && min_w <= 2) return launch_apply<T, 2, MODE>(c, a, n_sig, Tmax);
+    if (need(8) <= 160 * 1024) return launch_apply<T, 8, MODE>(c, a, n_sig, Tmax);
+    if (need(4) <= 160 * 1024 && min_w <= 4) return launch_apply<T, 4, MODE>(c, a, n_sig, Tmax);
+    if (need(2) <= 160 * 1024 && min_w <= 2) return launch_apply<T, 2, MODE>(c, a, n_sig, Tmax);
     set_error("n_fft=%d hop=%d smoothing=%d does not fit the 160 KB LDS of a CU", N, a.sg.hop, a.st);
     return ADN_ERR_UNSUPPORTED;
 }
@@ -769,7 +958,8 @@ int spectral_subtract(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off,
                       int smooth_time, int smooth_freq, T *d_y, const int64_t *d_y_off, int16_t *d_pcm16) {
     ADN_REQUIRE(c && d_x && d_off && d_len && d_noise && d_y && d_y_off, "null pointer argument");
     ADN_TRY(check_stft_args(n_fft, hop, n_ch));
-    ADN_REQUIRE(smooth_time >= 1 && smooth_time <= 7 && smooth_freq >= 1, "smoothing sizes out of range");
+    ADN_REQUIRE(smooth_time >= 1 && smooth_time <= 7 && smooth_freq >= 1 && smooth_freq <= 33,
+                "smoothing sizes out of range (time 1..7, frequency 1..33)");
     if (n_sig <= 0) return ADN_OK;
     if (max_len < n_fft) {
         set_error("window is longer than input signal (n_fft=%d, longest signal=%lld)", n_fft, (long long)max_len);

@@ -769,7 +769,7 @@ int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
     if (out_hops <= 0) return ADN_OK;
     const size_t lds = fast::apply_lds(W, MODE, a.sg.hop);
     int64_t seg = ceil_div(n_sig * out_hops, (int64_t)c->num_cus * 8);
-    seg = seg < 24 ? 24 : (seg > 96 ? 96 : seg);
+    seg = seg < 24 ? 24 : (seg > 192 ? 192 : seg);
     a.seg_hops = (int)seg;
     a.segs_per_sig = ceil_div(out_hops, seg);
     a.ablate = c->ablate;
