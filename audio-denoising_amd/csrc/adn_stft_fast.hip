@@ -22,6 +22,7 @@ static constexpr int RS = 68;       // exchange row stride (float2): 64 + 4 keep
 static constexpr int WBUF = 1088;   // float2 per wave buffer: 16 * RS >= padded natural image + 1
 static constexpr int MROW = 1032;   // floats per magnitude row (1025 used)
 static constexpr int FAST_ST = 3;   // time-smoothing frames this specialisation is built for
+static constexpr int PARK = 1026;   // float2 slots of a parked spectrum (1025 used)
 static constexpr int RAWPAD = 8;    // replicated bins kept beyond each end of a raw magnitude row
 
 __device__ __forceinline__ int nat(int k) { return k + ((k >> 8) << 3); }        // float2 index
@@ -349,9 +350,13 @@ __global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ 
 
 // ------------------------------------ fused STFT -> modify -> ISTFT overlap-add
 // Workgroup = W waves sliding along one segment of one signal.  Per iteration the waves
-// transform W consecutive frames (stage A), the frames whose time-smoothing neighbours are
-// all present are modified and inverse-transformed (stage B), and all threads overlap-add
-// the finished frames into a ring of hop accumulators, emitting the hops that are complete.
+// transform W NEW consecutive frames (stage A), every wave then modifies and inverse-transforms
+// one frame (stage B), and all threads overlap-add the finished frames into a ring of hop
+// accumulators, emitting the hops that are complete.
+// SUBTRACT mode smooths over the two neighbouring frames: the smoothed-magnitude rows live in a
+// ring of W + 2 rows that survives the iteration, and the last frame of an iteration, whose right
+// neighbour does not exist yet, has its spectrum parked in LDS; the last wave synthesises the
+// frame parked by the previous iteration instead.  No frame is transformed twice inside a segment.
 template <int W, int MODE, bool PROF>
 __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -360,7 +365,9 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
     const int RING = W + R;
     c2 *bufs = reinterpret_cast<c2 *>(smem);
     float *mags = reinterpret_cast<float *>(bufs + (size_t)W * WBUF);                 // [W][MROW]
-    float *acc = mags + (MODE == APPLY_SUBTRACT ? (size_t)W * MROW : 0);              // [RING][H]
+    constexpr int MR = W + 2;                                                         // magnitude rows kept
+    c2 *park = reinterpret_cast<c2 *>(mags + (MODE == APPLY_SUBTRACT ? (size_t)MR * MROW : 0));   // [PARK] SUBTRACT only
+    float *acc = reinterpret_cast<float *>(park + (MODE == APPLY_SUBTRACT ? PARK : 0));            // [RING][H]
     float *wsq = acc + (size_t)RING * H;                                              // [H] full-overlap norm
     c2 *twtab = reinterpret_cast<c2 *>(wsq + H);
     // the window lives in LDS (analysis and synthesis reads)
@@ -413,6 +420,10 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
 
     unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     constexpr bool prof = PROF;
+    // first new frame of the iteration; later iterations continue where the analysis stopped
+    int base = next_u - h;
+    base = base < 0 ? 0 : base;
+    int park_t = -1;                                       // frame whose spectrum is parked (last wave only)
 #pragma unroll 1
     while (next_u <= last_u) {
         unsigned long long tk = prof ? clock64() : 0;
@@ -423,9 +434,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                 tk = now;
             }
         };
-        int base = next_u - h;
-        base = base < 0 ? 0 : base;
-        const int t = base + wave;
+        int t = base + wave;
         int a_last = last_u + hr;
         a_last = a_last > Tn - 1 ? Tn - 1 : a_last;
         Spec s;
@@ -467,7 +476,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                 }
                 wave_sync();
                 // box mean along frequency -> shared row of this frame
-                float *mrow = mags + wave * MROW;
+                float *mrow = mags + (t % MR) * MROW;
                 const float inv_sf = 1.0f / (float)a.sf;
                 if (a.sf == 5) {
                     // the reference's box (smooth_freq = 5): all reads of a group of bins are
@@ -507,9 +516,31 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
         if (MODE == APPLY_SUBTRACT) lds_barrier();
         tick(1);
         const int ub = next_u;
+        // SUBTRACT: frames up to base + W - 2 have their right neighbour; the last wave's own frame
+        // is always parked and synthesised one iteration later
         int ue = base + W - 1 - hr;
-        if (base + W - 1 >= Tn - 1) ue = Tn - 1;
+        if (MODE == APPLY_GAIN && base + W - 1 >= Tn - 1) ue = Tn - 1;
         ue = ue > last_u ? last_u : ue;
+        if (MODE == APPLY_SUBTRACT && wave == W - 1) {
+            // swap the own spectrum (if any) with the parked one
+            const int own_t = t <= a_last ? t : -1;
+            if (park_t >= 0 || own_t >= 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const c2 plo = park[j * 64 + lane], phi = park[(8 + j) * 64 + lane];
+                    park[j * 64 + lane] = s.lo[j];
+                    park[(8 + j) * 64 + lane] = s.hi[j];
+                    s.lo[j] = plo;
+                    s.hi[j] = phi;
+                }
+                const c2 pm = park[1024];
+                wave_sync();
+                if (lane == 0) park[1024] = s.mid;
+                s.mid = pm;
+            }
+            t = park_t;                                    // -1: nothing to synthesise
+            park_t = own_t;
+        }
         // ---- stage B: modify, inverse transform, window
         if (t >= ub && t <= ue && !(a.ablate & 2)) {
             if (MODE == APPLY_SUBTRACT) {
@@ -520,7 +551,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                 for (int i = 0; i < FAST_ST; ++i) {
                     int tt = t - h + i;
                     tt = tt < 0 ? 0 : (tt > Tn - 1 ? Tn - 1 : tt);
-                    rows[i] = mags + (tt - base) * MROW;
+                    rows[i] = mags + (tt % MR) * MROW;
                 }
                 auto smooth = [&](int k) {
                     float ts = 0.0f;
@@ -594,7 +625,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                 for (int qq = 0; qq < 4; ++qq) {
                     const int u = j - qq;
                     ok[qq] = qq < r_eff && u >= ub && u <= ue;
-                    c[qq] = fbase[(ok[qq] ? u - base : 0) * (2 * WBUF) + off[qq]];
+                    c[qq] = fbase[(ok[qq] ? (u - base) & (W - 1) : 0) * (2 * WBUF) + off[qq]];
                 }
 #pragma unroll
                 for (int qq = 3; qq >= 0; --qq) v += ok[qq] ? c[qq] : 0.0f;
@@ -657,7 +688,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                     for (int qq = 0; qq < 4; ++qq) {
                         const int u = j - qq;
                         ok[qq] = u >= ub && u <= ue;
-                        c[qq] = *reinterpret_cast<const float4 *>(fbase + (ok[qq] ? u - base : 0) * (2 * WBUF) + off[qq]);
+                        c[qq] = *reinterpret_cast<const float4 *>(fbase + (ok[qq] ? (u - base) & (W - 1) : 0) * (2 * WBUF) + off[qq]);
                     }
 #pragma unroll
                     for (int qq = 3; qq >= 0; --qq) {          // oldest frame first
@@ -736,7 +767,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                     float *slot = acc + (j % RING) * H + i;
                     for (int qq = R - 1; qq >= 4; --qq) {
                         const int u = j - qq;
-                        if (u >= ub && u <= ue) *slot += fbase[(u - base) * (2 * WBUF) + natf((qq << LOGH) + i)];
+                        if (u >= ub && u <= ue) *slot += fbase[((u - base) & (W - 1)) * (2 * WBUF) + natf((qq << LOGH) + i)];
                     }
                     hop_sample(j, i, slot, off, R < 4 ? R : 4, wsq[i]);
                 }
@@ -746,6 +777,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
         lds_barrier();
         tick(5);
         next_u = ue + 1;
+        base = MODE == APPLY_SUBTRACT ? base + W : next_u;
     }
     if (prof && tid == 0)
         for (int i = 0; i < 12; ++i) atomicAdd(&a.dbg[i], ph[i]);
@@ -753,7 +785,8 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
 
 static size_t apply_lds(int W, int mode, int hop) {
     const int R = 2048 / hop;
-    return (size_t)W * WBUF * sizeof(c2) + (mode == APPLY_SUBTRACT ? (size_t)W * MROW * sizeof(float) : 0) +
+    return (size_t)W * WBUF * sizeof(c2) +
+           (mode == APPLY_SUBTRACT ? (size_t)(W + 2) * MROW * sizeof(float) + (size_t)PARK * sizeof(c2) : 0) +
            (size_t)(W + R) * hop * sizeof(float) + (size_t)hop * sizeof(float) + (size_t)TWTAB * sizeof(c2) +
            2048 * sizeof(float);
 }
