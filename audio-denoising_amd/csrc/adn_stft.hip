@@ -612,10 +612,17 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
     const int H = a.sg.hop, R = N / H;
     const int RING = W + R;
     const int bstride = lp_size(Nc), mstride = F + 1 + 2 * MAG_PAD;
-    V *bufs = reinterpret_cast<V *>(smem);
-    // [W][mstride]: row w holds bins 0..Nc at offset MAG_PAD, with replicated edge bins on both sides
-    T *mags = reinterpret_cast<T *>(bufs + (size_t)W * bstride) + MAG_PAD;
-    T *acc = mags - MAG_PAD + (MODE == APPLY_SUBTRACT ? (size_t)W * mstride : 0);   // [RING][H]
+    const int h = MODE == APPLY_SUBTRACT ? a.st / 2 : 0;
+    const int hr = MODE == APPLY_SUBTRACT ? a.st - h - 1 : 0;
+    // Frame t lives in buffer t % NB and its smoothed magnitudes in row t % MR.  An iteration
+    // transforms W new frames; the hr newest ones wait (parked in their buffers) for their right
+    // neighbours and are synthesised by the next iteration, so that every iteration after the
+    // first synthesises W frames and no frame is transformed twice inside a segment.
+    const int NB = W + hr, MR = W + h + hr;
+    V *bufs = reinterpret_cast<V *>(smem);                                // [NB][bstride]
+    // [MR][mstride]: a row holds bins 0..Nc at offset MAG_PAD, with replicated edge bins on both sides
+    T *mags = reinterpret_cast<T *>(bufs + (size_t)NB * bstride) + MAG_PAD;
+    T *acc = mags - MAG_PAD + (MODE == APPLY_SUBTRACT ? (size_t)MR * mstride : 0);   // [RING][H]
     T *wsq = acc + (size_t)RING * H;                                      // [H] norm of a fully overlapped hop
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
     const int64_t sig = blockIdx.x / a.segs_per_sig, seg = blockIdx.x % a.segs_per_sig;
@@ -630,15 +637,12 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
     int64_t next_u = ph0 - R + 1;
     next_u = next_u < 0 ? 0 : next_u;
     const int64_t last_u = (ph1 - 1 < Tn - 1) ? ph1 - 1 : Tn - 1;
-    const int h = MODE == APPLY_SUBTRACT ? a.st / 2 : 0;
-    const int hr = MODE == APPLY_SUBTRACT ? a.st - h - 1 : 0;
     const T *xs = a.x + a.sg.off[sig];
     T *ys = a.y + a.y_off[sig];
     int16_t *ps = a.pcm ? a.pcm + a.y_off[sig] : nullptr;
     const T *row = a.row + sig * a.row_stride;
     const T fscale = (T)(1.0 / tb.wsum);
     const T iscale = (T)(tb.wsum / (double)Nc);
-    V *buf = bufs + (size_t)wave * bstride;
 
     for (int i = tid; i < RING * H; i += W * 64) acc[i] = 0;
     for (int i = tid; i < H; i += W * 64) {
@@ -651,21 +655,22 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
     }
     __syncthreads();
 
+    int64_t base = next_u - h;                              // first new frame of the iteration
+    base = base < 0 ? 0 : base;
     while (next_u <= last_u) {
-        int64_t base = next_u - h;
-        base = base < 0 ? 0 : base;
-        const int64_t t = base + wave;
+        const int64_t ta = base + wave;
         int64_t a_last = last_u + hr;
         a_last = a_last > Tn - 1 ? Tn - 1 : a_last;
-        // ---- stage A: spectrum of frame t (and its clean magnitudes)
-        if (t <= a_last && !(a.ablate & 1)) {
-            wave_rfft_frame<T, V>(buf, xs, n, a.sg.n_ch, t, tb, H, fscale, lane);
+        // ---- stage A: spectrum of frame ta (and its clean magnitudes)
+        if (ta <= a_last && !(a.ablate & 1)) {
+            V *buf = bufs + (size_t)(ta % NB) * bstride;
+            wave_rfft_frame<T, V>(buf, xs, n, a.sg.n_ch, ta, tb, H, fscale, lane);
             if (MODE == APPLY_SUBTRACT && !(a.ablate & 32)) {
                 // clean magnitudes of the frame, then their box mean along frequency (edge
                 // replicated), in place: every lane reads the neighbourhoods of its bins before any
                 // lane overwrites a bin.  The time mean over the neighbouring frames follows in
                 // stage B, in the same order as the two 1-D passes of scipy's uniform_filter.
-                T *mrow = mags + (size_t)wave * mstride;
+                T *mrow = mags + (size_t)(ta % MR) * mstride;
                 for (int k = lane; k <= Nc; k += 64) {
                     const V z = buf[lp(k == Nc ? Nc : brev(k, logc))];
                     const T p2 = z.x * z.x + z.y * z.y;
@@ -711,13 +716,15 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
             }
         }
         __syncthreads();
-        // ---- frames [ub, ue] of this group can be finalised
+        // ---- frames [ub, ue] can be finalised: all their right neighbours have been transformed
+        // (ends of the signal: the neighbours are clamped to its first / last frame)
         const int64_t ub = next_u;
         int64_t ue = base + W - 1 - hr;
-        if (base + W - 1 >= Tn - 1) ue = Tn - 1;           // the right neighbours are clamped at Tn-1
         ue = ue > last_u ? last_u : ue;
-        // ---- stage B: modify the spectrum, inverse transform
-        if (t >= ub && t <= ue && !(a.ablate & 2)) {
+        // ---- stage B: wave w modifies the spectrum of frame ub + w and transforms it back
+        const int64_t t = ub + wave;
+        V *buf = bufs + (size_t)(t % NB) * bstride;
+        if (t <= ue && !(a.ablate & 2)) {
             if (a.ablate & 64) {
             } else if (MODE == APPLY_SUBTRACT) {
                 const T inv_st = (T)1 / (T)a.st;
@@ -726,7 +733,7 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
                     for (int dt = -h; dt <= hr; ++dt) {
                         int64_t tt = t + dt;
                         tt = tt < 0 ? 0 : (tt > Tn - 1 ? Tn - 1 : tt);
-                        tsum += mags[(size_t)(tt - base) * mstride + k];
+                        tsum += mags[(size_t)(tt % MR) * mstride + k];
                     }
                     const T sm = tsum * inv_st;
                     const int pk = lp(k == Nc ? Nc : brev(k, logc));
@@ -754,7 +761,8 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
             const int nj = (int)(ue - ub) + R;              // hops touched, < RING
             const int LOGH = 31 - __clz(H);                 // the hop is a power of two
             const int slot0 = (int)(ub % RING);
-            const T *frames = reinterpret_cast<const T *>(bufs) + (size_t)(ub - base) * (2 * bstride);
+            const T *frames = reinterpret_cast<const T *>(bufs);
+            const int fb0 = (int)(ub % NB);                 // buffer of frame ub
 #pragma unroll 1
             for (int idx = tid; idx < (nj << LOGH); idx += W * 64) {
                 const int jj = idx >> LOGH, i = idx & (H - 1);
@@ -766,9 +774,12 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
                 // frames ub + f, f in [f_lo, f_hi], overlap hop j
                 const int f_lo = jj - R + 1 > 0 ? jj - R + 1 : 0;
                 const int f_hi = jj < (int)(ue - ub) ? jj : (int)(ue - ub);
+                int fb = fb0 + f_lo;
+                fb = fb >= NB ? fb - NB : fb;
                 for (int f = f_lo; f <= f_hi; ++f) {
                     const int pos = ((jj - f) << LOGH) + i;
-                    v += frames[(size_t)f * (2 * bstride) + 2 * lp(pos >> 1) + (pos & 1)] * iscale * tb.window[pos];
+                    v += frames[(size_t)fb * (2 * bstride) + 2 * lp(pos >> 1) + (pos & 1)] * iscale * tb.window[pos];
+                    fb = fb + 1 >= NB ? 0 : fb + 1;
                 }
                 if (j <= ue || final_group) {
                     if (j >= ph0 && j < ph1) {
@@ -801,6 +812,7 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
         }
         __syncthreads();
         next_u = ue + 1;
+        base += W;
     }
 }
 
@@ -858,13 +870,20 @@ static int rows_dispatch(Ctx *c, const T *d_x, const Signals &sg, const Tables<T
     return ADN_ERR_UNSUPPORTED;
 }
 
+// LDS of k_stft_apply: frame buffers (W + the parked ones), magnitude rows, hop accumulators + norm
+template <typename T>
+static size_t apply_lds_bytes(int W, int mode, int Nc, int R, int hop, int st) {
+    using V = typename Vec2<T>::type;
+    const int h = mode == APPLY_SUBTRACT ? st / 2 : 0, hr = mode == APPLY_SUBTRACT ? st - h - 1 : 0;
+    return (size_t)(W + hr) * lp_size(Nc) * sizeof(V) +
+           (mode == APPLY_SUBTRACT ? (size_t)(W + h + hr) * (Nc + 2 + 2 * MAG_PAD) * sizeof(T) : 0) +
+           (size_t)(W + R + 1) * hop * sizeof(T);
+}
+
 template <typename T, int W, int MODE>
 static int launch_apply(Ctx *c, ApplyArgs<T> a, int64_t n_sig, int64_t Tmax) {
-    using V = typename Vec2<T>::type;
     const int N = a.tb.n_fft, Nc = N / 2, R = N / a.sg.hop;
-    const size_t lds = (size_t)W * lp_size(Nc) * sizeof(V) +
-                       (MODE == APPLY_SUBTRACT ? (size_t)W * (Nc + 2 + 2 * MAG_PAD) * sizeof(T) : 0) +
-                       (size_t)(W + R + 1) * a.sg.hop * sizeof(T);
+    const size_t lds = apply_lds_bytes<T>(W, MODE, Nc, R, a.sg.hop, a.st);
     const int64_t out_hops = Tmax - 1;
     if (out_hops <= 0) return ADN_OK;
     // enough workgroups to fill the chip several times, but long enough segments to
@@ -884,13 +903,8 @@ static int launch_apply(Ctx *c, ApplyArgs<T> a, int64_t n_sig, int64_t Tmax) {
 
 template <typename T, int MODE>
 static int apply_dispatch(Ctx *c, const ApplyArgs<T> &a, int64_t n_sig, int64_t Tmax) {
-    using V = typename Vec2<T>::type;
     const int N = a.tb.n_fft, Nc = N / 2, R = N / a.sg.hop;
-    auto need = [&](int W) {
-        return (size_t)W * lp_size(Nc) * sizeof(V) +
-               (MODE == APPLY_SUBTRACT ? (size_t)W * (Nc + 2 + 2 * MAG_PAD) * sizeof(T) : 0) +
-               (size_t)(W + R + 1) * a.sg.hop * sizeof(T);
-    };
+    auto need = [&](int W) { return apply_lds_bytes<T>(W, MODE, Nc, R, a.sg.hop, a.st); };
     const int min_w = MODE == APPLY_SUBTRACT ? a.st : 1;
     if constexpr (std::is_same<T, float>::value) {
         // the register-resident kernel is built for the reference's 3-frame time smoothing
@@ -899,6 +913,7 @@ static int apply_dispatch(Ctx *c, const ApplyArgs<T> &a, int64_t n_sig, int64_t 
     }
     if (need(8) <= 160 * 1024) return launch_apply<T, 8, MODE>(c, a, n_sig, Tmax);
     if (need(4) <= 160 * 1024 && min_w <= 4) return launch_apply<T, 4, MODE>(c, a, n_sig, Tmax);
+    if (need(3) <= 160 * 1024 && min_w <= 3) return launch_apply<T, 3, MODE>(c, a, n_sig, Tmax);
     if (need(2) <= 160 * 1024 && min_w <= 2) return launch_apply<T, 2, MODE>(c, a, n_sig, Tmax);
     set_error("n_fft=%d hop=%d smoothing=%d does not fit the 160 KB LDS of a CU", N, a.sg.hop, a.st);
     return ADN_ERR_UNSUPPORTED;

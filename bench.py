@@ -243,7 +243,7 @@ def main():
                                    % args.clips,
                        "clips_per_gpu": args.clips, "sharding": "clips round-robin over ranks, no collective"},
             "roofline": {"bound": "hbm", "kernel": "adn::fast::k_apply_fast<8, SUBTRACT, false> (phase 2b, one launch per step)"
-                         if args.dtype == "f32" else "adn::k_stft_apply<double, 4, SUBTRACT> (phase 2b)",
+                         if args.dtype == "f32" else "adn::k_stft_apply<double, 3, SUBTRACT> (phase 2b)",
                          "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": stages[dom]["hbm_frac"],
                          "traffic": measured_traffic("void adn::fast::k_apply_fast<8, 0, false>", args.clips)
