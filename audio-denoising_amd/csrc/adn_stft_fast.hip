@@ -22,6 +22,7 @@ static constexpr int RS = 68;       // exchange row stride (float2): 64 + 4 keep
 static constexpr int WBUF = 1088;   // float2 per wave buffer: 16 * RS >= padded natural image + 1
 static constexpr int MROW = 1032;   // floats per magnitude row (1025 used)
 static constexpr int FAST_ST = 3;   // time-smoothing frames this specialisation is built for
+static constexpr int ROWS_GPW = 8;  // groups of frames per workgroup of the rows kernel
 static constexpr int PARK = 1026;   // float2 slots of a parked spectrum (1025 used)
 static constexpr int RAWPAD = 8;    // replicated bins kept beyond each end of a raw magnitude row
 
@@ -276,11 +277,13 @@ __global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ 
     c2 *twtab = reinterpret_cast<c2 *>(tile + 1025 * (FT + 1) + ((1025 * (FT + 1)) & 1));
     float *wtab = reinterpret_cast<float *>(twtab + TWTAB);                // [2048] window
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t sig = blockIdx.x / groups_per_sig, grp = blockIdx.x % groups_per_sig;
+    // a workgroup handles ROWS_GPW consecutive groups of FT frames of one signal, so that the
+    // tables are staged once per ROWS_GPW groups
+    const int64_t wgs_per_sig = (groups_per_sig + ROWS_GPW - 1) / ROWS_GPW;
+    const int64_t sig = blockIdx.x / wgs_per_sig, grp0 = (blockIdx.x % wgs_per_sig) * ROWS_GPW;
     const int64_t n = sg.len[sig];
     const int64_t Tn = stft_frames(n, 2048, sg.hop, sg.padded);
-    const int64_t t0 = grp * FT;
-    if (t0 >= Tn) return;
+    if (grp0 * FT >= Tn) return;
     const float *xs = x + sg.off[sig];
     c2 *buf = bufs + (size_t)wave * WBUF;
     fill_tw_table(twtab, tb.fast_tw, threadIdx.x, W * 64);
@@ -292,6 +295,11 @@ __global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ 
     const float scale = (float)(1.0 / tb.wsum);
     const int ts = FT + 1;
     float vmax = 0.0f;
+#pragma unroll 1
+    for (int g = 0; g < ROWS_GPW; ++g) {
+    const int64_t t0 = (grp0 + g) * FT;
+    if (t0 >= Tn) break;
+    if (g) __syncthreads();                                  // the tile of the previous group has been stored
     for (int it = 0; it < FT / W; ++it) {
         const int ft = it * W + wave;
         const int64_t t = t0 + ft;
@@ -341,6 +349,7 @@ __global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ 
             const int k = idx / FT, ft = idx % FT;
             if (ft < nft) Srow[(size_t)k * Tmax + ft] = tile[k * ts + ft];
         }
+    }
     }
     if (sig_max != nullptr) {
         for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
@@ -845,7 +854,8 @@ int rows_fast(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &
     auto kern = fast::k_rows_fast<W>;
     ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(groups * n_sig)), dim3(W * 64), lds, c->stream, d_x, sg, tb,
+    const int64_t wgs = ceil_div(groups, (int64_t)fast::ROWS_GPW);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(wgs * n_sig)), dim3(W * 64), lds, c->stream, d_x, sg, tb,
                        groups, FT, Tmax, power, S, sig_max);
     ADN_HIP(hipGetLastError());
     return ADN_OK;
