@@ -234,11 +234,13 @@ __device__ void fft_dit_inv(V *buf, const V *tw, int logn, int lane) {
 // transform it; on return buf holds X[k] * scale at brev(k) for k < Nc and X[Nc] at buf[Nc].
 template <typename T, typename V>
 __device__ void wave_rfft_frame(V *buf, const T *__restrict__ x, int64_t n, int n_ch, int64_t t,
-                                const Tables<T> &tb, int hop, T scale, int lane) {
+                                const Tables<T> &tb, int hop, T scale, int lane, int ablate = 0,
+                                const T *win = nullptr) {
     const int Nc = tb.n_fft / 2, logc = tb.logc;
     const int64_t p0 = t * hop;
     constexpr int LB = 8;                                    // loads in flight per lane and batch
-    const V *wv = reinterpret_cast<const V *>(tb.window);
+    if (win == nullptr) win = tb.window;
+    const V *wv = reinterpret_cast<const V *>(win);
     if (n_ch == 1 && p0 + tb.n_fft <= n && (reinterpret_cast<uintptr_t>(x + p0) % sizeof(V)) == 0) {
         const V *xv = reinterpret_cast<const V *>(x + p0);
 #pragma unroll 1
@@ -276,11 +278,12 @@ __device__ void wave_rfft_frame(V *buf, const T *__restrict__ x, int64_t n, int 
     } else {
         for (int i = lane; i < Nc; i += 64) {
             const T a = fold_sample(x, p0 + 2 * i, n, n_ch), b = fold_sample(x, p0 + 2 * i + 1, n, n_ch);
-            buf[lp(i)] = V{a * tb.window[2 * i], b * tb.window[2 * i + 1]};
+            buf[lp(i)] = V{a * win[2 * i], b * win[2 * i + 1]};
         }
     }
     wave_sync();
-    fft_dif(buf, tb.tw, logc, lane);
+    if (!(ablate & 128)) fft_dif(buf, tb.tw, logc, lane);
+    if (ablate & 256) return;
     // split the packed transform into the real-signal spectrum, in place (pairs k <-> Nc-k),
     // four pairs per lane and batch; lane 0 then handles the two self-paired bins
     constexpr int U = 4;
@@ -623,7 +626,9 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
     // [MR][mstride]: a row holds bins 0..Nc at offset MAG_PAD, with replicated edge bins on both sides
     T *mags = reinterpret_cast<T *>(bufs + (size_t)NB * bstride) + MAG_PAD;
     T *acc = mags - MAG_PAD + (MODE == APPLY_SUBTRACT ? (size_t)MR * mstride : 0);   // [RING][H]
-    T *wsq = acc + (size_t)RING * H;                                      // [H] norm of a fully overlapped hop
+    T *wsq = acc + (size_t)RING * H;                                      // [H] 1 / norm of a fully overlapped hop
+    // the window is staged in LDS when the host found room for it (generic pointer: either memory)
+    const T *win = a.win_lds ? wsq + H : tb.window;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
     const int64_t sig = blockIdx.x / a.segs_per_sig, seg = blockIdx.x % a.segs_per_sig;
     const int64_t n = a.sg.len[sig];
@@ -645,13 +650,15 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
     const T iscale = (T)(tb.wsum / (double)Nc);
 
     for (int i = tid; i < RING * H; i += W * 64) acc[i] = 0;
+    if (a.win_lds)
+        for (int i = tid; i < N; i += W * 64) wsq[H + i] = tb.window[i];
     for (int i = tid; i < H; i += W * 64) {
         T norm = 0;
         for (int r = R - 1; r >= 0; --r) {                 // same order as the edge loop below
             const T w = tb.window[r * H + i];
             norm += w * w;
         }
-        wsq[i] = norm;
+        wsq[i] = (T)1 / (norm > (T)1e-10 ? norm : (T)1);    // reciprocal: one multiplication per output sample
     }
     __syncthreads();
 
@@ -664,19 +671,32 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
         // ---- stage A: spectrum of frame ta (and its clean magnitudes)
         if (ta <= a_last && !(a.ablate & 1)) {
             V *buf = bufs + (size_t)(ta % NB) * bstride;
-            wave_rfft_frame<T, V>(buf, xs, n, a.sg.n_ch, ta, tb, H, fscale, lane);
+            wave_rfft_frame<T, V>(buf, xs, n, a.sg.n_ch, ta, tb, H, fscale, lane, a.ablate, win);
             if (MODE == APPLY_SUBTRACT && !(a.ablate & 32)) {
                 // clean magnitudes of the frame, then their box mean along frequency (edge
                 // replicated), in place: every lane reads the neighbourhoods of its bins before any
                 // lane overwrites a bin.  The time mean over the neighbouring frames follows in
                 // stage B, in the same order as the two 1-D passes of scipy's uniform_filter.
                 T *mrow = mags + (size_t)(ta % MR) * mstride;
-                for (int k = lane; k <= Nc; k += 64) {
-                    const V z = buf[lp(k == Nc ? Nc : brev(k, logc))];
-                    const T p2 = z.x * z.x + z.y * z.y;
-                    const T mag = p2 > (T)0 ? p2 * inv_sqrt(p2) : (T)0;
-                    const T c1 = mag - a.alpha * row[k], c2 = a.beta * mag;
-                    mrow[k] = c1 > c2 ? c1 : c2;
+                constexpr int MB = 6;                            // bins per lane and batch, loads first
+#pragma unroll 1
+                for (int k0 = lane; k0 <= Nc; k0 += 64 * MB) {
+                    V z[MB];
+                    T nz[MB];
+#pragma unroll
+                    for (int u = 0; u < MB; ++u) {
+                        const int k = k0 + 64 * u <= Nc ? k0 + 64 * u : Nc;
+                        z[u] = buf[lp(k == Nc ? Nc : brev(k, logc))];
+                        nz[u] = row[k];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < MB; ++u) {
+                        const T p2 = z[u].x * z[u].x + z[u].y * z[u].y;
+                        const T mag = p2 > (T)0 ? p2 * inv_sqrt(p2) : (T)0;
+                        const T c1 = mag - a.alpha * nz[u], c2 = a.beta * mag;
+                        if (k0 + 64 * u <= Nc) mrow[k0 + 64 * u] = c1 > c2 ? c1 : c2;
+                    }
                 }
                 const int fl = a.sf / 2, fr = a.sf - fl - 1;
                 wave_sync();
@@ -691,28 +711,27 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
                 if (a.sf == 5) {                                 // the reference's box: all reads in flight together
 #pragma unroll
                     for (int u = 0; u < KB; ++u) {
-                        const int k = lane + 64 * u;
-                        T fs = 0;
-                        if (k <= Nc) {
-                            const T v0 = mrow[k - 2], v1 = mrow[k - 1], v2 = mrow[k], v3 = mrow[k + 1], v4 = mrow[k + 2];
-                            fs = (((((T)0 + v0) + v1) + v2) + v3) + v4;
-                        }
-                        box[u] = fs * inv_sf;
+                        if (64 * u > Nc) break;                  // uniform
+                        const int k = lane + 64 * u <= Nc ? lane + 64 * u : Nc;
+                        const T v0 = mrow[k - 2], v1 = mrow[k - 1], v2 = mrow[k], v3 = mrow[k + 1], v4 = mrow[k + 2];
+                        box[u] = ((((((T)0 + v0) + v1) + v2) + v3) + v4) * inv_sf;
                     }
                 } else {
 #pragma unroll
                     for (int u = 0; u < KB; ++u) {
-                        const int k = lane + 64 * u;
+                        if (64 * u > Nc) break;
+                        const int k = lane + 64 * u <= Nc ? lane + 64 * u : Nc;
                         T fs = 0;
-                        if (k <= Nc)
-                            for (int df = -fl; df <= fr; ++df) fs += mrow[k + df];
+                        for (int df = -fl; df <= fr; ++df) fs += mrow[k + df];
                         box[u] = fs * inv_sf;
                     }
                 }
                 wave_sync();
 #pragma unroll
-                for (int u = 0; u < KB; ++u)
+                for (int u = 0; u < KB; ++u) {
+                    if (64 * u > Nc) break;
                     if (lane + 64 * u <= Nc) mrow[lane + 64 * u] = box[u];
+                }
             }
         }
         __syncthreads();
@@ -728,20 +747,40 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
             if (a.ablate & 64) {
             } else if (MODE == APPLY_SUBTRACT) {
                 const T inv_st = (T)1 / (T)a.st;
-                for (int k = lane; k <= Nc; k += 64) {
-                    T tsum = 0;
-                    for (int dt = -h; dt <= hr; ++dt) {
-                        int64_t tt = t + dt;
-                        tt = tt < 0 ? 0 : (tt > Tn - 1 ? Tn - 1 : tt);
-                        tsum += mags[(size_t)(tt % MR) * mstride + k];
+                // rows of the time neighbours (clamped at the signal's first / last frame)
+                const T *trow[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    int64_t tt = t - h + i;
+                    tt = tt < 0 ? 0 : (tt > Tn - 1 ? Tn - 1 : tt);
+                    trow[i] = mags + (size_t)(tt % MR) * mstride;
+                }
+                constexpr int MB = 6;                            // bins per lane and batch, loads first
+#pragma unroll 1
+                for (int k0 = lane; k0 <= Nc; k0 += 64 * MB) {
+                    V z[MB];
+                    T tsum[MB];
+                    int pk[MB];
+#pragma unroll
+                    for (int u = 0; u < MB; ++u) {
+                        const int k = k0 + 64 * u <= Nc ? k0 + 64 * u : Nc;
+                        pk[u] = lp(k == Nc ? Nc : brev(k, logc));
+                        z[u] = buf[pk[u]];
+                        T ts = 0;
+#pragma unroll
+                        for (int i = 0; i < 7; ++i)
+                            if (i < a.st) ts += trow[i][k];
+                        tsum[u] = ts;
                     }
-                    const T sm = tsum * inv_st;
-                    const int pk = lp(k == Nc ? Nc : brev(k, logc));
-                    const V z = buf[pk];
-                    const T p2 = z.x * z.x + z.y * z.y;
-                    // clean * exp(i*angle(Z)) = clean * Z / |Z|; angle(0) = 0
-                    const T g = sm * inv_sqrt(p2);
-                    buf[pk] = p2 > (T)0 ? V{z.x * g, z.y * g} : V{sm, (T)0};
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < MB; ++u) {
+                        const T sm = tsum[u] * inv_st;
+                        const T p2 = z[u].x * z[u].x + z[u].y * z[u].y;
+                        // clean * exp(i*angle(Z)) = clean * Z / |Z|; angle(0) = 0
+                        const T g = sm * inv_sqrt(p2);
+                        if (k0 + 64 * u <= Nc) buf[pk[u]] = p2 > (T)0 ? V{z[u].x * g, z[u].y * g} : V{sm, (T)0};
+                    }
                 }
             } else {
                 for (int k = lane; k <= Nc; k += 64) {
@@ -778,23 +817,23 @@ __global__ __launch_bounds__(W * 64) void k_stft_apply(ApplyArgs<T> a) {
                 fb = fb >= NB ? fb - NB : fb;
                 for (int f = f_lo; f <= f_hi; ++f) {
                     const int pos = ((jj - f) << LOGH) + i;
-                    v += frames[(size_t)fb * (2 * bstride) + 2 * lp(pos >> 1) + (pos & 1)] * iscale * tb.window[pos];
+                    v += frames[(size_t)fb * (2 * bstride) + 2 * lp(pos >> 1) + (pos & 1)] * iscale * win[pos];
                     fb = fb + 1 >= NB ? 0 : fb + 1;
                 }
                 if (j <= ue || final_group) {
                     if (j >= ph0 && j < ph1) {
-                        T norm = wsq[i];
+                        T o = v * wsq[i];
                         if (j - R + 1 < 0 || j > Tn - 1) {            // first / last hops: fewer frames overlap
-                            norm = 0;
+                            T norm = 0;
                             int64_t t_lo = j - R + 1;
                             t_lo = t_lo < 0 ? 0 : t_lo;
                             const int64_t t_hi = j < Tn - 1 ? j : Tn - 1;
                             for (int64_t tt = t_lo; tt <= t_hi; ++tt) {
-                                const T w = tb.window[((int)(j - tt) << LOGH) + i];
+                                const T w = win[((int)(j - tt) << LOGH) + i];
                                 norm += w * w;
                             }
+                            o = v / (norm > (T)1e-10 ? norm : (T)1);
                         }
-                        T o = v / (norm > (T)1e-10 ? norm : (T)1);
                         if (!a.no_clip) o = o < (T)-1 ? (T)-1 : (o > (T)1 ? (T)1 : o);      // np.clip keeps NaN
                         const int64_t yo = ((j - R / 2) << LOGH) + i;
                         if (ps) {
@@ -883,7 +922,9 @@ static size_t apply_lds_bytes(int W, int mode, int Nc, int R, int hop, int st) {
 template <typename T, int W, int MODE>
 static int launch_apply(Ctx *c, ApplyArgs<T> a, int64_t n_sig, int64_t Tmax) {
     const int N = a.tb.n_fft, Nc = N / 2, R = N / a.sg.hop;
-    const size_t lds = apply_lds_bytes<T>(W, MODE, Nc, R, a.sg.hop, a.st);
+    size_t lds = apply_lds_bytes<T>(W, MODE, Nc, R, a.sg.hop, a.st);
+    a.win_lds = lds + (size_t)N * sizeof(T) <= 160 * 1024;
+    if (a.win_lds) lds += (size_t)N * sizeof(T);
     const int64_t out_hops = Tmax - 1;
     if (out_hops <= 0) return ADN_OK;
     // enough workgroups to fill the chip several times, but long enough segments to

@@ -88,6 +88,7 @@ struct ApplyArgs {
     int64_t row_stride;  // elements between signals (0 = shared)
     int64_t row_t_stride;  // GAIN mode: elements between the gain rows of consecutive frames (0 = one row for all)
     int16_t *pcm;        // optional: 16-bit PCM values of the output (same offsets as y); y then holds pcm / 32768
+    int win_lds;         // shape-generic kernel: the window table is staged in LDS (set by the launcher)
     int no_clip;         // 1: the output is not clipped to [-1, 1] (HPSS writes the ISTFT as it is)
     T alpha, beta;
     int st, sf;          // box sizes along time / frequency
