@@ -34,13 +34,6 @@ __device__ __forceinline__ c2 operator-(c2 a, c2 b) { return c2{a.x - b.x, a.y -
 __device__ __forceinline__ c2 mul(c2 a, c2 b) { return c2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
 __device__ __forceinline__ c2 mulc(c2 a, c2 b) { return c2{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }
 
-template <int CTRL>
-__device__ __forceinline__ float dpp(float v) {
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-template <int CTRL>
-__device__ __forceinline__ c2 dpp2(c2 v) { return c2{dpp<CTRL>(v.x), dpp<CTRL>(v.y)}; }
-
 // v * W16^M (forward) or its conjugate (inverse)
 template <int M, bool INV>
 __device__ __forceinline__ c2 mul_w16(c2 v) {
@@ -117,7 +110,10 @@ __device__ __forceinline__ LaneTw lane_tw(const c2 *tab, int lane) {
     return LaneTw{tab + lane, tab + 15 * 64 + (lane & 3)};
 }
 
-// In: lane l, r[j] = x[l + 64 j].  Out: lane l = 4*k1 + b, r[c] = X[k1 + 16 c + 256 * brev2(b)].
+// In: lane l, r[j] = x[l + 64 j].
+// Out: lane l = 16*cq + k1, r[4*cc + d] = X[k1 + 16 * (4*cq + cc) + 256 * d].
+// Three passes (16 x 16 x 4 points), all butterflies in registers, two exchanges through the
+// wave's LDS buffer E (16 rows of RS float2).
 template <bool INV>
 __device__ __forceinline__ void wave_fft1024(c2 (&r)[16], c2 *E, const LaneTw &t, int lane) {
     dft16<INV>(r);
@@ -133,34 +129,35 @@ __device__ __forceinline__ void wave_fft1024(c2 (&r)[16], c2 *E, const LaneTw &t
     for (int a = 0; a < 16; ++a) r[a] = E[row + 4 * a];
     wave_sync();
     dft16<INV>(r);
-    // radix-4 across the four lanes of a quad as two butterfly steps:
-    //   step 1 (partner lane ^ 2):  b < 2: v + p      b >= 2: p - v, lane 3 also times -i (+i inverse)
-    //   step 2 (partner lane ^ 1):  even:  u + p      odd:    p - u
-    // (sum and difference are both formed and selected: the DPP move fuses into the add / sub)
-    const int b = lane & 3;
-    c2 u[16];
+    // lane = 4*k1 + b now holds Y[c] (at r[P16(c)]) of the 16-point transforms over a (source index
+    // b + 4a): twiddle by W64^(b*c) and regroup so that one lane holds all four b of four values of
+    // c; row k1 of E takes the values at column 4*c + b
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         c2 v = r[P16(c)];
         if (c) v = INV ? mulc(v, t.t2[(c - 1) * 4]) : mul(v, t.t2[(c - 1) * 4]);
-        const c2 p = dpp2<0x4E>(v);
-        c2 s = (b < 2) ? v + p : p - v;
-        if (b == 3) s = INV ? c2{-s.y, s.x} : c2{s.y, -s.x};
-        u[c] = s;
+        E[row + 4 * c] = v;
     }
+    wave_sync();
+    const float4 *src = reinterpret_cast<const float4 *>(E + (lane & 15) * RS + (lane >> 4) * 16);
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        const c2 p = dpp2<0xB1>(u[c]);
-        r[c] = (b & 1) ? p - u[c] : u[c] + p;
+    for (int i = 0; i < 8; ++i) {
+        const float4 q = src[i];
+        r[2 * i] = c2{q.x, q.y};
+        r[2 * i + 1] = c2{q.z, q.w};
     }
+    wave_sync();
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) bfly4<INV>(r[4 * cc], r[4 * cc + 1], r[4 * cc + 2], r[4 * cc + 3]);
 }
 
 // Natural-order (padded) store of the layout produced by wave_fft1024.
 __device__ __forceinline__ void store_natural(const c2 (&r)[16], c2 *buf, int lane) {
-    const int b = lane & 3, d = ((b >> 1) | ((b & 1) << 1));
-    const int base = (lane >> 2) + 264 * d;           // k1 + nat(256 d)
+    const int base = (lane & 15) + 64 * (lane >> 4);          // k1 + 16 * 4 * cq
 #pragma unroll
-    for (int c = 0; c < 16; ++c) buf[base + 16 * c] = r[c];
+    for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) buf[base + 16 * cc + 264 * d] = r[4 * cc + d];   // nat(k1 + 16 c + 256 d)
 }
 
 // Frame at padded sample p0 of a signal -> layout-A registers (windowed, packed):
@@ -604,13 +601,12 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
             wave_fft1024<true>(r, buf, tw, lane);
             tick(11);
             if (!win_in_ola) {
-                // time samples of this lane: n = k1 + 16 c + 256 d; apply the synthesis window
-                const int b = lane & 3, d = ((b >> 1) | ((b & 1) << 1));
-                const c2 *wv = reinterpret_cast<const c2 *>(wtab) + (lane >> 2) + 256 * d;
+                // time samples of this lane: n = k1 + 16 (4 cq + cc) + 256 d; apply the synthesis window
+                const c2 *wv = reinterpret_cast<const c2 *>(wtab) + (lane & 15) + 64 * (lane >> 4);
 #pragma unroll
-                for (int c = 0; c < 16; ++c) {
-                    const c2 w = wv[16 * c];
-                    r[c] = c2{r[c].x * iscale * w.x, r[c].y * iscale * w.y};
+                for (int i = 0; i < 16; ++i) {
+                    const c2 w = wv[16 * (i >> 2) + 256 * (i & 3)];
+                    r[i] = c2{r[i].x * iscale * w.x, r[i].y * iscale * w.y};
                 }
             }
             store_natural(r, buf, lane);
