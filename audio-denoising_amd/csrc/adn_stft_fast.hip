@@ -211,6 +211,37 @@ __device__ __forceinline__ void load_frame(c2 (&r)[16], c2 *buf, const float *__
     }
 }
 
+// Raw samples of a frame fetched one iteration ahead (no arithmetic: the loads are in flight while
+// the workgroup overlap-adds).  mode 1: mono, pf[j >> 1] holds x[lane + 64 j] pairs; mode 2: stereo,
+// pf[j] holds the two (left, right) pairs of packed point lane + 64 j; 0: the frame needs the
+// ordinary loader (tail of the signal, odd alignment, more channels).
+__device__ __forceinline__ int prefetch_frame(float4 (&pf)[8], const float *__restrict__ xs, int64_t n, int n_ch,
+                                              int64_t p0, int lane) {
+    if (p0 + 2048 <= n && n_ch == 1 && (reinterpret_cast<uintptr_t>(xs + p0) & 7) == 0) {
+        const c2 *xv = reinterpret_cast<const c2 *>(xs + p0) + lane;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 16; j += 2) {
+            const c2 a = xv[64 * j], b = xv[64 * (j + 1)];
+            pf[j >> 1] = float4{a.x, a.y, b.x, b.y};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        return 1;
+    }
+    return 0;
+}
+
+__device__ __forceinline__ void window_prefetched(c2 (&r)[16], const float4 (&pf)[8], int mode,
+                                                  const float *__restrict__ window, int lane) {
+    const c2 *wv = reinterpret_cast<const c2 *>(window);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float4 q = pf[j >> 1];
+        const c2 w = wv[lane + 64 * j];
+        r[j] = (j & 1) ? c2{q.z * w.x, q.w * w.y} : c2{q.x * w.x, q.y * w.y};
+    }
+}
+
 // Real-signal spectrum of the packed transform held in buf (natural, padded).
 // lo[j] = X[k], hi[j] = X[1024-k] for k = lane + 64 j (lane 0, j 0: X[0] and X[1024]); mid = X[512].
 struct Spec {
@@ -430,6 +461,8 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
     int base = next_u - h;
     base = base < 0 ? 0 : base;
     int park_t = -1;                                       // frame whose spectrum is parked (last wave only)
+    float4 pf[8];                                          // next iteration's (mono) frame, fetched during the overlap-add
+    int pf_mode = 0;
 #pragma unroll 1
     while (next_u <= last_u) {
         unsigned long long tk = prof ? clock64() : 0;
@@ -447,7 +480,8 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
         // ---- stage A: spectrum of frame t
         if (t <= a_last && !(a.ablate & 1)) {
             c2 r[16];
-            load_frame(r, buf, xs, n, a.sg.n_ch, (int64_t)t * H, wtab, lane);
+            if (pf_mode) window_prefetched(r, pf, pf_mode, wtab, lane);
+            else load_frame(r, buf, xs, n, a.sg.n_ch, (int64_t)t * H, wtab, lane);
             if (prof) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             tick(6);
             wave_fft1024<false>(r, buf, tw, lane);
@@ -610,6 +644,12 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                 }
             }
             store_natural(r, buf, lane);
+        }
+        // the frame of the next iteration: loads issued now, consumed after the overlap-add
+        pf_mode = 0;
+        {
+            const int tn = base + W + wave;
+            if (tn <= a_last && !(a.ablate & 8)) pf_mode = prefetch_frame(pf, xs, n, a.sg.n_ch, (int64_t)tn * H, lane);
         }
         tick(2);
         lds_barrier();
