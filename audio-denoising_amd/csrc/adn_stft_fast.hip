@@ -433,10 +433,10 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
     const float iscale = (float)(tb.wsum / 1024.0);
     c2 *buf = bufs + wave * WBUF;
     float *bufr = reinterpret_cast<float *>(buf);
-    // hop == workgroup size: the overlap-add owns fixed sample positions per thread and applies
+    // hop 512 with four-fold overlap: the overlap-add owns fixed sample positions per thread and applies
     // the synthesis window (and the inverse-transform scale) there, from four 16-byte loads per
     // iteration, instead of sixteen 8-byte window loads per frame after the inverse transform
-    const bool win_in_ola = (H == W * 64 && R == 4);
+    const bool win_in_ola = (H == 512 && R == 4);
 
     fill_tw_table(twtab, tb.fast_tw, tid, W * 64);
     const LaneTw tw = lane_tw(twtab, lane);
@@ -703,12 +703,13 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                     *slot = v;
                 }
             };
-            if (H == W * 64 && R == 4) {
-                // hop == threads per workgroup: a thread owns FOUR consecutive samples
-                // i .. i+3 of every fourth hop, so every LDS access is 16 bytes, the finished
+            if (H == 512 && R == 4) {
+                // 128 threads per hop: a thread owns FOUR consecutive samples
+                // i .. i+3 of every NG-th hop, so every LDS access is 16 bytes, the finished
                 // samples leave in one 16-byte store, and the sample offsets inside a frame
                 // and the norm are per-thread constants
-                const int i = (tid & (W * 16 - 1)) * 4;
+                constexpr int NG = W / 2;                        // groups of 128 threads, one hop each
+                const int i = (tid & 127) * 4;
                 int off[4];
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) off[qq] = natf((qq << LOGH) + i);
@@ -720,10 +721,10 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                     wsyn[qq] = float4{w.x * iscale, w.y * iscale, w.z * iscale, w.w * iscale};
                 }
                 const bool y_vec = (reinterpret_cast<uintptr_t>(ys) & 15) == 0;
-                const int jj0 = tid / (W * 16);                 // 0..3
+                const int jj0 = tid >> 7;                        // 0..NG-1
                 int slot_i = (ub + jj0) % RING;
 #pragma unroll 1
-                for (int jj = jj0; jj < nj; jj += 4) {
+                for (int jj = jj0; jj < nj; jj += NG) {
                     const int j = ub + jj;
                     float4 *slot = reinterpret_cast<float4 *>(acc + slot_i * H + i);
                     float4 v = *slot;
@@ -797,7 +798,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
                     } else {
                         *slot = v;
                     }
-                    slot_i += 4;
+                    slot_i += NG;
                     slot_i = slot_i >= RING ? slot_i - RING : slot_i;
                 }
             } else {
@@ -840,8 +841,8 @@ static size_t apply_lds(int W, int mode, int hop) {
 
 template <int MODE>
 int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
-    // 8 waves per workgroup: in SUBTRACT mode they share the time-smoothing halo frames
-    // (6 of 8 transforms useful); 4-wave workgroups, two per CU, measured 2x slower.
+    // 8 waves per workgroup.  4-wave workgroups, two per CU, measured the same in GAIN mode (the
+    // overlap-add path handles W = 4 too) and do not fit LDS twice in SUBTRACT mode.
     constexpr int W = 8;
     const int64_t out_hops = Tmax - 1;
     if (out_hops <= 0) return ADN_OK;
