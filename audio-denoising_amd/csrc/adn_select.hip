@@ -1174,6 +1174,7 @@ static int64_t big_cand_cap(int64_t max_len, size_t key_bytes) {
 // Candidate capacities of the bracket levels: a level whose list would not fit the lean LDS
 // kernel is bracketed again (sample -> gather) on the gathered keys, about 14x shorter each time.
 static constexpr int BIG_MAX_LEVELS = 7;
+static constexpr size_t SEL_LEVEL_STOP_BYTES = 32 * 1024;
 static int big_level_caps(int64_t max_len, size_t key_bytes, int64_t *caps) {
     int n = 0;
     int64_t len = max_len;
@@ -1181,7 +1182,8 @@ static int big_level_caps(int64_t max_len, size_t key_bytes, int64_t *caps) {
         int64_t cap = big_cand_cap(len, key_bytes);
         if (cap < 2 * BIG_SAMPLE) cap = 2 * BIG_SAMPLE;      // a short list passes through a level whole
         caps[n++] = cap;
-        if ((size_t)cap * key_bytes <= SEL_LDS_MAX_BYTES) break;
+        // stop once the list is small enough for several selecting workgroups to share a CU
+        if ((size_t)cap * key_bytes <= SEL_LEVEL_STOP_BYTES) break;
         len = cap;
     }
     return n;
