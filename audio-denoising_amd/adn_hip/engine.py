@@ -25,8 +25,20 @@ def _suffix(dtype):
     raise TypeError("only float32 / float64 buffers are supported, got %s" % dtype)
 
 
+_EMPTY = {}          # device -> small buffer whose address stands for empty tensors
+
+
 def _ptr(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    """Device address of a tensor (NULL for None).  torch reports address 0 for an empty tensor; the
+    C ABI reserves NULL for "argument not given", so an empty tensor passes a valid dummy address."""
+    if t is None:
+        return C.c_void_p(0)
+    if t.numel() == 0:
+        buf = _EMPTY.get(t.device)
+        if buf is None:
+            buf = _EMPTY[t.device] = torch.empty(64, dtype=torch.uint8, device=t.device)
+        return C.c_void_p(buf.data_ptr())
+    return C.c_void_p(t.data_ptr())
 
 
 class Engine:
@@ -233,8 +245,8 @@ class Engine:
             starts = np.asarray(offsets, dtype=np.int64)
         out_lens = np.array([self.istft_out_samples(n, n_fft, hop) for n in lens], dtype=np.int64)
         out_off = np.concatenate([[0], np.cumsum(out_lens)[:-1]]).astype(np.int64)
-        yh = torch.empty(int(out_lens.sum()), dtype=x.dtype, device=x.device)
-        yp = torch.empty_like(yh)
+        yh = self._out_buffer(int(out_lens.sum()), x)
+        yp = self._out_buffer(int(out_lens.sum()), x)
         stats = torch.empty((len(lens), 5), dtype=torch.float64, device=x.device)
         bands = list(bands) if bands else []
         lo = (C.c_double * max(len(bands), 1))(*[float(b[0]) for b in bands])
@@ -259,7 +271,7 @@ class Engine:
         if out_offsets is None:
             out_offsets = np.concatenate([[0], np.cumsum(out_lens)[:-1]]).astype(np.int64)
         if out is None:
-            out = torch.empty(int(out_lens.sum()), dtype=x.dtype, device=x.device)
+            out = self._out_buffer(int(out_lens.sum()), x)
         noise_mag = noise_mag.to(dtype=x.dtype, device=x.device).contiguous()
         stride = 0 if noise_mag.dim() == 1 else noise_mag.shape[1]
         if noise_mag.shape[-1] != n_fft // 2 + 1:
@@ -281,7 +293,7 @@ class Engine:
         if out_offsets is None:
             out_offsets = np.concatenate([[0], np.cumsum(out_lens)[:-1]]).astype(np.int64)
         if out is None:
-            out = torch.empty(int(out_lens.sum()), dtype=x.dtype, device=x.device)
+            out = self._out_buffer(int(out_lens.sum()), x)
         gain = torch.empty((len(lens), n_fft // 2 + 1), dtype=x.dtype, device=x.device) if want_gain else None
         d_off, d_len, d_yoff = self._i64(starts), self._i64(lens), self._i64(out_offsets)
         self._call("adn_wiener", x.dtype, _ptr(x), len(lens), _ptr(d_off), _ptr(d_len),
@@ -289,6 +301,12 @@ class Engine:
                    int(kernel_bins), int(bool(vad_guided)), _ptr(out), _ptr(d_yoff), _ptr(gain),
                    _ptr(self._pcm_arg(pcm16, out)))
         return (out, out_lens, gain) if want_gain else (out, out_lens)
+
+    @staticmethod
+    def _out_buffer(total, like):
+        """Flat output tensor of `total` samples (a signal exactly one window long yields no output
+        samples at all: scipy's istft trim)."""
+        return torch.empty(total, dtype=like.dtype, device=like.device)
 
     @staticmethod
     def _pcm_arg(pcm16, out):
