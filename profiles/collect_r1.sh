@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-1 measurement set (run on the GPU box from the repo root):
+# Measurement set behind the committed profiles/r1_* files (run on the GPU box from the repo root):
 #   1. default bench line, 2. rocprofv3 kernel-trace stats of the same command,
 #   3./4. PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass) reduced by pmc_traffic.py,
 #   5. a PMC pass of eight SQ counters (instruction mix, vector-ALU / LDS activity, bank conflicts)
