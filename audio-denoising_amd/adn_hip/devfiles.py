@@ -12,6 +12,8 @@ src/wiener_filter.py:57-62).  The files are still written here, but
   and the upload.  A file changed by anyone else in between is read from disk as usual.
 
 Set ``ADN_DEVICE_FILES=0`` to switch the residency off (the files are identical either way).
+At most ``ADN_DEVICE_FILES_MB`` MiB (default 4096) of samples stay resident; larger files are
+simply read back from disk by the next stage.
 """
 import os
 from collections import OrderedDict
@@ -75,9 +77,17 @@ def write_wav(path, y, samplerate, channels, engine, pcm16=None):
         _remember(path, y, samplerate, channels)
 
 
+def _budget_bytes():
+    return int(float(os.environ.get("ADN_DEVICE_FILES_MB", "4096")) * (1 << 20))
+
+
 def _remember(path, t, samplerate, channels):
     key = os.path.realpath(path)
+    _resident.pop(key, None)
+    size = t.numel() * t.element_size()
+    if size > _budget_bytes():
+        return
     _resident[key] = (t, int(samplerate), int(channels), _stamp(key))
-    _resident.move_to_end(key)
-    while len(_resident) > _MAX_RESIDENT:
+    while len(_resident) > _MAX_RESIDENT or \
+            sum(v[0].numel() * v[0].element_size() for v in _resident.values()) > _budget_bytes():
         _resident.popitem(last=False)

@@ -282,3 +282,41 @@ def test_pcm_rule_matches_oracle(tmp_path):
     p = str(tmp_path / "q.wav")
     wavio.write(p, x[fin], 8000)
     assert np.array_equal(wavio.read(p)[0], orc.pcm_decode(q[fin], 16))
+
+
+def test_device_file_residency_bookkeeping(tmp_path, monkeypatch):
+    """Stage files kept resident (adn_hip.devfiles): keyed by path + size + mtime, dropped when the
+    file changes, bounded by count and by ADN_DEVICE_FILES_MB.  CPU tensors stand in for device ones."""
+    import torch
+    from adn_hip import devfiles, wavio
+
+    class Eng:
+        torch_device = torch.device("cpu")
+
+    devfiles.forget()
+    p = str(tmp_path / "a.wav")
+    x = np.linspace(-0.5, 0.5, 1000)
+    wavio.write(p, x, 8000)
+    onfile = torch.as_tensor(wavio.read(p)[0])
+    devfiles._remember(p, onfile.clone() + 1.0, 8000, 1)          # marker: resident copy differs from the file
+    t, sr, ch, frames = devfiles.read_wav(p, Eng(), torch.float64)
+    assert (sr, ch, frames) == (8000, 1, 1000) and torch.equal(t, onfile + 1.0)          # served from residency
+    t32, *_ = devfiles.read_wav(p, Eng(), torch.float32)                                # other dtype: from disk
+    assert t32.dtype == torch.float32 and torch.allclose(t32.double(), onfile)
+    devfiles._remember(p, onfile.clone() + 1.0, 8000, 1)
+    monkeypatch.setenv("ADN_DEVICE_FILES", "0")
+    assert torch.equal(devfiles.read_wav(p, Eng(), torch.float64)[0], onfile)           # switched off
+    monkeypatch.delenv("ADN_DEVICE_FILES")
+    wavio.write(p, x[:900], 8000)                                                       # file rewritten by someone else
+    assert devfiles.read_wav(p, Eng(), torch.float64)[3] == 900
+    # bounded: five files, at most four stay; a tiny byte budget keeps none
+    for i in range(5):
+        q = str(tmp_path / f"f{i}.wav")
+        wavio.write(q, x, 8000)
+        devfiles._remember(q, torch.zeros(1000, dtype=torch.float64), 8000, 1)
+    assert len(devfiles._resident) == 4 and os.path.realpath(str(tmp_path / "f0.wav")) not in devfiles._resident
+    monkeypatch.setenv("ADN_DEVICE_FILES_MB", "0.001")
+    devfiles._remember(p, torch.zeros(1000, dtype=torch.float64), 8000, 1)
+    assert os.path.realpath(p) not in devfiles._resident
+    devfiles.forget()
+    assert not devfiles._resident
