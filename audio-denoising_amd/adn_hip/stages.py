@@ -431,7 +431,7 @@ def run_step_inprocess(label, fn, argv, log_path):
                 rc = ex.code if isinstance(ex.code, int) else 1
                 if not isinstance(ex.code, int):
                     print(ex.code)
-        except BaseException:  # noqa: BLE001 - a stage failure of any kind ends the run like a non-zero exit
+        except Exception:  # noqa: BLE001 - a stage failure of any kind ends the run like a non-zero exit
             traceback.print_exc(file=buf)
             rc = 1
     dt = time.time() - t0
