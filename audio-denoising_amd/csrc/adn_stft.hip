@@ -477,9 +477,30 @@ __global__ __launch_bounds__(256) void k_vad_energy(const T *__restrict__ x, Sig
     const T *xs = x + sg.off[sig];
     const int64_t s = i * frame_len, e = (s + frame_len < n) ? s + frame_len : n;
     double acc = 0.0;
-    for (int64_t p = s + lane; p < e; p += 64) {
-        const double v = (double)fold_sample(xs, p, n, sg.n_ch);
-        acc += v * v;
+    constexpr int VEC = 16 / (int)sizeof(T);
+    if (sg.n_ch == 1 && ((e - s) % VEC) == 0 && (reinterpret_cast<uintptr_t>(xs + s) & 15) == 0) {
+        // mono, aligned: 16-byte loads, all of a lane's loads in flight together
+        using VT = typename std::conditional<sizeof(T) == 4, float4, double2>::type;
+        const VT *xv = reinterpret_cast<const VT *>(xs + s);
+        const int nv4 = (int)((e - s) / VEC);
+        constexpr int UB = 4;
+        for (int q0 = lane; q0 < nv4; q0 += 64 * UB) {
+            VT v[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) v[u] = xv[q0 + 64 * u < nv4 ? q0 + 64 * u : q0];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (u && q0 + 64 * u >= nv4) break;
+                const T *ve = reinterpret_cast<const T *>(&v[u]);
+#pragma unroll
+                for (int c = 0; c < VEC; ++c) acc += (double)ve[c] * (double)ve[c];
+            }
+        }
+    } else {
+        for (int64_t p = s + lane; p < e; p += 64) {
+            const double v = (double)fold_sample(xs, p, n, sg.n_ch);
+            acc += v * v;
+        }
     }
     for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
     if (lane == 0) {
