@@ -21,6 +21,7 @@ namespace adn {
 
 static constexpr int SEL_THREADS = 256;
 static constexpr int SEL_LDS_BYTES = 48 * 1024;
+static constexpr int64_t SEL_ONE_WAVE_MAX = 1024;       // segments up to this length are selected by one wave
 static constexpr size_t SEL_LDS_MAX_BYTES = 96 * 1024;  // longest segment the lean LDS kernel stages
 
 __device__ __forceinline__ void hist_add_matched(uint32_t *hist, uint32_t digit, bool active) {
@@ -396,8 +397,9 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
 // spectra, bracket candidates): 32-bit indexing, keys staged once, every pass re-scans them
 // (only keys that match the digits fixed so far touch the histogram), LDS = n keys exactly so
 // that several workgroups share a CU.  Same results as k_select.
-template <typename T, int XF, bool MASKED>
-__global__ __launch_bounds__(SEL_THREADS) void k_select_lds(const T *__restrict__ vals,
+// NT threads per workgroup: 256, or 64 (one wave, no cross-wave waits) for short segments.
+template <typename T, int XF, bool MASKED, int NT = SEL_THREADS>
+__global__ __launch_bounds__(NT) void k_select_lds(const T *__restrict__ vals,
                                                             const int64_t *__restrict__ seg_off,
                                                             int64_t seg_stride,
                                                             const int64_t *__restrict__ seg_len,
@@ -487,12 +489,12 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_lds(const T *__restrict_
         const VT *vv = reinterpret_cast<const VT *>(vrow);
         const MT *mv4 = reinterpret_cast<const MT *>(mrow);
         constexpr int LBV = 6;
-        for (int j0 = 0; j0 < nv; j0 += LBV * SEL_THREADS) {
+        for (int j0 = 0; j0 < nv; j0 += LBV * NT) {
             VT xq[LBV];
             MT mq[LBV];
 #pragma unroll
             for (int u = 0; u < LBV; ++u) {
-                const int j = j0 + u * SEL_THREADS + tid;
+                const int j = j0 + u * NT + tid;
                 if (j < nv) {
                     xq[u] = vv[j];
                     if (MASKED) mq[u] = mv4[j];
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_lds(const T *__restrict_
             }
 #pragma unroll
             for (int u = 0; u < LBV; ++u) {
-                const int j = j0 + u * SEL_THREADS + tid;
+                const int j = j0 + u * NT + tid;
                 if (j < nv) {
                     const T *xe = reinterpret_cast<const T *>(&xq[u]);
 #pragma unroll
@@ -509,22 +511,22 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_lds(const T *__restrict_
                 }
             }
         }
-        for (int i = nv * VEC + tid; i < n; i += SEL_THREADS) take(i, vrow[i], MASKED ? mrow[i] : (unsigned char)0);
+        for (int i = nv * VEC + tid; i < n; i += NT) take(i, vrow[i], MASKED ? mrow[i] : (unsigned char)0);
     } else {
         constexpr int LB = 8;
-        for (int i0 = 0; i0 < n; i0 += LB * SEL_THREADS) {
+        for (int i0 = 0; i0 < n; i0 += LB * NT) {
             T xv[LB];
             unsigned char mv[LB];
 #pragma unroll
             for (int u = 0; u < LB; ++u) {
-                const int i = i0 + u * SEL_THREADS + tid;
+                const int i = i0 + u * NT + tid;
                 const bool ok = i < n;
                 xv[u] = ok ? vrow[i] : (T)0;
                 if (MASKED) mv[u] = ok ? mrow[i] : (unsigned char)0;
             }
 #pragma unroll
             for (int u = 0; u < LB; ++u) {
-                const int i = i0 + u * SEL_THREADS + tid;
+                const int i = i0 + u * NT + tid;
                 if (i < n) take(i, xv[u], MASKED ? mv[u] : (unsigned char)0);
             }
         }
@@ -537,6 +539,13 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_lds(const T *__restrict_
             msum += __shfl_xor(msum, d);
             mcnt += __shfl_xor(mcnt, d);
         }
+    }
+    if (MASKED && NT < 256) {                       // partial sums of the waves that do not exist
+        if (tid < 4) {
+            s_msum[tid] = 0.0;
+            s_mcnt[tid] = 0;
+        }
+        __syncthreads();
     }
     if (lane == 0) {
         atomicMin(&s_kmin, tmin);
@@ -557,7 +566,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_lds(const T *__restrict_
     bool done = s_nan != 0 || passes == 0;
     for (int pass = 0; pass < passes && !done; ++pass) {
         const int shift = 8 * (passes - 1 - pass);
-        hist[tid] = 0;
+        for (int b = tid; b < 256; b += NT) hist[b] = 0;
         if (tid == 0) {
             s_next = 256;
             s_lo_max = 0;
@@ -566,11 +575,11 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_lds(const T *__restrict_
         __syncthreads();
         if (pass == 0) {
 #pragma unroll 4
-            for (int i = tid; i < n; i += SEL_THREADS)
+            for (int i = tid; i < n; i += NT)
                 atomicAdd(&hist[(uint32_t)((keys[i] - kmin) >> shift) & 0xFFu], 1u);
         } else {
 #pragma unroll 4
-            for (int i = tid; i < n; i += SEL_THREADS) {
+            for (int i = tid; i < n; i += NT) {
                 const K u = keys[i] - kmin;
                 if ((u >> (shift + 8)) == prefix) atomicAdd(&hist[(uint32_t)(u >> shift) & 0xFFu], 1u);
             }
@@ -606,11 +615,12 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_lds(const T *__restrict_
         if (!together) {
             // s[r0] is the largest key of its bin and s[r1] the smallest key of the next
             // non-empty bin: one sweep settles both
-            if (hist[tid] && (uint32_t)tid > digit) atomicMin(&s_next, (uint32_t)tid);
+            for (int b = tid; b < 256; b += NT)
+                if (hist[b] && (uint32_t)b > digit) atomicMin(&s_next, (uint32_t)b);
             __syncthreads();
             const K pre_hi = (prefix << 8) | (K)s_next;
             K lo_max = 0, hi_min = ~(K)0;
-            for (int i = tid; i < n; i += SEL_THREADS) {
+            for (int i = tid; i < n; i += NT) {
                 const K u = keys[i] - kmin;
                 const K top = u >> shift;
                 if (top == new_prefix && u > lo_max) lo_max = u;
@@ -1323,13 +1333,19 @@ int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {
         MaskedMean mm{a.d_mask, a.mask_div, a.mask_stride, a.d_masked_mean};
         const SubsetRanks none{nullptr, 1, 0, nullptr, nullptr, nullptr};
         dim3 grid((unsigned)a.n_seg), block(SEL_THREADS);
-#define ADN_LAUNCH_LDS(XFV, MK)                                                                              \
+#define ADN_LAUNCH_LDS_NT(XFV, MK, NTV)                                                                      \
     do {                                                                                                     \
-        auto kern = k_select_lds<T, XFV, MK>;                                                                \
+        auto kern = k_select_lds<T, XFV, MK, NTV>;                                                           \
         ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                    \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));                  \
-        hipLaunchKernelGGL(kern, grid, block, dyn, c->stream, d_vals, a.d_seg_off, a.seg_stride, a.d_seg_len, \
-                           a.len_div, a.uniform_len, a.mode, a.q, a.d_center, a.d_out, mm, none);            \
+        hipLaunchKernelGGL(kern, grid, dim3(NTV), dyn, c->stream, d_vals, a.d_seg_off, a.seg_stride,         \
+                           a.d_seg_len, a.len_div, a.uniform_len, a.mode, a.q, a.d_center, a.d_out, mm, none); \
+    } while (0)
+        /* short segments: one wave per segment, more segments resident per CU and no cross-wave waits */   \
+#define ADN_LAUNCH_LDS(XFV, MK)                                                                              \
+    do {                                                                                                     \
+        if (a.max_len <= SEL_ONE_WAVE_MAX) ADN_LAUNCH_LDS_NT(XFV, MK, 64);                                   \
+        else ADN_LAUNCH_LDS_NT(XFV, MK, SEL_THREADS);                                                        \
     } while (0)
         const bool masked = a.d_masked_mean != nullptr;
         if (a.xform == XF_ABSDEV) {
@@ -1340,6 +1356,7 @@ int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {
             else ADN_LAUNCH_LDS(XF_NONE, false);
         }
 #undef ADN_LAUNCH_LDS
+#undef ADN_LAUNCH_LDS_NT
         ADN_HIP(hipGetLastError());
         return ADN_OK;
     }
