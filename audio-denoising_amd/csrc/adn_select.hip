@@ -397,7 +397,8 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
 // spectra, bracket candidates): 32-bit indexing, keys staged once, every pass re-scans them
 // (only keys that match the digits fixed so far touch the histogram), LDS = n keys exactly so
 // that several workgroups share a CU.  Same results as k_select.
-// NT threads per workgroup: 256, or 64 (one wave, no cross-wave waits) for short segments.
+// NT threads per workgroup: 64 (one wave, no cross-wave waits) for short segments, 256, or more
+// for rows of several thousand keys (fewer keys per lane in every sweep).
 template <typename T, int XF, bool MASKED, int NT = SEL_THREADS>
 __global__ __launch_bounds__(NT) void k_select_lds(const T *__restrict__ vals,
                                                             const int64_t *__restrict__ seg_off,
@@ -416,8 +417,9 @@ __global__ __launch_bounds__(NT) void k_select_lds(const T *__restrict__ vals,
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t s_digit, s_before, s_count, s_nan, s_next;
     __shared__ K s_lo_max, s_hi_min, s_kmin, s_kmax;
-    __shared__ double s_msum[4];
-    __shared__ int s_mcnt[4];
+    constexpr int NW = NT / 64 < 4 ? 4 : NT / 64;          // per-wave partial sums (at least the four of 256 threads)
+    __shared__ double s_msum[NW];
+    __shared__ int s_mcnt[NW];
 
     const int64_t seg = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -541,7 +543,7 @@ __global__ __launch_bounds__(NT) void k_select_lds(const T *__restrict__ vals,
         }
     }
     if (MASKED && NT < 256) {                       // partial sums of the waves that do not exist
-        if (tid < 4) {
+        if (tid < NW) {
             s_msum[tid] = 0.0;
             s_mcnt[tid] = 0;
         }
@@ -658,8 +660,13 @@ __global__ __launch_bounds__(NT) void k_select_lds(const T *__restrict__ vals,
         }
         out[seg] = res;
         if (MASKED) {
-            const T tot = (T)s_msum[0] + (T)s_msum[1] + (T)s_msum[2] + (T)s_msum[3];
-            const int cn = s_mcnt[0] + s_mcnt[1] + s_mcnt[2] + s_mcnt[3];
+            T tot = (T)s_msum[0] + (T)s_msum[1] + (T)s_msum[2] + (T)s_msum[3];
+            int cn = s_mcnt[0] + s_mcnt[1] + s_mcnt[2] + s_mcnt[3];
+#pragma unroll
+            for (int w = 4; w < NW; ++w) {
+                tot += (T)s_msum[w];
+                cn += s_mcnt[w];
+            }
             mm.out[seg] = (double)(tot / (T)(cn > 1 ? cn : 1));
         }
     }

@@ -251,3 +251,25 @@ def test_frame_count_edges_all_kernels(hop, n_ch):
                 finally:
                     e.force_generic(False)
                 assert np.array_equal(host(y1), yc[oc[i]:oc[i + 1]])
+
+
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
+def test_wiener_long_rows(dt):
+    """A 45 s signal at 48 kHz: the per-bin statistics run over more than 4096 frames, which takes
+    the many-threads-per-row variant of the LDS select (with the fused VAD-masked mean)."""
+    e = engine()
+    n = 45 * SR
+    x = synth.noisy_speech(n, SR, 42, 90)
+    if dt == torch.float32:
+        x = x.astype(np.float32).astype(np.float64)
+    want, gain_want = orc.wiener(x, SR)
+    y, lens, gain = e.wiener(dev(x, dt), [n], SR, want_gain=True)
+    assert e.stft_num_frames(n, 2048, 512) > 4096
+    chk = check64 if dt == torch.float64 else check32
+    chk(host(y), want)
+    tol = 1e-9 if dt == torch.float64 else 2e-4
+    assert np.max(np.abs(host(gain)[0].astype(np.float64) - gain_want)) <= tol
+    # vad_guided = False: the speech estimate is the per-bin median (second selection, unmasked)
+    want2, _ = orc.wiener(x, SR, vad_guided=False)
+    y2, _ = e.wiener(dev(x, dt), [n], SR, vad_guided=False)
+    chk(host(y2), want2)
