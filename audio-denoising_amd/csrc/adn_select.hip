@@ -984,13 +984,26 @@ __global__ __launch_bounds__(256) void k_big_sample(const T *__restrict__ vals, 
     // stratified sample: BIG_SAMPLE / RUN evenly spaced runs of RUN consecutive elements (one or
     // two cache lines per run instead of one line per sample)
     constexpr int RUN = 16, NRUN = BIG_SAMPLE / RUN;
-    for (int j = tid; j < BIG_SAMPLE; j += 256) {
-        const int run = j / RUN, w = j % RUN;
-        int64_t i = (int64_t)(((double)run + 0.5) * (double)n / (double)NRUN) - RUN / 2 + w;
-        i = i < 0 ? 0 : (i < n ? i : n - 1);
-        T x = v[i];
-        if (XF == XF_ABSDEV) x = fabs(x - c);
-        sk[j] = x != x ? ~(K)0 : key_of(x);
+    {
+        // all sixteen loads of a thread are issued before the first key is formed
+        constexpr int PER = BIG_SAMPLE / 256;
+        T xs[PER];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int j = tid + 256 * u;
+            const int run = j / RUN, w = j % RUN;
+            int64_t i = (int64_t)(((double)run + 0.5) * (double)n / (double)NRUN) - RUN / 2 + w;
+            i = i < 0 ? 0 : (i < n ? i : n - 1);
+            xs[u] = v[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            T x = xs[u];
+            if (XF == XF_ABSDEV) x = fabs(x - c);
+            sk[tid + 256 * u] = x != x ? ~(K)0 : key_of(x);
+        }
     }
     const double p = (double)r0 / (double)n;
     const int delta = (int)(4.5 * sqrt((double)BIG_SAMPLE * p * (1.0 - p))) + 3;
