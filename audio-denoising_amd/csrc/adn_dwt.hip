@@ -369,11 +369,13 @@ __device__ __forceinline__ void ch_store(T *__restrict__ p, const T (&v)[ChVec<T
 }
 
 // Pass 1: finest-band coefficients of every frame -> D (frames * n_d1 values per block).
-template <typename T, int NCH>
+// NC: number of coefficients per frame when known at compile time (0: m.n_coef, up to CH_MAXC).
+template <typename T, int NCH, int NC>
 __global__ __launch_bounds__(256) void k_ch_stats(const T *__restrict__ x, T *__restrict__ D,
                                                   BlockGeom g, ChannelMap<T> m,
                                                   int64_t tiles_per_block) {
-    constexpr int FPT = ChVec<T, NCH>::FPT;
+    constexpr int FPT = ChVec<T, NCH>::FPT, KMAX = NC ? NC : CH_MAXC;
+    const int n_coef = NC ? NC : m.n_coef;
     const int64_t b = blockIdx.x / tiles_per_block;
     const int64_t f0 = ((blockIdx.x % tiles_per_block) * 256 + threadIdx.x) * FPT;
     const int64_t frames = g.frames[b];
@@ -388,25 +390,38 @@ __global__ __launch_bounds__(256) void k_ch_stats(const T *__restrict__ x, T *__
     for (int f = 0; f < FPT; ++f) {
         if (f >= nf) break;
 #pragma unroll
-        for (int k = 0; k < CH_MAXC; ++k) {
-            if (k >= m.n_coef - m.n_d1 && k < m.n_coef) {
+        for (int k = 0; k < KMAX; ++k) {
+            if (k >= n_coef - m.n_d1 && k < n_coef) {
                 T s = 0;
 #pragma unroll
                 for (int i = 0; i < NCH; ++i) s += m.W[k][i] * v[f * NCH + i];
-                dst[f * m.n_d1 + k - (m.n_coef - m.n_d1)] = s;
+                dst[f * m.n_d1 + k - (n_coef - m.n_d1)] = s;
             }
         }
     }
 }
 
 // Pass 2: analysis, shrink of every detail coefficient, synthesis, per frame.
-template <typename T, int NCH>
+// Soft / hard shrink; binary32 uses the hardware reciprocal for t / |d| (same 0, inf and NaN cases as the
+// division: t * rcp(0) = inf -> factor clamped to 0; 0 * inf = NaN like 0 / 0).
+__device__ __forceinline__ float shrink_ch(float d, float t, int thr_mode) {
+    if (thr_mode == ADN_THR_SOFT) {
+        float f = 1.0f - t * __builtin_amdgcn_rcpf(fabsf(d));
+        f = f < 0.0f ? 0.0f : f;
+        return d * f;
+    }
+    return fabsf(d) < t ? 0.0f : d;
+}
+__device__ __forceinline__ double shrink_ch(double d, double t, int thr_mode) { return shrink(d, t, thr_mode); }
+
+template <typename T, int NCH, int NC>
 __global__ __launch_bounds__(256) void k_ch_apply(const T *__restrict__ x, T *__restrict__ y,
                                                   BlockGeom g, ChannelMap<T> m,
                                                   int64_t tiles_per_block,
                                                   const double *__restrict__ thresh, int thr_mode,
                                                   int64_t *__restrict__ zeroed) {
-    constexpr int FPT = ChVec<T, NCH>::FPT;
+    constexpr int FPT = ChVec<T, NCH>::FPT, KMAX = NC ? NC : CH_MAXC;
+    const int n_coef = NC ? NC : m.n_coef;
     const int64_t b = blockIdx.x / tiles_per_block;
     const int64_t f0 = ((blockIdx.x % tiles_per_block) * 256 + threadIdx.x) * FPT;
     const int64_t frames = g.frames[b];
@@ -423,25 +438,25 @@ __global__ __launch_bounds__(256) void k_ch_apply(const T *__restrict__ x, T *__
         ch_load<T, NCH>(in + f0 * NCH, v, vec_in, nf);
 #pragma unroll
         for (int f = 0; f < FPT; ++f) {
-            T c[CH_MAXC];
+            T c[KMAX];
 #pragma unroll
             for (int i = 0; i < NCH; ++i) o[f * NCH + i] = 0;
 #pragma unroll
-            for (int k = 0; k < CH_MAXC; ++k) {
+            for (int k = 0; k < KMAX; ++k) {
                 T s = 0;
-                if (k < m.n_coef) {
+                if (k < n_coef) {
 #pragma unroll
                     for (int i = 0; i < NCH; ++i) s += m.W[k][i] * v[f * NCH + i];
                     if (k >= m.n_approx) {
                         nz += (f < nf && fabs(s) < t) ? 1 : 0;
-                        s = shrink(s, t, thr_mode);
+                        s = shrink_ch(s, t, thr_mode);
                     }
                 }
                 c[k] = s;
             }
 #pragma unroll
-            for (int k = 0; k < CH_MAXC; ++k)
-                if (k < m.n_coef) {
+            for (int k = 0; k < KMAX; ++k)
+                if (k < n_coef) {
 #pragma unroll
                     for (int i = 0; i < NCH; ++i) o[f * NCH + i] += m.V[i][k] * c[k];
                 }
@@ -503,12 +518,19 @@ static int channel_denoise(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t
     T *D = ws_take<T>(c, (size_t)g.n_blocks * g.d_stride);
     const int64_t tiles = ceil_div(max_frames, 256 * ChVec<T, NCH>::FPT);
     dim3 grid((unsigned)(tiles * g.n_blocks)), block(256);
-    hipLaunchKernelGGL((k_ch_stats<T, NCH>), grid, block, 0, c->stream, d_in, D, g, m, tiles);
+    // stereo at the reference's level 2 has three coefficients per frame: that shape is compiled in
+    const bool three = NCH == 2 && m.n_coef == 3;
+    if (three) hipLaunchKernelGGL((k_ch_stats<T, NCH, 3>), grid, block, 0, c->stream, d_in, D, g, m, tiles);
+    else hipLaunchKernelGGL((k_ch_stats<T, NCH, 0>), grid, block, 0, c->stream, d_in, D, g, m, tiles);
     double *thresh = nullptr;
     ADN_TRY(mad_threshold<T>(c, D, g, 8, ADN_EXT_PERIODIZATION, m.n_d1, max_frames * m.n_d1,
                              d_sigma, d_thresh, &thresh));
-    hipLaunchKernelGGL((k_ch_apply<T, NCH>), grid, block, 0, c->stream, d_in, d_out, g, m, tiles,
-                       thresh, thr_mode, d_zeroed);
+    if (three)
+        hipLaunchKernelGGL((k_ch_apply<T, NCH, 3>), grid, block, 0, c->stream, d_in, d_out, g, m, tiles, thresh,
+                           thr_mode, d_zeroed);
+    else
+        hipLaunchKernelGGL((k_ch_apply<T, NCH, 0>), grid, block, 0, c->stream, d_in, d_out, g, m, tiles, thresh,
+                           thr_mode, d_zeroed);
     ADN_HIP(hipGetLastError());
     return ADN_OK;
 }

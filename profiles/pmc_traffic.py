@@ -33,10 +33,10 @@ def main():
             continue
         out["kernels"][k] = {"fetch_bytes": f, "write_bytes": w, "hbm_bytes": f + w,
                              "hbm_bytes_per_clip": (f + w) / clips}
-    cal = out["kernels"].get("void adn::k_ch_apply<float, 2>")
+    cal = out["kernels"].get("void adn::k_ch_apply<float, 2, 3>")
     if cal:
         expect = clips * 60 * 48000 * 2 * 4
-        out["calibration"] = {"kernel": "k_ch_apply<float, 2>", "expected_read_bytes": expect,
+        out["calibration"] = {"kernel": "k_ch_apply<float, 2, 3>", "expected_read_bytes": expect,
                               "fetch_ratio": cal["fetch_bytes"] / expect, "write_ratio": cal["write_bytes"] / expect}
     json.dump(out, open(sys.argv[4], "w"), indent=1)
     print(json.dumps(out, indent=1))
