@@ -368,40 +368,53 @@ __device__ __forceinline__ void ch_store(T *__restrict__ p, const T (&v)[ChVec<T
     }
 }
 
+// Chunks (16-byte accesses) per thread of the channel-axis kernels: the per-wave set-up (block geometry,
+// threshold, map entries: a chain of dependent scalar loads) is paid once per CH_CPT chunks, and a tile
+// that lies inside its block issues all its loads before the first use.
+constexpr int CH_CPT = 1;
+
 // Pass 1: finest-band coefficients of every frame -> D (frames * n_d1 values per block).
-// NC: number of coefficients per frame when known at compile time (0: m.n_coef, up to CH_MAXC).
+// NC: number of coefficients per frame when known at compile time (0: m.n_coef, up to CH_MAXC);
+// NC != 0 also states n_approx == 1 and n_d1 == 1.
 template <typename T, int NCH, int NC>
 __global__ __launch_bounds__(256) void k_ch_stats(const T *__restrict__ x, T *__restrict__ D,
                                                   BlockGeom g, ChannelMap<T> m,
                                                   int64_t tiles_per_block) {
     constexpr int FPT = ChVec<T, NCH>::FPT, KMAX = NC ? NC : CH_MAXC;
-    const int n_coef = NC ? NC : m.n_coef;
+    const int n_coef = NC ? NC : m.n_coef, n_d1 = NC ? 1 : m.n_d1;
     const int64_t b = blockIdx.x / tiles_per_block;
-    const int64_t f0 = ((blockIdx.x % tiles_per_block) * 256 + threadIdx.x) * FPT;
+    const int64_t c0 = (blockIdx.x % tiles_per_block) * (256 * CH_CPT) + threadIdx.x;
     const int64_t frames = g.frames[b];
-    if (f0 >= frames) return;
-    const int nf = frames - f0 < FPT ? (int)(frames - f0) : FPT;
     const T *in = x + g.in_off[b];
     const bool vec = (reinterpret_cast<uintptr_t>(in) & 15) == 0;
-    T v[FPT * NCH];
-    ch_load<T, NCH>(in + f0 * NCH, v, vec, nf);
-    T *dst = D + b * g.d_stride + f0 * m.n_d1;
+    T *dblk = D + b * g.d_stride;
+    T v[CH_CPT][FPT * NCH];
+    int nf[CH_CPT];
 #pragma unroll
-    for (int f = 0; f < FPT; ++f) {
-        if (f >= nf) break;
+    for (int j = 0; j < CH_CPT; ++j) {
+        const int64_t f0 = (c0 + j * 256) * FPT;
+        nf[j] = frames - f0 >= FPT ? FPT : (frames > f0 ? (int)(frames - f0) : 0);
+        if (nf[j] > 0) ch_load<T, NCH>(in + f0 * NCH, v[j], vec, nf[j]);
+    }
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-            if (k >= n_coef - m.n_d1 && k < n_coef) {
-                T s = 0;
+    for (int j = 0; j < CH_CPT; ++j) {
+        T *dst = dblk + (c0 + j * 256) * FPT * n_d1;
 #pragma unroll
-                for (int i = 0; i < NCH; ++i) s += m.W[k][i] * v[f * NCH + i];
-                dst[f * m.n_d1 + k - (n_coef - m.n_d1)] = s;
+        for (int f = 0; f < FPT; ++f) {
+            if (f >= nf[j]) break;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+                if (k >= n_coef - n_d1 && k < n_coef) {
+                    T s = 0;
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i) s += m.W[k][i] * v[j][f * NCH + i];
+                    dst[f * n_d1 + k - (n_coef - n_d1)] = s;
+                }
             }
         }
     }
 }
 
-// Pass 2: analysis, shrink of every detail coefficient, synthesis, per frame.
 // Soft / hard shrink; binary32 uses the hardware reciprocal for t / |d| (same 0, inf and NaN cases as the
 // division: t * rcp(0) = inf -> factor clamped to 0; 0 * inf = NaN like 0 / 0).
 __device__ __forceinline__ float shrink_ch(float d, float t, int thr_mode) {
@@ -414,6 +427,7 @@ __device__ __forceinline__ float shrink_ch(float d, float t, int thr_mode) {
 }
 __device__ __forceinline__ double shrink_ch(double d, double t, int thr_mode) { return shrink(d, t, thr_mode); }
 
+// Pass 2: analysis, shrink of every detail coefficient, synthesis, per frame.
 template <typename T, int NCH, int NC>
 __global__ __launch_bounds__(256) void k_ch_apply(const T *__restrict__ x, T *__restrict__ y,
                                                   BlockGeom g, ChannelMap<T> m,
@@ -421,21 +435,28 @@ __global__ __launch_bounds__(256) void k_ch_apply(const T *__restrict__ x, T *__
                                                   const double *__restrict__ thresh, int thr_mode,
                                                   int64_t *__restrict__ zeroed) {
     constexpr int FPT = ChVec<T, NCH>::FPT, KMAX = NC ? NC : CH_MAXC;
-    const int n_coef = NC ? NC : m.n_coef;
+    const int n_coef = NC ? NC : m.n_coef, n_approx = NC ? 1 : m.n_approx;
     const int64_t b = blockIdx.x / tiles_per_block;
-    const int64_t f0 = ((blockIdx.x % tiles_per_block) * 256 + threadIdx.x) * FPT;
+    const int64_t c0 = (blockIdx.x % tiles_per_block) * (256 * CH_CPT) + threadIdx.x;
     const int64_t frames = g.frames[b];
-    const bool live = f0 < frames;
     const T t = (T)thresh[b];
+    const T *in = x + g.in_off[b];
+    T *out = y + g.out_off[b];
+    const bool vec_in = (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+    const bool vec_out = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    T v[CH_CPT][FPT * NCH];
+    int nf[CH_CPT];
+#pragma unroll
+    for (int j = 0; j < CH_CPT; ++j) {
+        const int64_t f0 = (c0 + j * 256) * FPT;
+        nf[j] = frames - f0 >= FPT ? FPT : (frames > f0 ? (int)(frames - f0) : 0);
+        if (nf[j] > 0) ch_load<T, NCH>(in + f0 * NCH, v[j], vec_in, nf[j]);
+    }
     int nz = 0;
-    if (live) {
-        const int nf = frames - f0 < FPT ? (int)(frames - f0) : FPT;
-        const T *in = x + g.in_off[b];
-        T *out = y + g.out_off[b];
-        const bool vec_in = (reinterpret_cast<uintptr_t>(in) & 15) == 0;
-        const bool vec_out = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
-        T v[FPT * NCH], o[FPT * NCH];
-        ch_load<T, NCH>(in + f0 * NCH, v, vec_in, nf);
+#pragma unroll
+    for (int j = 0; j < CH_CPT; ++j) {
+        if (nf[j] == 0) continue;
+        T o[FPT * NCH];
 #pragma unroll
         for (int f = 0; f < FPT; ++f) {
             T c[KMAX];
@@ -446,9 +467,9 @@ __global__ __launch_bounds__(256) void k_ch_apply(const T *__restrict__ x, T *__
                 T s = 0;
                 if (k < n_coef) {
 #pragma unroll
-                    for (int i = 0; i < NCH; ++i) s += m.W[k][i] * v[f * NCH + i];
-                    if (k >= m.n_approx) {
-                        nz += (f < nf && fabs(s) < t) ? 1 : 0;
+                    for (int i = 0; i < NCH; ++i) s += m.W[k][i] * v[j][f * NCH + i];
+                    if (k >= n_approx) {
+                        nz += (f < nf[j] && fabs(s) < t) ? 1 : 0;
                         s = shrink_ch(s, t, thr_mode);
                     }
                 }
@@ -461,7 +482,7 @@ __global__ __launch_bounds__(256) void k_ch_apply(const T *__restrict__ x, T *__
                     for (int i = 0; i < NCH; ++i) o[f * NCH + i] += m.V[i][k] * c[k];
                 }
         }
-        ch_store<T, NCH>(out + f0 * NCH, o, vec_out, nf);
+        ch_store<T, NCH>(out + (c0 + j * 256) * FPT * NCH, o, vec_out, nf[j]);
     }
     if (zeroed != nullptr) {
         for (int d = 32; d >= 1; d >>= 1) nz += __shfl_xor(nz, d);
@@ -516,10 +537,10 @@ static int channel_denoise(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t
     ADN_TRY(ws_reserve(c, ws_need((size_t)g.n_blocks * g.d_stride, sizeof(T)) +
                           mad_ws_bytes(g.n_blocks, max_frames * m.n_d1)));
     T *D = ws_take<T>(c, (size_t)g.n_blocks * g.d_stride);
-    const int64_t tiles = ceil_div(max_frames, 256 * ChVec<T, NCH>::FPT);
+    const int64_t tiles = ceil_div(max_frames, 256 * CH_CPT * ChVec<T, NCH>::FPT);
     dim3 grid((unsigned)(tiles * g.n_blocks)), block(256);
     // stereo at the reference's level 2 has three coefficients per frame: that shape is compiled in
-    const bool three = NCH == 2 && m.n_coef == 3;
+    const bool three = NCH == 2 && m.n_coef == 3 && m.n_approx == 1 && m.n_d1 == 1;
     if (three) hipLaunchKernelGGL((k_ch_stats<T, NCH, 3>), grid, block, 0, c->stream, d_in, D, g, m, tiles);
     else hipLaunchKernelGGL((k_ch_stats<T, NCH, 0>), grid, block, 0, c->stream, d_in, D, g, m, tiles);
     double *thresh = nullptr;

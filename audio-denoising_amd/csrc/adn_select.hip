@@ -680,6 +680,7 @@ __global__ __launch_bounds__(NT) void k_select_lds(const T *__restrict__ vals,
 // histogram for the next pass.  32-bit keys take 3 passes, 64-bit keys 6.
 static constexpr int BIG_BINS = 2048;
 static constexpr int BIG_TILE = 8192;          // elements per workgroup
+static constexpr int GATHER_TILE = 8192;       // ... of the bracket gather
 static constexpr int64_t BIG_THRESHOLD = 32768;
 
 struct BigState {            // per segment
@@ -931,6 +932,7 @@ __global__ void k_big_finish(const BigState *__restrict__ st, const int64_t *__r
 // then runs on the few gathered keys.  If the statistics fall outside the bracket (or the
 // bracket holds too many keys, e.g. a constant segment) the radix passes above run instead.
 static constexpr int BIG_SAMPLE = 4096;
+static constexpr int SAMPLE_THREADS = 256;     // threads of the sampling workgroup (one per segment)
 
 // Where the wanted ranks of a list come from.  Level 1 works on the segment itself (all null);
 // deeper levels work on the keys gathered by the previous level: the ranks are those of the
@@ -954,7 +956,7 @@ __device__ __forceinline__ bool list_ranks(const RankSrc &rs, int64_t seg, int64
 }
 
 template <typename T, int XF>
-__global__ __launch_bounds__(256) void k_big_sample(const T *__restrict__ vals, const int64_t *__restrict__ seg_off,
+__global__ __launch_bounds__(SAMPLE_THREADS) void k_big_sample(const T *__restrict__ vals, const int64_t *__restrict__ seg_off,
                                                     int64_t seg_stride, const int64_t *__restrict__ seg_len,
                                                     int64_t len_div, int64_t uniform_len,
                                                     const double *__restrict__ center, BigState *__restrict__ st,
@@ -985,13 +987,13 @@ __global__ __launch_bounds__(256) void k_big_sample(const T *__restrict__ vals, 
     // two cache lines per run instead of one line per sample)
     constexpr int RUN = 16, NRUN = BIG_SAMPLE / RUN;
     {
-        // all sixteen loads of a thread are issued before the first key is formed
-        constexpr int PER = BIG_SAMPLE / 256;
+        // all loads of a thread are issued before the first key is formed
+        constexpr int PER = BIG_SAMPLE / SAMPLE_THREADS;
         T xs[PER];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int j = tid + 256 * u;
+            const int j = tid + SAMPLE_THREADS * u;
             const int run = j / RUN, w = j % RUN;
             int64_t i = (int64_t)(((double)run + 0.5) * (double)n / (double)NRUN) - RUN / 2 + w;
             i = i < 0 ? 0 : (i < n ? i : n - 1);
@@ -1002,7 +1004,7 @@ __global__ __launch_bounds__(256) void k_big_sample(const T *__restrict__ vals, 
         for (int u = 0; u < PER; ++u) {
             T x = xs[u];
             if (XF == XF_ABSDEV) x = fabs(x - c);
-            sk[tid + 256 * u] = x != x ? ~(K)0 : key_of(x);
+            sk[tid + SAMPLE_THREADS * u] = x != x ? ~(K)0 : key_of(x);
         }
     }
     const double p = (double)r0 / (double)n;
@@ -1017,9 +1019,9 @@ __global__ __launch_bounds__(256) void k_big_sample(const T *__restrict__ vals, 
         if (rank < 0 || rank >= BIG_SAMPLE) continue;   // open end of the bracket
         K prefix = 0;
         for (int shift = BITS - 8; shift >= 0; shift -= 8) {
-            hist[tid] = 0;
+            if (tid < 256) hist[tid] = 0;
             __syncthreads();
-            for (int j = tid; j < BIG_SAMPLE; j += 256) {
+            for (int j = tid; j < BIG_SAMPLE; j += SAMPLE_THREADS) {
                 const K k = sk[j];
                 const bool match = shift == BITS - 8 || ((k ^ prefix) >> (shift + 8 < BITS ? shift + 8 : 0)) == 0;
                 if (match) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
@@ -1070,7 +1072,7 @@ __global__ __launch_bounds__(256) void k_big_gather(const T *__restrict__ vals, 
     __shared__ int s_nan;
     const int64_t seg = blockIdx.x / tiles_per_seg, tile = blockIdx.x % tiles_per_seg;
     const int64_t n = seg_len ? seg_len[seg / len_div] : uniform_len;
-    const int64_t i0 = tile * BIG_TILE;
+    const int64_t i0 = tile * GATHER_TILE;
     if (i0 >= n) return;
     const K lo = (K)st[seg].lo, hi = (K)st[seg].hi;
     if (lo > hi) return;
@@ -1087,48 +1089,79 @@ __global__ __launch_bounds__(256) void k_big_gather(const T *__restrict__ vals, 
     unsigned int below = 0;
     bool saw_nan = false, spilled = false;
     // batches of BATCH elements per thread: all loads of a batch are in flight together, the
-    // keep decisions are one bit each, and a wave appends with ONE LDS atomic per batch
-    constexpr int BATCH = 16;
-    for (int b0 = 0; b0 < BIG_TILE / 256; b0 += BATCH) {
+    // keep decisions are one bit each, and a wave appends with ONE LDS atomic per batch.
+    // A tile that lies inside its segment and starts on a 16-byte boundary takes 16-byte loads
+    // and no bounds checks (the order of the gathered keys does not matter).
+    constexpr int BATCH = 32, VEC = 16 / (int)sizeof(T);
+    const bool full = i0 + GATHER_TILE <= n && (reinterpret_cast<uintptr_t>(v + i0) & 15) == 0;
+    for (int b0 = 0; b0 < GATHER_TILE / 256; b0 += BATCH) {
         if (i0 + (int64_t)b0 * 256 >= n) break;
         T xs[BATCH];
-        unsigned int keepmask = 0;
+        bool keep[BATCH];
+        if (full) {
+            const float4 *v4 = reinterpret_cast<const float4 *>(v + i0 + (int64_t)b0 * 256);
+            float4 q[BATCH / VEC];
+#pragma unroll
+            for (int u = 0; u < BATCH / VEC; ++u) q[u] = v4[u * 256 + tid];
+#pragma unroll
+            for (int u = 0; u < BATCH / VEC; ++u) {
+                const T *e = reinterpret_cast<const T *>(&q[u]);
+#pragma unroll
+                for (int w = 0; w < VEC; ++w) xs[u * VEC + w] = e[w];
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                T x = xs[u];
+                if (XF == XF_ABSDEV) x = fabs(x - c);
+                xs[u] = x;
+                saw_nan |= (x != x);
+                const K k = x != x ? ~(K)0 : key_of(x);
+                below += (k < lo);
+                keep[u] = (K)(k - lo) <= (K)(hi - lo);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int64_t i = i0 + (int64_t)(b0 + u) * 256 + tid;
+                xs[u] = i < n ? v[i] : (T)0;
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const int64_t i = i0 + (int64_t)(b0 + u) * 256 + tid;
+                const bool in = i < n;
+                T x = xs[u];
+                if (XF == XF_ABSDEV) x = fabs(x - c);
+                xs[u] = x;
+                saw_nan |= in && (x != x);
+                const K k = x != x ? ~(K)0 : key_of(x);
+                below += (in && k < lo);
+                keep[u] = in && k >= lo && k <= hi;
+            }
+        }
+        // positions from wave ballots (no cross-lane round trips): key u of lane l goes after the
+        // kept keys u' < u of the whole wave and the kept keys u of the lanes below l
+        unsigned long long bal[BATCH];
+        unsigned int total = 0;
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            const int64_t i = i0 + (int64_t)(b0 + u) * 256 + tid;
-            xs[u] = i < n ? v[i] : (T)0;
+            bal[u] = __ballot(keep[u]);
+            total += (unsigned int)__popcll(bal[u]);
         }
-#pragma unroll
-        for (int u = 0; u < BATCH; ++u) {
-            const int64_t i = i0 + (int64_t)(b0 + u) * 256 + tid;
-            const bool in = i < n;
-            T x = xs[u];
-            if (XF == XF_ABSDEV) x = fabs(x - c);
-            xs[u] = x;
-            saw_nan |= in && (x != x);
-            const K k = x != x ? ~(K)0 : key_of(x);
-            below += (in && k < lo);
-            keepmask |= (in && k >= lo && k <= hi) ? (1u << u) : 0u;
-        }
-        const unsigned int cnt = __popc(keepmask);
-        unsigned int incl = cnt;
-        for (int d = 1; d < 64; d <<= 1) {
-            const unsigned int o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
-        const unsigned int total = __shfl(incl, 63);
         if (total == 0) continue;
         unsigned int base = 0;
-        if (lane == 63) base = atomicAdd(&s_fill, total);
-        base = __shfl(base, 63);
-        unsigned int pos = base + incl - cnt;
+        if (lane == 0) base = atomicAdd(&s_fill, total);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base + total <= STAGE) {
 #pragma unroll
-        for (int u = 0; u < BATCH; ++u)
-            if (keepmask & (1u << u)) {
-                if (pos < STAGE) stage[pos] = xs[u];
-                else spilled = true;                 // far more candidates than a bracket should hold
-                ++pos;
+            for (int u = 0; u < BATCH; ++u) {
+                if (keep[u])
+                    stage[base + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal[u] >> 32),
+                                                           __builtin_amdgcn_mbcnt_lo((unsigned int)bal[u], 0u))] = xs[u];
+                base += (unsigned int)__popcll(bal[u]);
             }
+        } else {
+            spilled = true;                          // far more candidates than a bracket should hold
+        }
     }
     for (int d = 32; d >= 1; d >>= 1) below += __shfl_xor(below, d);
     if (lane == 0 && below) atomicAdd(&s_below, (unsigned long long)below);
@@ -1266,20 +1299,22 @@ static int launch_select_big(Ctx *c, const T *d_vals, const SelectArgs &a) {
     // not fit LDS), then the exact selection over the last list
     {
         const RankSrc none{nullptr, 1, 0, nullptr, nullptr};
-        hipLaunchKernelGGL((k_big_sample<T, XF>), dim3((unsigned)a.n_seg), dim3(256), 0, c->stream, d_vals, a.d_seg_off,
+        hipLaunchKernelGGL((k_big_sample<T, XF>), dim3((unsigned)a.n_seg), dim3(SAMPLE_THREADS), 0, c->stream, d_vals, a.d_seg_off,
                            a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len, a.d_center, st, a.mode, a.q, none);
-        hipLaunchKernelGGL((k_big_gather<T, XF>), dim3((unsigned)(a.n_seg * tiles)), dim3(256), 0, c->stream, d_vals,
+        const int64_t gtiles = ceil_div(a.max_len, GATHER_TILE);
+        ADN_REQUIRE(a.n_seg * gtiles < (int64_t)0x7FFFFFFF, "select batch too large for one launch");
+        hipLaunchKernelGGL((k_big_gather<T, XF>), dim3((unsigned)(a.n_seg * gtiles)), dim3(256), 0, c->stream, d_vals,
                            a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len, a.d_center, st, cand_l[0],
-                           caps[0], tiles);
+                           caps[0], gtiles);
         hipLaunchKernelGGL(k_big_check, dim3(nb), dim3(256), 0, c->stream, st, a.d_seg_len, a.len_div, a.uniform_len,
                            a.n_seg, a.mode, a.q, caps[0], none, len_l[0], valid_l[0], below_l[0], lohi_l[0]);
     }
     for (int l = 1; l < n_levels; ++l) {
         const RankSrc rs{a.d_seg_len, a.len_div, a.uniform_len, below_l[l - 1], valid_l[l - 1]};
-        const int64_t ltiles = ceil_div(caps[l - 1], BIG_TILE);
+        const int64_t ltiles = ceil_div(caps[l - 1], GATHER_TILE);
         ADN_REQUIRE(a.n_seg * ltiles < (int64_t)0x7FFFFFFF, "select batch too large for one launch");
         hipLaunchKernelGGL(k_big_init_level, dim3(nb), dim3(256), 0, c->stream, st_l[l], a.n_seg);
-        hipLaunchKernelGGL((k_big_sample<T, XF_NONE>), dim3((unsigned)a.n_seg), dim3(256), 0, c->stream, cand_l[l - 1],
+        hipLaunchKernelGGL((k_big_sample<T, XF_NONE>), dim3((unsigned)a.n_seg), dim3(SAMPLE_THREADS), 0, c->stream, cand_l[l - 1],
                            (const int64_t *)nullptr, caps[l - 1], len_l[l - 1], (int64_t)1, (int64_t)0,
                            (const double *)nullptr, st_l[l], a.mode, a.q, rs);
         hipLaunchKernelGGL((k_big_gather<T, XF_NONE>), dim3((unsigned)(a.n_seg * ltiles)), dim3(256), 0, c->stream,
