@@ -380,6 +380,7 @@ template <typename T, int NCH, int NC>
 __global__ __launch_bounds__(256) void k_ch_stats(const T *__restrict__ x, T *__restrict__ D,
                                                   BlockGeom g, ChannelMap<T> m,
                                                   int64_t tiles_per_block) {
+#pragma clang fp contract(off)     // products and sums rounded one by one, like the single-pass statistics
     constexpr int FPT = ChVec<T, NCH>::FPT, KMAX = NC ? NC : CH_MAXC;
     const int n_coef = NC ? NC : m.n_coef, n_d1 = NC ? 1 : m.n_d1;
     const int64_t b = blockIdx.x / tiles_per_block;
@@ -528,24 +529,31 @@ static size_t mad_ws_bytes(int64_t n_blocks, int64_t max_seg) {
 }
 
 #include "adn_dwt_tiles.hpp"
+#include "adn_dwt_mad1p.hpp"
 
 template <typename T, int NCH>
 static int channel_denoise(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_frames,
                            const ChannelMap<T> &m, int thr_mode, double *d_sigma,
                            double *d_thresh, int64_t *d_zeroed) {
     g.d_stride = max_frames * m.n_d1;
-    ADN_TRY(ws_reserve(c, ws_need((size_t)g.n_blocks * g.d_stride, sizeof(T)) +
-                          mad_ws_bytes(g.n_blocks, max_frames * m.n_d1)));
-    T *D = ws_take<T>(c, (size_t)g.n_blocks * g.d_stride);
     const int64_t tiles = ceil_div(max_frames, 256 * CH_CPT * ChVec<T, NCH>::FPT);
     dim3 grid((unsigned)(tiles * g.n_blocks)), block(256);
     // stereo at the reference's level 2 has three coefficients per frame: that shape is compiled in
     const bool three = NCH == 2 && m.n_coef == 3 && m.n_approx == 1 && m.n_d1 == 1;
-    if (three) hipLaunchKernelGGL((k_ch_stats<T, NCH, 3>), grid, block, 0, c->stream, d_in, D, g, m, tiles);
-    else hipLaunchKernelGGL((k_ch_stats<T, NCH, 0>), grid, block, 0, c->stream, d_in, D, g, m, tiles);
     double *thresh = nullptr;
-    ADN_TRY(mad_threshold<T>(c, D, g, 8, ADN_EXT_PERIODIZATION, m.n_d1, max_frames * m.n_d1,
-                             d_sigma, d_thresh, &thresh));
+    if (three && m1_applicable<T>(c, max_frames)) {
+        // threshold statistics in one pass over the input, no coefficient array
+        ADN_TRY(ws_reserve(c, m1_ws_bytes<T>(g.n_blocks, max_frames)));
+        ADN_TRY(stereo_mad_single_pass<T>(c, d_in, g, max_frames, m.W[2][0], m.W[2][1], d_sigma, d_thresh, &thresh));
+    } else {
+        ADN_TRY(ws_reserve(c, ws_need((size_t)g.n_blocks * g.d_stride, sizeof(T)) +
+                              mad_ws_bytes(g.n_blocks, max_frames * m.n_d1)));
+        T *D = ws_take<T>(c, (size_t)g.n_blocks * g.d_stride);
+        if (three) hipLaunchKernelGGL((k_ch_stats<T, NCH, 3>), grid, block, 0, c->stream, d_in, D, g, m, tiles);
+        else hipLaunchKernelGGL((k_ch_stats<T, NCH, 0>), grid, block, 0, c->stream, d_in, D, g, m, tiles);
+        ADN_TRY(mad_threshold<T>(c, D, g, 8, ADN_EXT_PERIODIZATION, m.n_d1, max_frames * m.n_d1,
+                                 d_sigma, d_thresh, &thresh));
+    }
     if (three)
         hipLaunchKernelGGL((k_ch_apply<T, NCH, 3>), grid, block, 0, c->stream, d_in, d_out, g, m, tiles, thresh,
                            thr_mode, d_zeroed);

@@ -1,0 +1,640 @@
+// Threshold statistics of stereo blocks in ONE pass over the input (included by adn_dwt.hip).
+//
+// The reference's threshold is sigma * sqrt(2 ln n) with sigma = median(|d - median(d)|) over the
+// finest detail coefficients d of a block (denoise.py:16-23, 80-83).  For a stereo block at level 2
+// every frame has one such coefficient, d = w0 * left + w1 * right.  The two medians are nested, so
+// the plain route materialises d and selects twice (three passes over it).  Here:
+//
+//   1. k_m1_sample: a stratified sample of S coefficients per block (runs of 16 consecutive frames)
+//      gives (a) a key bracket [lo_m, hi_m] that holds the block's median ranks with probability
+//      ~ 1 - 1e-5 and (b), with m^ = the bracket's midpoint, a value bracket [alo, ahi] for
+//      |d - m^| that holds the ranks of the absolute deviation, widened by the largest possible
+//      |median - m^| so that it still holds them once the true median is known.
+//   2. k_m1_gather: one pass over the block: coefficients on the fly, keys below each bracket
+//      counted, keys inside gathered (~2.5 % and ~6.5 % of the block).
+//   3. Exact selection among the gathered keys (LDS radix select with rank offsets): the median,
+//      then |d - median| of the second list.
+//   4. k_m1_verify proves the second selection: both order statistics must lie inside
+//      (alo + e, ahi - e) with e = |median - m^| + rounding slack; then every key counted as
+//      "below" really is below them and every key left out above really is above.
+//   5. k_m1_fallback: blocks that fail any check (bracket missed, list overflow, constant or
+//      non-finite data) are selected exactly by one workgroup streaming the block (radix passes
+//      over the on-the-fly coefficients).  Resolved blocks cost it one early exit.
+//
+// Every result is an exact order statistic of the same multiset the plain route selects from.
+#pragma once
+
+template <typename T>
+struct M1 {
+    using K = typename KeyT<T>::type;
+    static constexpr int S = (int)((128 * 1024) / sizeof(K));          // sample keys per block (LDS resident)
+    static constexpr double FRAC_M = sizeof(T) == 4 ? 0.04 : 0.06;     // list capacities as fractions of the block
+    static constexpr double FRAC_A = sizeof(T) == 4 ? 0.10 : 0.14;
+};
+static constexpr int M1_THREADS = 1024;     // sample / fallback workgroups
+static constexpr int M1_RUN = 16;           // consecutive frames per sample run
+static constexpr int M1_BINS = 2048;        // 11-bit digits
+static constexpr int M1_TILE = 4096;        // frames per gather workgroup (256 threads x 16)
+
+struct M1State {                  // per block
+    unsigned long long lo_m, hi_m;    // key bracket of the median (lo > hi: unusable)
+    double mhat;                      // centre estimate, a value of the block's dtype
+    double alo, ahi;                  // value bracket of |d - mhat| (alo < 0: open below, ahi = inf: open above)
+    unsigned long long below_m, below_a;
+    unsigned int n_m, n_a;            // keys gathered (may exceed the capacity: overflow)
+    int has_nan, usable;
+};
+
+template <typename T>
+__device__ __forceinline__ T m1_d1(T w0, T w1, T v0, T v1) {
+#pragma clang fp contract(off)     // two rounded products and one rounded sum everywhere the coefficient is formed
+    T s = 0;
+    s += w0 * v0;
+    s += w1 * v1;
+    return s;
+}
+template <typename T>
+__device__ __forceinline__ typename KeyT<T>::type m1_key(T x) {
+    using K = typename KeyT<T>::type;
+    return x != x ? ~(K)0 : key_of(x);
+}
+
+// One atomic per group of equal digits in a wave (constant or narrow data would serialise otherwise).
+__device__ __forceinline__ void m1_hist_add(uint32_t *hist, uint32_t digit, int nbits, bool active) {
+    unsigned long long m = __ballot(active);
+    for (int b = 0; b < nbits; ++b) {
+        const bool bit = (digit >> b) & 1u;
+        const unsigned long long bm = __ballot(bit);
+        m &= bit ? bm : ~bm;
+    }
+    if (active && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&hist[digit], (uint32_t)__popcll(m));
+}
+
+// Bin of `rank` in a histogram of M1_BINS counters: all M1_THREADS threads, two bins each.
+// Returns through dig / bef (LDS words) the bin and the count of keys in lower bins.
+__device__ __forceinline__ void m1_find_bin(const uint32_t *hist, uint32_t rank, uint32_t *wtot, uint32_t *dig,
+                                            uint32_t *bef) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t c0 = hist[2 * tid], c1 = hist[2 * tid + 1], sum = c0 + c1;
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += wtot[w];
+    incl += base;
+    const uint32_t excl = incl - sum;
+    if (excl <= rank && rank < incl) {
+        const bool second = rank >= excl + c0;
+        *dig = (uint32_t)(2 * tid + (second ? 1 : 0));
+        *bef = excl + (second ? c0 : 0u);
+    }
+    __syncthreads();
+}
+
+// Keys of sample ranks ra <= rb among the S keys in LDS: 11-bit MSD radix selection on key - kmin,
+// both ranks in the same sweeps (a second histogram once their prefixes part).
+template <typename K, int S>
+__device__ void m1_select2(const K *sk, K kmin, K kmax, uint32_t ra, uint32_t rb, uint32_t (*hist)[M1_BINS],
+                           uint32_t (*wtot)[M1_THREADS / 64], uint32_t *s_dig, uint32_t *s_bef, K *ka, K *kb) {
+    constexpr int BITS = (int)sizeof(K) * 8;
+    const int tid = threadIdx.x;
+    const K width = kmax - kmin;
+    const int bits = width ? BITS - (BITS == 64 ? __clzll((long long)width) : __clz((int)width)) : 0;
+    const int passes = (bits + 10) / 11;
+    K pa = 0, pb = 0;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = 11 * (passes - 1 - p);
+        const bool same = pa == pb;
+        for (int i = tid; i < 2 * M1_BINS; i += M1_THREADS) (&hist[0][0])[i] = 0;
+        __syncthreads();
+        for (int j = tid; j < S; j += M1_THREADS) {
+            const K u = sk[j] - kmin;
+            const K top = p == 0 ? (K)0 : (K)(u >> (shift + 11));
+            const uint32_t digit = (uint32_t)(u >> shift) & (M1_BINS - 1);
+            if (top == pa) atomicAdd(&hist[0][digit], 1u);
+            if (!same && top == pb) atomicAdd(&hist[1][digit], 1u);
+        }
+        __syncthreads();
+        m1_find_bin(hist[0], ra, wtot[0], &s_dig[0], &s_bef[0]);
+        m1_find_bin(hist[same ? 0 : 1], rb, wtot[1], &s_dig[1], &s_bef[1]);
+        pa = (pa << 11) | (K)s_dig[0];
+        pb = (pb << 11) | (K)s_dig[1];
+        ra -= s_bef[0];
+        rb -= s_bef[1];
+        __syncthreads();
+    }
+    *ka = kmin + pa;
+    *kb = kmin + pb;
+}
+
+template <typename T>
+__global__ __launch_bounds__(M1_THREADS) void k_m1_sample(const T *__restrict__ x, BlockGeom g, T w0, T w1,
+                                                          M1State *__restrict__ st) {
+    using K = typename KeyT<T>::type;
+    constexpr int S = M1<T>::S, PER = S / M1_THREADS, NRUN = S / M1_RUN;
+    extern __shared__ __align__(16) unsigned char smem[];
+    K *sk = reinterpret_cast<K *>(smem);
+    __shared__ uint32_t hist[2][M1_BINS];
+    __shared__ uint32_t wtot[2][M1_THREADS / 64];
+    __shared__ uint32_t s_dig[2], s_bef[2];
+    __shared__ K s_kmin, s_kmax;
+    const int64_t b = blockIdx.x;
+    const int64_t n = g.frames[b];
+    const int tid = threadIdx.x, lane = tid & 63;
+    M1State s{};
+    if (n <= S) {
+        // short block: every coefficient is a candidate of both selections
+        if (tid == 0) {
+            s.lo_m = 0;
+            s.hi_m = ~0ull;
+            s.mhat = 0.0;
+            s.alo = -1.0;
+            s.ahi = __longlong_as_double(0x7FF0000000000000ll);
+            s.usable = 1;
+            st[b] = s;
+        }
+        return;
+    }
+    const T *in = x + g.in_off[b];
+    if (tid == 0) {
+        s_kmin = ~(K)0;
+        s_kmax = 0;
+    }
+    __syncthreads();
+    K tmin = ~(K)0, tmax = 0;
+    {
+        T v0[PER], v1[PER];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int j = tid + M1_THREADS * u;
+            const int run = j / M1_RUN, w = j % M1_RUN;
+            int64_t i = (int64_t)(((double)run + 0.5) * (double)n / (double)NRUN) - M1_RUN / 2 + w;
+            i = i < 0 ? 0 : (i < n ? i : n - 1);
+            v0[u] = in[2 * i];
+            v1[u] = in[2 * i + 1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const K k = m1_key(m1_d1(w0, w1, v0[u], v1[u]));
+            sk[tid + M1_THREADS * u] = k;
+            tmin = k < tmin ? k : tmin;
+            tmax = k > tmax ? k : tmax;
+        }
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const K a = __shfl_xor(tmin, d), c = __shfl_xor(tmax, d);
+        tmin = a < tmin ? a : tmin;
+        tmax = c > tmax ? c : tmax;
+    }
+    if (lane == 0) {
+        atomicMin(&s_kmin, tmin);
+        atomicMax(&s_kmax, tmax);
+    }
+    __syncthreads();
+    // sample ranks that bracket the block's median ranks (4.5 sigma of the binomial + 3)
+    const int64_t r0 = (n - 1) / 2;
+    const int delta = (int)(4.5 * sqrt((double)S * 0.25)) + 3;
+    const int rs = (int)((double)r0 * (double)S / (double)n);
+    int want_lo = rs - delta, want_hi = rs + delta + 1;
+    const bool open_lo = want_lo < 0, open_hi = want_hi >= S;
+    want_lo = open_lo ? 0 : want_lo;
+    want_hi = open_hi ? S - 1 : want_hi;
+    K klo, khi;
+    m1_select2<K, S>(sk, s_kmin, s_kmax, (uint32_t)want_lo, (uint32_t)want_hi, hist, wtot, s_dig, s_bef, &klo, &khi);
+    const T lo_v = val_of(klo), hi_v = val_of(khi);
+    const bool finite = klo != ~(K)0 && khi != ~(K)0 && fabs(lo_v) <= (T)1e30 && fabs(hi_v) <= (T)1e30;
+    if (!finite || open_lo || open_hi || klo == khi) {
+        // non-finite or (nearly) constant data, or a degenerate sample: the exact fallback takes the block
+        if (tid == 0) {
+            s.lo_m = 1;
+            s.hi_m = 0;
+            s.alo = 1.0;
+            s.ahi = 0.0;
+            s.usable = 0;
+            st[b] = s;
+        }
+        return;
+    }
+    const T mhat = lo_v + (hi_v - lo_v) / (T)2;
+    const double eps_v = fmax((double)hi_v - (double)mhat, (double)mhat - (double)lo_v);
+    // the same sample as |d - mhat|
+    __syncthreads();
+    if (tid == 0) {
+        s_kmin = ~(K)0;
+        s_kmax = 0;
+    }
+    __syncthreads();
+    tmin = ~(K)0;
+    tmax = 0;
+    for (int j = tid; j < S; j += M1_THREADS) {
+        const K kk = sk[j];
+        const K k = kk == ~(K)0 ? kk : m1_key((T)fabs(val_of(kk) - mhat));
+        sk[j] = k;
+        tmin = k < tmin ? k : tmin;
+        tmax = k > tmax ? k : tmax;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        const K a = __shfl_xor(tmin, d), c = __shfl_xor(tmax, d);
+        tmin = a < tmin ? a : tmin;
+        tmax = c > tmax ? c : tmax;
+    }
+    if (lane == 0) {
+        atomicMin(&s_kmin, tmin);
+        atomicMax(&s_kmax, tmax);
+    }
+    __syncthreads();
+    K kalo, kahi;
+    m1_select2<K, S>(sk, s_kmin, s_kmax, (uint32_t)want_lo, (uint32_t)want_hi, hist, wtot, s_dig, s_bef, &kalo, &kahi);
+    if (tid == 0) {
+        const double eps_t = sizeof(T) == 4 ? 1.1920929e-7 : 2.220446049250313e-16;
+        const bool open_above = kahi == ~(K)0 || !(fabs(val_of(kahi)) <= (T)1e30);
+        const double a_lo = (double)val_of(kalo), a_hi = open_above ? 0.0 : (double)val_of(kahi);
+        const double slop = 16.0 * eps_t * (a_hi + fabs((double)mhat) + eps_v) + 1e-300;
+        const double alo = a_lo - eps_v - slop, ahi = a_hi + eps_v + slop;
+        s.lo_m = (unsigned long long)klo;
+        s.hi_m = (unsigned long long)khi;
+        s.mhat = (double)mhat;
+        s.alo = alo <= 0.0 ? -1.0 : (double)(T)alo;
+        s.ahi = open_above ? __longlong_as_double(0x7FF0000000000000ll) : (double)(T)ahi;
+        s.usable = 1;
+        st[b] = s;
+    }
+}
+
+// One pass over the blocks: keys below each bracket counted, keys inside gathered.
+template <typename T>
+__global__ __launch_bounds__(256) void k_m1_gather(const T *__restrict__ x, BlockGeom g, T w0, T w1,
+                                                   M1State *__restrict__ st, T *__restrict__ cand_m, int64_t cap_m,
+                                                   T *__restrict__ cand_a, int64_t cap_a, int64_t tiles_per_block) {
+    using K = typename KeyT<T>::type;
+    constexpr int BATCH = 16;                               // frames per thread
+    constexpr int FPL = (16 / (int)sizeof(T)) / 2;          // frames per 16-byte load
+    constexpr int NL = BATCH / FPL;
+    __shared__ T stage_m[M1_TILE], stage_a[M1_TILE];
+    __shared__ unsigned long long s_below_m, s_below_a;
+    __shared__ unsigned int s_fill_m, s_fill_a, s_base_m, s_base_a;
+    __shared__ int s_nan;
+    const int64_t b = blockIdx.x / tiles_per_block, tile = blockIdx.x % tiles_per_block;
+    const int64_t n = g.frames[b];
+    const int64_t f0 = tile * M1_TILE;
+    if (f0 >= n) return;
+    const K lo = (K)st[b].lo_m, hi = (K)st[b].hi_m;
+    if (lo > hi) return;
+    const T mhat = (T)st[b].mhat, alo = (T)st[b].alo, ahi = (T)st[b].ahi;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0) {
+        s_below_m = 0;
+        s_below_a = 0;
+        s_fill_m = 0;
+        s_fill_a = 0;
+        s_nan = 0;
+    }
+    __syncthreads();
+    const T *in = x + g.in_off[b] + 2 * f0;
+    T d[BATCH];
+    bool live[BATCH];
+    const bool full = f0 + M1_TILE <= n && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
+    if (full) {
+        const float4 *v4 = reinterpret_cast<const float4 *>(in);
+        float4 q[NL];
+#pragma unroll
+        for (int u = 0; u < NL; ++u) q[u] = v4[u * 256 + tid];
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const T *e = reinterpret_cast<const T *>(&q[u]);
+#pragma unroll
+            for (int f = 0; f < FPL; ++f) {
+                d[u * FPL + f] = m1_d1(w0, w1, e[2 * f], e[2 * f + 1]);
+                live[u * FPL + f] = true;
+            }
+        }
+    } else {
+        T v0[BATCH], v1[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int64_t f = (int64_t)u * 256 + tid;
+            live[u] = f0 + f < n;
+            v0[u] = live[u] ? in[2 * f] : (T)0;
+            v1[u] = live[u] ? in[2 * f + 1] : (T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) d[u] = m1_d1(w0, w1, v0[u], v1[u]);
+    }
+    unsigned int below_m = 0, below_a = 0;
+    bool saw_nan = false;
+    // ---- median bracket (keys)
+    {
+        bool keep[BATCH];
+        unsigned long long bal[BATCH];
+        unsigned int total = 0;
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const T xv = d[u];
+            saw_nan |= live[u] && (xv != xv);
+            const K k = m1_key(xv);
+            below_m += (live[u] && k < lo);
+            keep[u] = live[u] && (K)(k - lo) <= (K)(hi - lo);
+            bal[u] = __ballot(keep[u]);
+            total += (unsigned int)__popcll(bal[u]);
+        }
+        if (total) {
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(&s_fill_m, total);
+            base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                if (keep[u])
+                    stage_m[base + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal[u] >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo((unsigned int)bal[u], 0u))] = d[u];
+                base += (unsigned int)__popcll(bal[u]);
+            }
+        }
+    }
+    // ---- absolute-deviation bracket (values of |d - mhat|); the coefficient itself is gathered
+    {
+        bool keep[BATCH];
+        unsigned long long bal[BATCH];
+        unsigned int total = 0;
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const T a = fabs(d[u] - mhat);
+            below_a += (live[u] && a < alo);
+            keep[u] = live[u] && a >= alo && a <= ahi;
+            bal[u] = __ballot(keep[u]);
+            total += (unsigned int)__popcll(bal[u]);
+        }
+        if (total) {
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(&s_fill_a, total);
+            base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                if (keep[u])
+                    stage_a[base + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal[u] >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo((unsigned int)bal[u], 0u))] = d[u];
+                base += (unsigned int)__popcll(bal[u]);
+            }
+        }
+    }
+    for (int dd = 32; dd >= 1; dd >>= 1) {
+        below_m += __shfl_xor(below_m, dd);
+        below_a += __shfl_xor(below_a, dd);
+    }
+    if (lane == 0) {
+        if (below_m) atomicAdd(&s_below_m, (unsigned long long)below_m);
+        if (below_a) atomicAdd(&s_below_a, (unsigned long long)below_a);
+    }
+    if (saw_nan) s_nan = 1;
+    __syncthreads();
+    const unsigned int cm = s_fill_m, ca = s_fill_a;
+    if (tid == 0) {
+        s_base_m = cm ? atomicAdd(&st[b].n_m, cm) : 0u;
+        s_base_a = ca ? atomicAdd(&st[b].n_a, ca) : 0u;
+        if (s_below_m) atomicAdd(&st[b].below_m, s_below_m);
+        if (s_below_a) atomicAdd(&st[b].below_a, s_below_a);
+        if (s_nan) st[b].has_nan = 1;
+    }
+    __syncthreads();
+    {
+        const int64_t base = s_base_m;
+        T *dst = cand_m + b * cap_m;
+        for (unsigned int p = tid; p < cm; p += 256)
+            if (base + p < cap_m) dst[base + p] = stage_m[p];      // beyond the capacity: seen by n_m > cap_m
+    }
+    {
+        const int64_t base = s_base_a;
+        T *dst = cand_a + b * cap_a;
+        for (unsigned int p = tid; p < ca; p += 256)
+            if (base + p < cap_a) dst[base + p] = stage_a[p];
+    }
+}
+
+// Per block: are the wanted ranks inside the gathered lists?  Descriptors for the two selections.
+__global__ void k_m1_check(const M1State *st, const int64_t *frames, int64_t n_blocks, int64_t cap_m, int64_t cap_a,
+                           int64_t *len_m, int64_t *len_a, unsigned long long *below_m, unsigned long long *below_a,
+                           int *valid_m, int *valid_a, int *resolved, double *med, double *mad) {
+    const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const M1State s = st[b];
+    const int64_t n = frames[b], r0 = (n - 1) / 2, r1 = n / 2;
+    const double nan = __longlong_as_double(0x7FF8000000000000ll);
+    const bool ok_m = s.usable && !s.has_nan && (int64_t)s.n_m <= cap_m && r0 >= (int64_t)s.below_m &&
+                      r1 - (int64_t)s.below_m < (int64_t)s.n_m;
+    const bool ok_a = ok_m && (int64_t)s.n_a <= cap_a && r0 >= (int64_t)s.below_a &&
+                      r1 - (int64_t)s.below_a < (int64_t)s.n_a;
+    len_m[b] = ok_m ? (int64_t)s.n_m : 0;
+    len_a[b] = ok_a ? (int64_t)s.n_a : 0;
+    below_m[b] = s.below_m;
+    below_a[b] = s.below_a;
+    valid_m[b] = ok_m ? 1 : 0;
+    valid_a[b] = ok_a ? 1 : 0;
+    // a NaN anywhere in the block: both medians are NaN (numpy), nothing left to select
+    const bool is_nan = s.usable && s.has_nan;
+    resolved[b] = is_nan ? 1 : 0;
+    med[b] = nan;
+    mad[b] = nan;
+}
+
+// Per block: does the second selection stand now that the median is known?
+template <typename T>
+__global__ void k_m1_verify(const M1State *st, int64_t n_blocks, const int *valid_a, const double *med,
+                            const double *pair_a, int *resolved) {
+    const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (b >= n_blocks || resolved[b] || !valid_a[b]) return;
+    const M1State s = st[b];
+    const double eps_t = sizeof(T) == 4 ? 1.1920929e-7 : 2.220446049250313e-16;
+    const double c = (double)(T)med[b];
+    const double t0 = pair_a[2 * b], t1 = pair_a[2 * b + 1];
+    const double span = fabs(t1) + fabs(c) + fabs(s.mhat) + (s.ahi <= 1.7e308 ? fabs(s.ahi) : 0.0);
+    const double e = fabs(c - s.mhat) * (1.0 + 4.0 * eps_t) + 8.0 * eps_t * span + 1e-300;
+    const bool ok_lo = s.alo < 0.0 || t0 > s.alo + e;
+    const bool ok_hi = !(s.ahi <= 1.7e308) || t1 < s.ahi - e;
+    if (ok_lo && ok_hi && t0 == t0 && t1 == t1) resolved[b] = 1;
+}
+
+// Exact fallback: one workgroup per unresolved block, 8-bit MSD radix passes over the coefficients
+// computed on the fly.  Returns the key of `rank`; *nan_seen is set when the block holds a NaN.
+template <typename T>
+__device__ typename KeyT<T>::type m1_slow_rank(const T *in, int64_t n, T w0, T w1, bool absdev, T c, uint64_t rank,
+                                               uint32_t *hist, uint32_t *s_dig, uint32_t *s_bef, int *nan_seen) {
+    using K = typename KeyT<T>::type;
+    constexpr int BITS = KeyT<T>::bits;
+    const int tid = threadIdx.x;
+    K prefix = 0;
+    for (int shift = BITS - 8; shift >= 0; shift -= 8) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const int64_t n_pad = (n + M1_THREADS - 1) / M1_THREADS * M1_THREADS;     // whole waves take every step
+        for (int64_t i = tid; i < n_pad; i += M1_THREADS) {
+            const bool in_range = i < n;
+            T v = 0;
+            if (in_range) v = m1_d1(w0, w1, in[2 * i], in[2 * i + 1]);
+            if (absdev) v = fabs(v - c);
+            const K k = m1_key(v);
+            if (in_range && k == ~(K)0) *nan_seen = 1;
+            const bool match = in_range && (shift == BITS - 8 || (K)((k ^ prefix) >> (shift + 8 < BITS ? shift + 8 : 0)) == 0);
+            m1_hist_add(hist, (uint32_t)(k >> shift) & 255u, 8, match);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+            const uint32_t sum = c0 + c1 + c2 + c3;
+            uint32_t incl = sum;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if (tid >= d) incl += o;
+            }
+            const unsigned long long m = __ballot((uint64_t)incl > rank);
+            if (m && tid == (int)__ffsll((unsigned long long)m) - 1) {
+                uint32_t r = (uint32_t)rank - (incl - sum);
+                int dgt = 4 * tid;
+                uint32_t bef = incl - sum;
+                if (r >= c0) { r -= c0; bef += c0; ++dgt;
+                    if (r >= c1) { r -= c1; bef += c1; ++dgt;
+                        if (r >= c2) { r -= c2; bef += c2; ++dgt; } } }
+                *s_dig = (uint32_t)dgt;
+                *s_bef = bef;
+            }
+        }
+        __syncthreads();
+        prefix |= (K)(*s_dig) << shift;
+        rank -= *s_bef;
+        __syncthreads();
+    }
+    return prefix;
+}
+
+template <typename T>
+__global__ __launch_bounds__(M1_THREADS) void k_m1_fallback(const T *__restrict__ x, BlockGeom g, T w0, T w1,
+                                                            const int *__restrict__ resolved, double *med, double *mad) {
+    using K = typename KeyT<T>::type;
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_dig, s_bef;
+    __shared__ int s_nan;
+    const int64_t b = blockIdx.x;
+    if (resolved[b]) return;
+    const int64_t n = g.frames[b];
+    const T *in = x + g.in_off[b];
+    const double nan = __longlong_as_double(0x7FF8000000000000ll);
+    if (threadIdx.x == 0) s_nan = 0;
+    __syncthreads();
+    if (n <= 0) {
+        if (threadIdx.x == 0) {
+            med[b] = nan;
+            mad[b] = nan;
+        }
+        return;
+    }
+    const uint64_t r0 = (uint64_t)((n - 1) / 2), r1 = (uint64_t)(n / 2);
+    const K k0 = m1_slow_rank<T>(in, n, w0, w1, false, (T)0, r0, hist, &s_dig, &s_bef, &s_nan);
+    const K k1 = r1 == r0 ? k0 : m1_slow_rank<T>(in, n, w0, w1, false, (T)0, r1, hist, &s_dig, &s_bef, &s_nan);
+    __syncthreads();
+    if (s_nan) {
+        if (threadIdx.x == 0) {
+            med[b] = nan;
+            mad[b] = nan;
+        }
+        return;
+    }
+    const T a = val_of(k0), bb = val_of(k1);
+    const T m = r0 == r1 ? a : (T)((a + bb) / (T)2);
+    const K q0 = m1_slow_rank<T>(in, n, w0, w1, true, m, r0, hist, &s_dig, &s_bef, &s_nan);
+    const K q1 = r1 == r0 ? q0 : m1_slow_rank<T>(in, n, w0, w1, true, m, r1, hist, &s_dig, &s_bef, &s_nan);
+    if (threadIdx.x == 0) {
+        const T ta = val_of(q0), tb = val_of(q1);
+        med[b] = (double)m;
+        mad[b] = s_nan ? nan : (double)(r0 == r1 ? ta : (T)((ta + tb) / (T)2));
+    }
+}
+
+// ---------------------------------------------------------------- host side
+template <typename T>
+static int64_t m1_cap(int64_t max_frames, double frac) {
+    const int64_t want = (int64_t)((double)max_frames * frac) + 1024;
+    return want > M1<T>::S ? want : M1<T>::S;
+}
+// Blocks this long (and shorter) take the single-pass route: both candidate lists must fit the LDS select.
+template <typename T>
+static bool m1_applicable(const Ctx *c, int64_t max_frames) {
+    return !c->force_generic &&
+           (size_t)m1_cap<T>(max_frames, M1<T>::FRAC_A) <= select_subset_max_keys(sizeof(typename KeyT<T>::type)) &&
+           max_frames < (int64_t(1) << 31);
+}
+template <typename T>
+static size_t m1_ws_bytes(int64_t n_blocks, int64_t max_frames) {
+    const size_t nb = (size_t)n_blocks;
+    return ws_need(nb, sizeof(M1State)) + ws_need(nb * (size_t)m1_cap<T>(max_frames, M1<T>::FRAC_M), sizeof(T)) +
+           ws_need(nb * (size_t)m1_cap<T>(max_frames, M1<T>::FRAC_A), sizeof(T)) + 4 * ws_need(nb, 8) + 3 * ws_need(nb, 4) +
+           3 * ws_need(nb, 8) + ws_need(2 * nb, 8);
+}
+
+// Median absolute deviation (sigma) and universal threshold of every stereo block; *thresh_ws
+// receives the per-block thresholds (device, binary64).
+template <typename T>
+static int stereo_mad_single_pass(Ctx *c, const T *d_in, const BlockGeom &g, int64_t max_frames, T w0, T w1,
+                                  double *d_sigma_out, double *d_thresh_out, double **thresh_ws) {
+    const size_t nb = (size_t)g.n_blocks;
+    const int64_t cap_m = m1_cap<T>(max_frames, M1<T>::FRAC_M), cap_a = m1_cap<T>(max_frames, M1<T>::FRAC_A);
+    M1State *st = ws_take<M1State>(c, nb);
+    T *cand_m = ws_take<T>(c, nb * (size_t)cap_m);
+    T *cand_a = ws_take<T>(c, nb * (size_t)cap_a);
+    int64_t *len_m = ws_take<int64_t>(c, nb), *len_a = ws_take<int64_t>(c, nb);
+    unsigned long long *below_m = ws_take<unsigned long long>(c, nb), *below_a = ws_take<unsigned long long>(c, nb);
+    int *valid_m = ws_take<int>(c, nb), *valid_a = ws_take<int>(c, nb), *resolved = ws_take<int>(c, nb);
+    double *med = ws_take<double>(c, nb), *mad = ws_take<double>(c, nb), *thresh = ws_take<double>(c, nb);
+    double *pair_a = ws_take<double>(c, 2 * nb);
+    if (c->ws_used > c->ws_bytes) {
+        set_error("internal: workspace not reserved for the single-pass threshold statistics");
+        return ADN_ERR_NOMEM;
+    }
+    const unsigned nbk = (unsigned)ceil_div(g.n_blocks, 256);
+    {
+        auto kern = k_m1_sample<T>;
+        const size_t dyn = (size_t)M1<T>::S * sizeof(typename KeyT<T>::type);
+        ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL(kern, dim3((unsigned)g.n_blocks), dim3(M1_THREADS), dyn, c->stream, d_in, g, w0, w1, st);
+    }
+    const int64_t tiles = ceil_div(max_frames, M1_TILE);
+    ADN_REQUIRE(g.n_blocks * tiles < (int64_t)0x7FFFFFFF, "wavelet batch too large for one launch");
+    hipLaunchKernelGGL((k_m1_gather<T>), dim3((unsigned)(g.n_blocks * tiles)), dim3(256), 0, c->stream, d_in, g, w0, w1, st,
+                       cand_m, cap_m, cand_a, cap_a, tiles);
+    hipLaunchKernelGGL(k_m1_check, dim3(nbk), dim3(256), 0, c->stream, st, g.frames, g.n_blocks, cap_m, cap_a, len_m, len_a,
+                       below_m, below_a, valid_m, valid_a, resolved, med, mad);
+    ADN_HIP(hipGetLastError());
+    SubsetSelect sm;
+    sm.n_seg = g.n_blocks;
+    sm.cap = cap_m;
+    sm.d_len = len_m;
+    sm.d_orig_len = g.frames;
+    sm.d_below = below_m;
+    sm.d_valid = valid_m;
+    sm.d_out = med;
+    ADN_TRY(launch_select_subset<T>(c, cand_m, sm));
+    SubsetSelect sa;
+    sa.n_seg = g.n_blocks;
+    sa.cap = cap_a;
+    sa.d_len = len_a;
+    sa.d_orig_len = g.frames;
+    sa.d_below = below_a;
+    sa.d_valid = valid_a;
+    sa.xform = XF_ABSDEV;
+    sa.d_center = med;
+    sa.d_out = mad;
+    sa.d_pair = pair_a;
+    ADN_TRY(launch_select_subset<T>(c, cand_a, sa));
+    hipLaunchKernelGGL((k_m1_verify<T>), dim3(nbk), dim3(256), 0, c->stream, st, g.n_blocks, valid_a, med, pair_a, resolved);
+    hipLaunchKernelGGL((k_m1_fallback<T>), dim3((unsigned)g.n_blocks), dim3(M1_THREADS), 0, c->stream, d_in, g, w0, w1,
+                       resolved, med, mad);
+    hipLaunchKernelGGL(k_universal_threshold, dim3(nbk), dim3(256), 0, c->stream, g.frames, g.n_blocks, mad, thresh,
+                       d_sigma_out, d_thresh_out);
+    ADN_HIP(hipGetLastError());
+    *thresh_ws = thresh;
+    return ADN_OK;
+}

@@ -38,6 +38,24 @@ int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a);
 // callers add it to their ws_reserve request, once per launch_select call they make.
 size_t select_ws_bytes(int64_t n_seg, int64_t max_len);
 
+// Median of segments of which only a gathered SUBSET is at hand (the keys inside a value bracket): list s holds
+// d_len[s] keys at d_cand + s * cap; the ranks are those of the original segment (d_orig_len[s] keys) minus
+// d_below[s], the number of its keys below the bracket.  Lists with d_valid[s] == 0 are skipped (d_out untouched).
+// The whole list is staged in LDS: cap <= select_subset_max_keys(sizeof key).
+struct SubsetSelect {
+    int64_t n_seg = 0, cap = 0;
+    const int64_t *d_len = nullptr, *d_orig_len = nullptr;
+    const unsigned long long *d_below = nullptr;
+    const int *d_valid = nullptr;
+    int xform = XF_NONE;
+    const double *d_center = nullptr;     // per segment, for XF_ABSDEV
+    double *d_out = nullptr;              // per segment result
+    double *d_pair = nullptr;             // optional: the two middle order statistics, [2*s], [2*s+1]
+};
+template <typename T>
+int launch_select_subset(Ctx *c, const T *d_cand, const SubsetSelect &a);
+size_t select_subset_max_keys(size_t key_bytes);
+
 // -------------------------------------------------------------- wavelets
 template <typename T>
 int wavelet_denoise(Ctx *c, const T *d_in, T *d_out, int64_t n_blocks, const int64_t *d_in_off,

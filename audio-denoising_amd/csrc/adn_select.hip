@@ -23,6 +23,7 @@ static constexpr int SEL_THREADS = 256;
 static constexpr int SEL_LDS_BYTES = 48 * 1024;
 static constexpr int64_t SEL_ONE_WAVE_MAX = 1024;       // segments up to this length are selected by one wave
 static constexpr size_t SEL_LDS_MAX_BYTES = 96 * 1024;  // longest segment the lean LDS kernel stages
+static constexpr size_t SUBSET_LDS_BYTES = 144 * 1024;  // ... when it selects from gathered candidate lists (one workgroup per CU)
 
 __device__ __forceinline__ void hist_add_matched(uint32_t *hist, uint32_t digit, bool active) {
     unsigned long long m = __ballot(active);
@@ -91,6 +92,7 @@ struct SubsetRanks {
     const unsigned long long *below;      // keys of the original segment below the bracket
     const int *valid;                     // 0: skip this segment
     const unsigned long long *lohi;       // bracket keys [2*seg], [2*seg+1]: every key lies between them
+    double *pair = nullptr;               // optional (LDS kernel): the two order statistics, [2*seg], [2*seg+1]
 };
 
 template <typename T, int XF>
@@ -657,6 +659,10 @@ __global__ __launch_bounds__(NT) void k_select_lds(const T *__restrict__ vals,
         } else {
             const T a = val_of((K)(k0 + kmin)), b = val_of((K)(k1 + kmin));
             res = select_result<T>(a, b, r0 == r1, frac, mode);
+            if (sub.pair) {
+                sub.pair[2 * seg] = (double)a;
+                sub.pair[2 * seg + 1] = (double)b;
+            }
         }
         out[seg] = res;
         if (MASKED) {
@@ -1442,5 +1448,34 @@ int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {
 
 template int launch_select<float>(Ctx *, const float *, const SelectArgs &);
 template int launch_select<double>(Ctx *, const double *, const SelectArgs &);
+
+size_t select_subset_max_keys(size_t key_bytes) { return SUBSET_LDS_BYTES / key_bytes; }
+
+template <typename T>
+int launch_select_subset(Ctx *c, const T *d_cand, const SubsetSelect &a) {
+    using K = typename KeyT<T>::type;
+    if (a.n_seg <= 0) return ADN_OK;
+    ADN_REQUIRE((size_t)a.cap <= select_subset_max_keys(sizeof(K)), "internal: candidate lists too long for the LDS select");
+    const size_t dyn = (size_t)a.cap * sizeof(K);
+    const MaskedMean mm{nullptr, 1, 0, nullptr};
+    SubsetRanks sub{a.d_orig_len, 1, 0, a.d_below, a.d_valid, nullptr};
+    sub.pair = a.d_pair;
+    constexpr int NT = 1024;                       // lists of tens of thousands of keys: few keys per lane in every sweep
+    if (a.xform == XF_ABSDEV) {
+        auto kern = k_select_lds<T, XF_ABSDEV, false, NT>;
+        ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL(kern, dim3((unsigned)a.n_seg), dim3(NT), dyn, c->stream, d_cand, (const int64_t *)nullptr, a.cap,
+                           a.d_len, (int64_t)1, (int64_t)0, (int)SEL_MEDIAN, 50.0, a.d_center, a.d_out, mm, sub);
+    } else {
+        auto kern = k_select_lds<T, XF_NONE, false, NT>;
+        ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+        hipLaunchKernelGGL(kern, dim3((unsigned)a.n_seg), dim3(NT), dyn, c->stream, d_cand, (const int64_t *)nullptr, a.cap,
+                           a.d_len, (int64_t)1, (int64_t)0, (int)SEL_MEDIAN, 50.0, (const double *)nullptr, a.d_out, mm, sub);
+    }
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
+template int launch_select_subset<float>(Ctx *, const float *, const SubsetSelect &);
+template int launch_select_subset<double>(Ctx *, const double *, const SubsetSelect &);
 
 }  // namespace adn

@@ -296,3 +296,75 @@ def test_blocks_sharded_like_ranks_match_single_call():
             assert np.array_equal(a, b)
     want, _, _ = orc.denoise_signal(x, sr)
     check64(full[:len(want)], want)
+
+
+def _stereo_batch(e, blocks, dt, thr_mode="soft"):
+    lens = np.array([b.shape[0] for b in blocks], dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)[:-1]]) * 2
+    xd = dev(np.concatenate([b.reshape(-1) for b in blocks]), dt)
+    out = torch.full((int(lens.sum()) * 2,), float("nan"), dtype=dt, device="cuda:0")
+    st = e.wavelet_denoise(xd, e._i64(off), e._i64(lens), out, e._i64(off), n_ch=2, wavelet="db4", level=2,
+                           thr_mode=thr_mode, max_frames=int(lens.max()), want_stats=True)
+    o = host(out)
+    return [o[a:a + 2 * l].reshape(l, 2) for a, l in zip(off, lens)], [host(s) for s in st]
+
+
+@pytest.mark.parametrize("dt,longest", [(torch.float32, 300000), (torch.float64, 120000)])
+def test_stereo_single_pass_statistics_exact(dt, longest):
+    """Stereo blocks take their threshold statistics from one pass over the input (sample ->
+    brackets -> gather -> exact selection among the gathered keys, verified, exact fallback).
+    Sigma, threshold, zero counts and output must EQUAL those of the plain route (coefficient
+    array + two full selections) for Gaussian, heavy-tailed, quantised, bimodal, half-silent,
+    constant, silent, NaN-carrying, short and one-frame blocks, and match the oracle."""
+    e = engine()
+    rng = np.random.default_rng(77)
+    npdt = np.float32 if dt == torch.float32 else np.float64
+
+    def st(n, kind):
+        if kind == "gauss":
+            x = 0.1 * rng.standard_normal((n, 2))
+        elif kind == "laplace":
+            x = 0.05 * rng.laplace(size=(n, 2))
+        elif kind == "pcm":
+            x = np.round(0.2 * rng.standard_normal((n, 2)) * 512) / 512
+        elif kind == "bimodal":
+            s = rng.choice([-1.0, 1.0], size=n)
+            x = np.stack([s * 0.5 + 1e-3 * rng.standard_normal(n), -s * 0.5 + 1e-3 * rng.standard_normal(n)], axis=1)
+        elif kind == "halfsilent":
+            x = 0.1 * rng.standard_normal((n, 2))
+            x[: n // 2 + 7] = 0.0
+        elif kind == "const":
+            x = np.tile(np.array([[0.25, -0.125]]), (n, 1))
+        elif kind == "zero":
+            x = np.zeros((n, 2))
+        elif kind == "nan":
+            x = 0.1 * rng.standard_normal((n, 2))
+            x[n // 3, 1] = np.nan
+        elif kind == "offset":
+            x = 0.01 * rng.standard_normal((n, 2)) + np.array([[0.7, -0.6]])
+        return x.astype(npdt)
+
+    spec = [(longest, "gauss"), (100000, "laplace"), (40000, "gauss"), (32768, "gauss"), (20000, "laplace"),
+            (5, "gauss"), (1, "gauss"), (longest - 1, "zero"), (110000, "nan"), (longest, "bimodal"),
+            (90000, "const"), (longest - 3, "halfsilent"), (65001, "pcm"), (70000, "offset"), (16385, "gauss")]
+    blocks = [st(n, k) for n, k in spec]
+    for thr_mode in ("soft", "hard"):
+        ys, s1 = _stereo_batch(e, blocks, dt, thr_mode)
+        e.force_generic(True)
+        try:
+            yg, s2 = _stereo_batch(e, blocks, dt, thr_mode)
+        finally:
+            e.force_generic(False)
+        for name, a, b in zip(("sigma", "thresh", "zeroed"), s1, s2):
+            assert np.array_equal(a, b, equal_nan=True), (name, thr_mode, a, b)
+        for (n, k), y, g in zip(spec, ys, yg):
+            assert np.array_equal(y, g, equal_nan=True), (n, k)
+    # oracle: sigma of every block (binary64 restatement on the same inputs)
+    for (n, k), blk, sg in zip(spec, blocks, s1[0]):
+        _, s_or, _ = orc.denoise_block(blk.astype(np.float64), "db4", 2, "soft")
+        if np.isnan(s_or):
+            assert np.isnan(sg), (n, k)
+        else:
+            # the coefficients are rounded in the block's dtype: a few ulps of the largest sample
+            scale = max(float(np.max(np.abs(blk))), 1e-3)
+            assert abs(sg - s_or) <= (1e-6 if dt == torch.float32 else 1e-14) * scale, (n, k, sg, s_or)
