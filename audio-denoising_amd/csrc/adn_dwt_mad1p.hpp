@@ -11,7 +11,7 @@
 //      |d - m^| that holds the ranks of the absolute deviation, widened by the largest possible
 //      |median - m^| so that it still holds them once the true median is known.
 //   2. k_m1_gather: one pass over the block: coefficients on the fly, keys below each bracket
-//      counted, keys inside gathered (~2.5 % and ~6.5 % of the block).
+//      counted, keys inside gathered (~3.5 % and ~9 % of the block).
 //   3. Exact selection among the gathered keys (LDS radix select with rank offsets): the median,
 //      then |d - median| of the second list.
 //   4. k_m1_verify proves the second selection: both order statistics must lie inside
@@ -27,14 +27,16 @@
 template <typename T>
 struct M1 {
     using K = typename KeyT<T>::type;
-    static constexpr int S = (int)((128 * 1024) / sizeof(K));          // sample keys per block (LDS resident)
-    static constexpr double FRAC_M = sizeof(T) == 4 ? 0.04 : 0.06;     // list capacities as fractions of the block
-    static constexpr double FRAC_A = sizeof(T) == 4 ? 0.10 : 0.14;
+    static constexpr int S = 16384;                // sample keys per block (LDS resident: 64 / 128 KB)
+    static constexpr double FRAC_M = 0.05;         // list capacities as fractions of the block: the brackets hold
+    static constexpr double FRAC_A = 0.13;         // ~3.5 % and ~9 % of a Gaussian block
 };
 static constexpr int M1_THREADS = 1024;     // sample / fallback workgroups
 static constexpr int M1_RUN = 16;           // consecutive frames per sample run
 static constexpr int M1_BINS = 2048;        // 11-bit digits
 static constexpr int M1_TILE = 4096;        // frames per gather workgroup (256 threads x 16)
+static constexpr int M1_STAGE_M = 1024;     // bracket keys a tile can stage: median list (~3.5 % expected),
+static constexpr int M1_STAGE_A = 2048;     // absolute-deviation list (~9 %)
 
 struct M1State {                  // per block
     unsigned long long lo_m, hi_m;    // key bracket of the median (lo > hi: unusable)
@@ -43,6 +45,7 @@ struct M1State {                  // per block
     unsigned long long below_m, below_a;
     unsigned int n_m, n_a;            // keys gathered (may exceed the capacity: overflow)
     int has_nan, usable;
+    int spill;                        // a tile held more bracket keys than its LDS stage: lists incomplete
 };
 
 template <typename T>
@@ -59,15 +62,19 @@ __device__ __forceinline__ typename KeyT<T>::type m1_key(T x) {
     return x != x ? ~(K)0 : key_of(x);
 }
 
-// One atomic per group of equal digits in a wave (constant or narrow data would serialise otherwise).
-__device__ __forceinline__ void m1_hist_add(uint32_t *hist, uint32_t digit, int nbits, bool active) {
-    unsigned long long m = __ballot(active);
-    for (int b = 0; b < nbits; ++b) {
-        const bool bit = (digit >> b) & 1u;
-        const unsigned long long bm = __ballot(bit);
-        m &= bit ? bm : ~bm;
+// Histogram update of a wave: when every active lane holds the same digit (constant data, or the
+// leading digits of narrow data) one lane adds the whole count, otherwise every lane adds its own.
+__device__ __forceinline__ void m1_hist_add(uint32_t *hist, uint32_t digit, bool active) {
+    const unsigned long long act = __ballot(active);
+    if (act == 0) return;
+    const int first = (int)__ffsll((long long)act) - 1;
+    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)digit, first);
+    const unsigned long long same = __ballot(active && digit == d0);
+    if (same == act) {
+        if ((int)(threadIdx.x & 63) == first) atomicAdd(&hist[d0], (uint32_t)__popcll(act));
+    } else if (active) {
+        atomicAdd(&hist[digit], 1u);
     }
-    if (active && (int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&hist[digit], (uint32_t)__popcll(m));
 }
 
 // Bin of `rank` in a histogram of M1_BINS counters: all M1_THREADS threads, two bins each.
@@ -96,24 +103,57 @@ __device__ __forceinline__ void m1_find_bin(const uint32_t *hist, uint32_t rank,
     __syncthreads();
 }
 
-// Keys of sample ranks ra <= rb among the S keys in LDS: 11-bit MSD radix selection on key - kmin,
-// both ranks in the same sweeps (a second histogram once their prefixes part).
-template <typename K, int S>
-__device__ void m1_select2(const K *sk, K kmin, K kmax, uint32_t ra, uint32_t rb, uint32_t (*hist)[M1_BINS],
-                           uint32_t (*wtot)[M1_THREADS / 64], uint32_t *s_dig, uint32_t *s_bef, K *ka, K *kb) {
+// Keys that bracket the ranks ra <= rb of the `count` keys sk[0], sk[stride], sk[2 stride], ...:
+// 11-bit MSD radix selection on key - kmin, both ranks in the same sweeps (a second histogram once
+// their prefixes part).  At most M1_PASSES digits are resolved; the bits below them are rounded
+// outwards (*ka <= key of rank ra, *kb >= key of rank rb), which widens a bracket by less than 2^-10
+// of an octave.  CLIP: only the keys inside [kmin, kmax] are histogrammed, the keys below kmin are
+// counted and taken off the ranks (most keys then cost a comparison instead of an LDS atomic).
+// Returns false when a rank falls outside [kmin, kmax] (CLIP only).
+static constexpr int M1_PASSES = 2;
+template <typename K, bool CLIP>
+__device__ bool m1_select2(const K *sk, int count, int stride, K kmin, K kmax, uint32_t ra, uint32_t rb,
+                           uint32_t (*hist)[M1_BINS], uint32_t (*wtot)[M1_THREADS / 64], uint32_t *s_dig,
+                           uint32_t *s_bef, uint32_t *s_cnt, K *ka, K *kb) {
     constexpr int BITS = (int)sizeof(K) * 8;
     const int tid = threadIdx.x;
     const K width = kmax - kmin;
     const int bits = width ? BITS - (BITS == 64 ? __clzll((long long)width) : __clz((int)width)) : 0;
     const int passes = (bits + 10) / 11;
+    const int done = passes < M1_PASSES ? passes : M1_PASSES;
     K pa = 0, pb = 0;
-    for (int p = 0; p < passes; ++p) {
+    if (CLIP) {
+        if (tid < 2) s_cnt[tid] = 0;
+        __syncthreads();
+        uint32_t below = 0, inside = 0;
+        for (int j = tid; j < count; j += M1_THREADS) {
+            const K k = sk[(size_t)j * stride];
+            below += k < kmin;
+            inside += (K)(k - kmin) <= width;
+        }
+        for (int d = 32; d >= 1; d >>= 1) {
+            below += __shfl_xor(below, d);
+            inside += __shfl_xor(inside, d);
+        }
+        if ((tid & 63) == 0) {
+            atomicAdd(&s_cnt[0], below);
+            atomicAdd(&s_cnt[1], inside);
+        }
+        __syncthreads();
+        const uint32_t nb = s_cnt[0], ni = s_cnt[1];
+        __syncthreads();
+        if (ra < nb || rb - nb >= ni) return false;
+        ra -= nb;
+        rb -= nb;
+    }
+    for (int p = 0; p < done; ++p) {
         const int shift = 11 * (passes - 1 - p);
         const bool same = pa == pb;
         for (int i = tid; i < 2 * M1_BINS; i += M1_THREADS) (&hist[0][0])[i] = 0;
         __syncthreads();
-        for (int j = tid; j < S; j += M1_THREADS) {
-            const K u = sk[j] - kmin;
+        for (int j = tid; j < count; j += M1_THREADS) {
+            const K u = sk[(size_t)j * stride] - kmin;
+            if (CLIP && u > width) continue;
             const K top = p == 0 ? (K)0 : (K)(u >> (shift + 11));
             const uint32_t digit = (uint32_t)(u >> shift) & (M1_BINS - 1);
             if (top == pa) atomicAdd(&hist[0][digit], 1u);
@@ -128,8 +168,33 @@ __device__ void m1_select2(const K *sk, K kmin, K kmax, uint32_t ra, uint32_t rb
         rb -= s_bef[1];
         __syncthreads();
     }
-    *ka = kmin + pa;
-    *kb = kmin + pb;
+    const int rest = 11 * (passes - done);            // unresolved low bits
+    *ka = kmin + (pa << rest);
+    const K top_b = (pb << rest) | (rest ? (((K)1 << rest) - 1) : (K)0);
+    *kb = top_b > width ? kmax : kmin + top_b;
+    return true;
+}
+
+// The bracket of sample ranks [want_lo, want_hi] among the S keys in LDS, in two steps: every
+// M1_COARSE-th key gives a coarse bracket (a few thousand ranks wide), then the full sample is
+// selected inside it.  False: a bracket missed (the caller leaves the block to the exact fallback).
+static constexpr int M1_COARSE = 16;
+template <typename K, int S>
+__device__ bool m1_bracket(const K *sk, K kmin, K kmax, int want_lo, int want_hi, uint32_t (*hist)[M1_BINS],
+                           uint32_t (*wtot)[M1_THREADS / 64], uint32_t *s_dig, uint32_t *s_bef, uint32_t *s_cnt,
+                           K *ka, K *kb) {
+    constexpr int SC = S / M1_COARSE;
+    const int dc = (int)(4.5 * sqrt((double)SC * 0.25)) + 3;
+    int c_lo = want_lo / M1_COARSE - dc, c_hi = want_hi / M1_COARSE + dc + 1;
+    K cl = kmin, ch = kmax;
+    if (c_lo >= 0 || c_hi < SC) {
+        K a, b;
+        const int qa = c_lo < 0 ? 0 : c_lo, qb = c_hi >= SC ? SC - 1 : c_hi;
+        m1_select2<K, false>(sk, SC, M1_COARSE, kmin, kmax, (uint32_t)qa, (uint32_t)qb, hist, wtot, s_dig, s_bef, s_cnt, &a, &b);
+        cl = c_lo < 0 ? kmin : a;
+        ch = c_hi >= SC ? kmax : b;
+    }
+    return m1_select2<K, true>(sk, S, 1, cl, ch, (uint32_t)want_lo, (uint32_t)want_hi, hist, wtot, s_dig, s_bef, s_cnt, ka, kb);
 }
 
 template <typename T>
@@ -141,7 +206,7 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_sample(const T *__restrict__ 
     K *sk = reinterpret_cast<K *>(smem);
     __shared__ uint32_t hist[2][M1_BINS];
     __shared__ uint32_t wtot[2][M1_THREADS / 64];
-    __shared__ uint32_t s_dig[2], s_bef[2];
+    __shared__ uint32_t s_dig[2], s_bef[2], s_cnt[2];
     __shared__ K s_kmin, s_kmax;
     const int64_t b = blockIdx.x;
     const int64_t n = g.frames[b];
@@ -174,7 +239,8 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_sample(const T *__restrict__ 
         for (int u = 0; u < PER; ++u) {
             const int j = tid + M1_THREADS * u;
             const int run = j / M1_RUN, w = j % M1_RUN;
-            int64_t i = (int64_t)(((double)run + 0.5) * (double)n / (double)NRUN) - M1_RUN / 2 + w;
+            // centre of run r: (r + 1/2) n / NRUN (n < 2^31, so the product fits 64 bits)
+            int64_t i = (int64_t)(((uint64_t)(2 * run + 1) * (uint64_t)n) / (uint64_t)(2 * NRUN)) - M1_RUN / 2 + w;
             i = i < 0 ? 0 : (i < n ? i : n - 1);
             v0[u] = in[2 * i];
             v1[u] = in[2 * i + 1];
@@ -206,11 +272,11 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_sample(const T *__restrict__ 
     const bool open_lo = want_lo < 0, open_hi = want_hi >= S;
     want_lo = open_lo ? 0 : want_lo;
     want_hi = open_hi ? S - 1 : want_hi;
-    K klo, khi;
-    m1_select2<K, S>(sk, s_kmin, s_kmax, (uint32_t)want_lo, (uint32_t)want_hi, hist, wtot, s_dig, s_bef, &klo, &khi);
+    K klo = 0, khi = 0;
+    const bool got_m = m1_bracket<K, S>(sk, s_kmin, s_kmax, want_lo, want_hi, hist, wtot, s_dig, s_bef, s_cnt, &klo, &khi);
     const T lo_v = val_of(klo), hi_v = val_of(khi);
     const bool finite = klo != ~(K)0 && khi != ~(K)0 && fabs(lo_v) <= (T)1e30 && fabs(hi_v) <= (T)1e30;
-    if (!finite || open_lo || open_hi || klo == khi) {
+    if (!got_m || !finite || open_lo || open_hi || klo == khi) {
         // non-finite or (nearly) constant data, or a degenerate sample: the exact fallback takes the block
         if (tid == 0) {
             s.lo_m = 1;
@@ -250,8 +316,19 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_sample(const T *__restrict__ 
         atomicMax(&s_kmax, tmax);
     }
     __syncthreads();
-    K kalo, kahi;
-    m1_select2<K, S>(sk, s_kmin, s_kmax, (uint32_t)want_lo, (uint32_t)want_hi, hist, wtot, s_dig, s_bef, &kalo, &kahi);
+    K kalo = 0, kahi = 0;
+    const bool got_a = m1_bracket<K, S>(sk, s_kmin, s_kmax, want_lo, want_hi, hist, wtot, s_dig, s_bef, s_cnt, &kalo, &kahi);
+    if (!got_a) {
+        if (tid == 0) {
+            s.lo_m = 1;
+            s.hi_m = 0;
+            s.alo = 1.0;
+            s.ahi = 0.0;
+            s.usable = 0;
+            st[b] = s;
+        }
+        return;
+    }
     if (tid == 0) {
         const double eps_t = sizeof(T) == 4 ? 1.1920929e-7 : 2.220446049250313e-16;
         const bool open_above = kahi == ~(K)0 || !(fabs(val_of(kahi)) <= (T)1e30);
@@ -268,23 +345,100 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_sample(const T *__restrict__ 
     }
 }
 
+// The sixteen coefficients of a thread against both brackets: counts of the keys below them and the
+// keys inside appended to the workgroup's LDS stages (positions from wave ballots, eight keys at a
+// time so that the ballots stay in scalar registers).  FULL: every coefficient exists (a tile inside
+// its block), no per-key bounds.
+template <typename T, bool FULL>
+__device__ __forceinline__ void m1_classify(const T (&d)[16], const bool (&live_in)[16], typename KeyT<T>::type lo,
+                                            typename KeyT<T>::type hi, T mhat, T alo, T ahi, T *stage_m, T *stage_a,
+                                            unsigned int *s_fill_m, unsigned int *s_fill_a, unsigned int &below_m,
+                                            unsigned int &below_a, bool &saw_nan) {
+    using K = typename KeyT<T>::type;
+    constexpr int SUB = 8;
+    const int lane = threadIdx.x & 63;
+    const K span = hi - lo;
+#pragma unroll
+    for (int h = 0; h < 16; h += SUB) {
+        // ---- median bracket (keys)
+        {
+            bool keep[SUB];
+            unsigned long long bal[SUB];
+            unsigned int total = 0;
+#pragma unroll
+            for (int u = 0; u < SUB; ++u) {
+                const bool live = FULL || live_in[h + u];
+                const T xv = d[h + u];
+                saw_nan |= live && (xv != xv);
+                const K k = m1_key(xv);
+                below_m += (live && k < lo);
+                keep[u] = live && (K)(k - lo) <= span;
+                bal[u] = __ballot(keep[u]);
+                total += (unsigned int)__popcll(bal[u]);
+            }
+            if (total) {
+                unsigned int base = 0;
+                if (lane == 0) base = atomicAdd(s_fill_m, total);
+                base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+                for (int u = 0; u < SUB; ++u) {
+                    const unsigned int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal[u] >> 32),
+                                                                              __builtin_amdgcn_mbcnt_lo((unsigned int)bal[u], 0u));
+                    if (keep[u] && pos < M1_STAGE_M) stage_m[pos] = d[h + u];
+                    base += (unsigned int)__popcll(bal[u]);
+                }
+            }
+        }
+        // ---- absolute-deviation bracket (values of |d - mhat|); the coefficient itself is gathered
+        {
+            bool keep[SUB];
+            unsigned long long bal[SUB];
+            unsigned int total = 0;
+#pragma unroll
+            for (int u = 0; u < SUB; ++u) {
+                const bool live = FULL || live_in[h + u];
+                const T a = fabs(d[h + u] - mhat);
+                below_a += (live && a < alo);
+                keep[u] = live && a >= alo && a <= ahi;
+                bal[u] = __ballot(keep[u]);
+                total += (unsigned int)__popcll(bal[u]);
+            }
+            if (total) {
+                unsigned int base = 0;
+                if (lane == 0) base = atomicAdd(s_fill_a, total);
+                base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+                for (int u = 0; u < SUB; ++u) {
+                    const unsigned int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal[u] >> 32),
+                                                                              __builtin_amdgcn_mbcnt_lo((unsigned int)bal[u], 0u));
+                    if (keep[u] && pos < M1_STAGE_A) stage_a[pos] = d[h + u];
+                    base += (unsigned int)__popcll(bal[u]);
+                }
+            }
+        }
+    }
+}
+
 // One pass over the blocks: keys below each bracket counted, keys inside gathered.
-template <typename T>
+// FULL: workgroup (block b, tile t) of a grid of n_blocks x tiles_per_block takes the tile if it lies
+// inside the block (one frame per load instruction, no bounds); the other instantiation runs one
+// workgroup per block on the block's last, partial tile.
+template <typename T, bool FULL>
 __global__ __launch_bounds__(256) void k_m1_gather(const T *__restrict__ x, BlockGeom g, T w0, T w1,
                                                    M1State *__restrict__ st, T *__restrict__ cand_m, int64_t cap_m,
                                                    T *__restrict__ cand_a, int64_t cap_a, int64_t tiles_per_block) {
     using K = typename KeyT<T>::type;
+    using V2 = T __attribute__((ext_vector_type(2)));
     constexpr int BATCH = 16;                               // frames per thread
-    constexpr int FPL = (16 / (int)sizeof(T)) / 2;          // frames per 16-byte load
-    constexpr int NL = BATCH / FPL;
-    __shared__ T stage_m[M1_TILE], stage_a[M1_TILE];
+    __shared__ T stage_m[M1_STAGE_M], stage_a[M1_STAGE_A];
     __shared__ unsigned long long s_below_m, s_below_a;
     __shared__ unsigned int s_fill_m, s_fill_a, s_base_m, s_base_a;
     __shared__ int s_nan;
-    const int64_t b = blockIdx.x / tiles_per_block, tile = blockIdx.x % tiles_per_block;
+    const int64_t b = FULL ? blockIdx.x / tiles_per_block : blockIdx.x;
     const int64_t n = g.frames[b];
+    const int64_t tile = FULL ? blockIdx.x % tiles_per_block : n / M1_TILE;
     const int64_t f0 = tile * M1_TILE;
-    if (f0 >= n) return;
+    if (FULL ? f0 + M1_TILE > n : f0 >= n) return;
     const K lo = (K)st[b].lo_m, hi = (K)st[b].hi_m;
     if (lo > hi) return;
     const T mhat = (T)st[b].mhat, alo = (T)st[b].alo, ahi = (T)st[b].ahi;
@@ -300,20 +454,24 @@ __global__ __launch_bounds__(256) void k_m1_gather(const T *__restrict__ x, Bloc
     const T *in = x + g.in_off[b] + 2 * f0;
     T d[BATCH];
     bool live[BATCH];
-    const bool full = f0 + M1_TILE <= n && (reinterpret_cast<uintptr_t>(in) & 15) == 0;
-    if (full) {
-        const float4 *v4 = reinterpret_cast<const float4 *>(in);
-        float4 q[NL];
+    if (FULL) {
+        // a frame (two samples) is one load when the block starts at an even element of an aligned buffer
+        V2 q[BATCH];
+        if ((reinterpret_cast<uintptr_t>(in) & (sizeof(V2) - 1)) == 0) {
+            const V2 *v2 = reinterpret_cast<const V2 *>(in);
 #pragma unroll
-        for (int u = 0; u < NL; ++u) q[u] = v4[u * 256 + tid];
+            for (int u = 0; u < BATCH; ++u) q[u] = v2[u * 256 + tid];
+        } else {
 #pragma unroll
-        for (int u = 0; u < NL; ++u) {
-            const T *e = reinterpret_cast<const T *>(&q[u]);
-#pragma unroll
-            for (int f = 0; f < FPL; ++f) {
-                d[u * FPL + f] = m1_d1(w0, w1, e[2 * f], e[2 * f + 1]);
-                live[u * FPL + f] = true;
+            for (int u = 0; u < BATCH; ++u) {
+                q[u].x = in[2 * (u * 256 + tid)];
+                q[u].y = in[2 * (u * 256 + tid) + 1];
             }
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            d[u] = m1_d1(w0, w1, q[u].x, q[u].y);
+            live[u] = true;
         }
     } else {
         T v0[BATCH], v1[BATCH];
@@ -329,60 +487,27 @@ __global__ __launch_bounds__(256) void k_m1_gather(const T *__restrict__ x, Bloc
     }
     unsigned int below_m = 0, below_a = 0;
     bool saw_nan = false;
-    // ---- median bracket (keys)
-    {
-        bool keep[BATCH];
-        unsigned long long bal[BATCH];
-        unsigned int total = 0;
+    if (lo == 0 && hi == ~(K)0) {
+        // short block, every coefficient is a candidate of both lists: stored in place, no staging
+        T *dm = cand_m + b * cap_m + f0, *da = cand_a + b * cap_a + f0;
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            const T xv = d[u];
-            saw_nan |= live[u] && (xv != xv);
-            const K k = m1_key(xv);
-            below_m += (live[u] && k < lo);
-            keep[u] = live[u] && (K)(k - lo) <= (K)(hi - lo);
-            bal[u] = __ballot(keep[u]);
-            total += (unsigned int)__popcll(bal[u]);
-        }
-        if (total) {
-            unsigned int base = 0;
-            if (lane == 0) base = atomicAdd(&s_fill_m, total);
-            base = __builtin_amdgcn_readfirstlane(base);
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                if (keep[u])
-                    stage_m[base + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal[u] >> 32),
-                                                             __builtin_amdgcn_mbcnt_lo((unsigned int)bal[u], 0u))] = d[u];
-                base += (unsigned int)__popcll(bal[u]);
+            const int64_t f = (int64_t)u * 256 + tid;
+            if (live[u]) {
+                dm[f] = d[u];
+                da[f] = d[u];
+                saw_nan |= d[u] != d[u];
             }
         }
-    }
-    // ---- absolute-deviation bracket (values of |d - mhat|); the coefficient itself is gathered
-    {
-        bool keep[BATCH];
-        unsigned long long bal[BATCH];
-        unsigned int total = 0;
-#pragma unroll
-        for (int u = 0; u < BATCH; ++u) {
-            const T a = fabs(d[u] - mhat);
-            below_a += (live[u] && a < alo);
-            keep[u] = live[u] && a >= alo && a <= ahi;
-            bal[u] = __ballot(keep[u]);
-            total += (unsigned int)__popcll(bal[u]);
+        if (saw_nan) st[b].has_nan = 1;
+        if (tid == 0) {
+            const unsigned int cnt = (unsigned int)(n - f0 < M1_TILE ? n - f0 : M1_TILE);
+            atomicAdd(&st[b].n_m, cnt);
+            atomicAdd(&st[b].n_a, cnt);
         }
-        if (total) {
-            unsigned int base = 0;
-            if (lane == 0) base = atomicAdd(&s_fill_a, total);
-            base = __builtin_amdgcn_readfirstlane(base);
-#pragma unroll
-            for (int u = 0; u < BATCH; ++u) {
-                if (keep[u])
-                    stage_a[base + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal[u] >> 32),
-                                                             __builtin_amdgcn_mbcnt_lo((unsigned int)bal[u], 0u))] = d[u];
-                base += (unsigned int)__popcll(bal[u]);
-            }
-        }
+        return;
     }
+    m1_classify<T, FULL>(d, live, lo, hi, mhat, alo, ahi, stage_m, stage_a, &s_fill_m, &s_fill_a, below_m, below_a, saw_nan);
     for (int dd = 32; dd >= 1; dd >>= 1) {
         below_m += __shfl_xor(below_m, dd);
         below_a += __shfl_xor(below_a, dd);
@@ -393,8 +518,10 @@ __global__ __launch_bounds__(256) void k_m1_gather(const T *__restrict__ x, Bloc
     }
     if (saw_nan) s_nan = 1;
     __syncthreads();
-    const unsigned int cm = s_fill_m, ca = s_fill_a;
+    const unsigned int cm = s_fill_m < M1_STAGE_M ? s_fill_m : M1_STAGE_M;
+    const unsigned int ca = s_fill_a < M1_STAGE_A ? s_fill_a : M1_STAGE_A;
     if (tid == 0) {
+        if (s_fill_m > M1_STAGE_M || s_fill_a > M1_STAGE_A) st[b].spill = 1;
         s_base_m = cm ? atomicAdd(&st[b].n_m, cm) : 0u;
         s_base_a = ca ? atomicAdd(&st[b].n_a, ca) : 0u;
         if (s_below_m) atomicAdd(&st[b].below_m, s_below_m);
@@ -425,7 +552,7 @@ __global__ void k_m1_check(const M1State *st, const int64_t *frames, int64_t n_b
     const M1State s = st[b];
     const int64_t n = frames[b], r0 = (n - 1) / 2, r1 = n / 2;
     const double nan = __longlong_as_double(0x7FF8000000000000ll);
-    const bool ok_m = s.usable && !s.has_nan && (int64_t)s.n_m <= cap_m && r0 >= (int64_t)s.below_m &&
+    const bool ok_m = s.usable && !s.has_nan && !s.spill && (int64_t)s.n_m <= cap_m && r0 >= (int64_t)s.below_m &&
                       r1 - (int64_t)s.below_m < (int64_t)s.n_m;
     const bool ok_a = ok_m && (int64_t)s.n_a <= cap_a && r0 >= (int64_t)s.below_a &&
                       r1 - (int64_t)s.below_a < (int64_t)s.n_a;
@@ -471,16 +598,28 @@ __device__ typename KeyT<T>::type m1_slow_rank(const T *in, int64_t n, T w0, T w
     for (int shift = BITS - 8; shift >= 0; shift -= 8) {
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
-        const int64_t n_pad = (n + M1_THREADS - 1) / M1_THREADS * M1_THREADS;     // whole waves take every step
-        for (int64_t i = tid; i < n_pad; i += M1_THREADS) {
-            const bool in_range = i < n;
-            T v = 0;
-            if (in_range) v = m1_d1(w0, w1, in[2 * i], in[2 * i + 1]);
-            if (absdev) v = fabs(v - c);
-            const K k = m1_key(v);
-            if (in_range && k == ~(K)0) *nan_seen = 1;
-            const bool match = in_range && (shift == BITS - 8 || (K)((k ^ prefix) >> (shift + 8 < BITS ? shift + 8 : 0)) == 0);
-            m1_hist_add(hist, (uint32_t)(k >> shift) & 255u, 8, match);
+        // whole waves take every step; the loads of UB steps are in flight together
+        constexpr int UB = 8;
+        const int64_t span = (int64_t)UB * M1_THREADS;
+        const int64_t n_pad = (n + span - 1) / span * span;
+        for (int64_t i0 = tid; i0 < n_pad; i0 += span) {
+            T a0[UB], a1[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int64_t i = i0 + (int64_t)u * M1_THREADS;
+                a0[u] = i < n ? in[2 * i] : (T)0;
+                a1[u] = i < n ? in[2 * i + 1] : (T)0;
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const bool in_range = i0 + (int64_t)u * M1_THREADS < n;
+                T v = m1_d1(w0, w1, a0[u], a1[u]);
+                if (absdev) v = fabs(v - c);
+                const K k = m1_key(v);
+                if (in_range && k == ~(K)0) *nan_seen = 1;
+                const bool match = in_range && (shift == BITS - 8 || (K)((k ^ prefix) >> (shift + 8 < BITS ? shift + 8 : 0)) == 0);
+                m1_hist_add(hist, (uint32_t)(k >> shift) & 255u, match);
+            }
         }
         __syncthreads();
         if (tid < 64) {
@@ -601,10 +740,13 @@ static int stereo_mad_single_pass(Ctx *c, const T *d_in, const BlockGeom &g, int
         ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
         hipLaunchKernelGGL(kern, dim3((unsigned)g.n_blocks), dim3(M1_THREADS), dyn, c->stream, d_in, g, w0, w1, st);
     }
-    const int64_t tiles = ceil_div(max_frames, M1_TILE);
-    ADN_REQUIRE(g.n_blocks * tiles < (int64_t)0x7FFFFFFF, "wavelet batch too large for one launch");
-    hipLaunchKernelGGL((k_m1_gather<T>), dim3((unsigned)(g.n_blocks * tiles)), dim3(256), 0, c->stream, d_in, g, w0, w1, st,
-                       cand_m, cap_m, cand_a, cap_a, tiles);
+    const int64_t tiles = max_frames / M1_TILE;            // whole tiles of the longest block
+    ADN_REQUIRE(g.n_blocks * (tiles + 1) < (int64_t)0x7FFFFFFF, "wavelet batch too large for one launch");
+    if (tiles > 0)
+        hipLaunchKernelGGL((k_m1_gather<T, true>), dim3((unsigned)(g.n_blocks * tiles)), dim3(256), 0, c->stream, d_in, g,
+                           w0, w1, st, cand_m, cap_m, cand_a, cap_a, tiles);
+    hipLaunchKernelGGL((k_m1_gather<T, false>), dim3((unsigned)g.n_blocks), dim3(256), 0, c->stream, d_in, g, w0, w1, st,
+                       cand_m, cap_m, cand_a, cap_a, (int64_t)1);
     hipLaunchKernelGGL(k_m1_check, dim3(nbk), dim3(256), 0, c->stream, st, g.frames, g.n_blocks, cap_m, cap_a, len_m, len_a,
                        below_m, below_a, valid_m, valid_a, resolved, med, mad);
     ADN_HIP(hipGetLastError());

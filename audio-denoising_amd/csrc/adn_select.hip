@@ -23,7 +23,7 @@ static constexpr int SEL_THREADS = 256;
 static constexpr int SEL_LDS_BYTES = 48 * 1024;
 static constexpr int64_t SEL_ONE_WAVE_MAX = 1024;       // segments up to this length are selected by one wave
 static constexpr size_t SEL_LDS_MAX_BYTES = 96 * 1024;  // longest segment the lean LDS kernel stages
-static constexpr size_t SUBSET_LDS_BYTES = 144 * 1024;  // ... when it selects from gathered candidate lists (one workgroup per CU)
+static constexpr size_t SUBSET_LDS_BYTES = 156 * 1024;  // ... when it selects from gathered candidate lists (one workgroup per CU)
 
 __device__ __forceinline__ void hist_add_matched(uint32_t *hist, uint32_t digit, bool active) {
     unsigned long long m = __ballot(active);

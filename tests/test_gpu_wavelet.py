@@ -309,7 +309,7 @@ def _stereo_batch(e, blocks, dt, thr_mode="soft"):
     return [o[a:a + 2 * l].reshape(l, 2) for a, l in zip(off, lens)], [host(s) for s in st]
 
 
-@pytest.mark.parametrize("dt,longest", [(torch.float32, 300000), (torch.float64, 120000)])
+@pytest.mark.parametrize("dt,longest", [(torch.float32, 290000), (torch.float64, 120000)])
 def test_stereo_single_pass_statistics_exact(dt, longest):
     """Stereo blocks take their threshold statistics from one pass over the input (sample ->
     brackets -> gather -> exact selection among the gathered keys, verified, exact fallback).
