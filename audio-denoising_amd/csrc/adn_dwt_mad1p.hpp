@@ -46,6 +46,7 @@ struct M1State {                  // per block
     unsigned int n_m, n_a;            // keys gathered (may exceed the capacity: overflow)
     int has_nan, usable;
     int spill;                        // a tile held more bracket keys than its LDS stage: lists incomplete
+    int tie_m, tie_a;                 // lo_m == hi_m (alo == ahi): the keys equal to it are counted, not gathered
 };
 
 template <typename T>
@@ -105,7 +106,8 @@ __device__ __forceinline__ void m1_find_bin(const uint32_t *hist, uint32_t rank,
 
 // Keys that bracket the ranks ra <= rb of the `count` keys sk[0], sk[stride], sk[2 stride], ...:
 // 11-bit MSD radix selection on key - kmin, both ranks in the same sweeps (a second histogram once
-// their prefixes part).  At most M1_PASSES digits are resolved; the bits below them are rounded
+// their prefixes part).  M1_PASSES digits are resolved (all of them while the two ranks share their
+// prefix: tied samples give ka == kb exactly); the bits below them are rounded
 // outwards (*ka <= key of rank ra, *kb >= key of rank rb), which widens a bracket by less than 2^-10
 // of an octave.  CLIP: only the keys inside [kmin, kmax] are histogrammed, the keys below kmin are
 // counted and taken off the ranks (most keys then cost a comparison instead of an LDS atomic).
@@ -120,7 +122,7 @@ __device__ bool m1_select2(const K *sk, int count, int stride, K kmin, K kmax, u
     const K width = kmax - kmin;
     const int bits = width ? BITS - (BITS == 64 ? __clzll((long long)width) : __clz((int)width)) : 0;
     const int passes = (bits + 10) / 11;
-    const int done = passes < M1_PASSES ? passes : M1_PASSES;
+    int done = 0;
     K pa = 0, pb = 0;
     if (CLIP) {
         if (tid < 2) s_cnt[tid] = 0;
@@ -146,7 +148,9 @@ __device__ bool m1_select2(const K *sk, int count, int stride, K kmin, K kmax, u
         ra -= nb;
         rb -= nb;
     }
-    for (int p = 0; p < done; ++p) {
+    // beyond M1_PASSES digits only while both ranks still share their prefix (ties need the exact key)
+    for (int p = 0; p < passes && (p < M1_PASSES || pa == pb); ++p) {
+        done = p + 1;
         const int shift = 11 * (passes - 1 - p);
         const bool same = pa == pb;
         for (int i = tid; i < 2 * M1_BINS; i += M1_THREADS) (&hist[0][0])[i] = 0;
@@ -276,8 +280,8 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_sample(const T *__restrict__ 
     const bool got_m = m1_bracket<K, S>(sk, s_kmin, s_kmax, want_lo, want_hi, hist, wtot, s_dig, s_bef, s_cnt, &klo, &khi);
     const T lo_v = val_of(klo), hi_v = val_of(khi);
     const bool finite = klo != ~(K)0 && khi != ~(K)0 && fabs(lo_v) <= (T)1e30 && fabs(hi_v) <= (T)1e30;
-    if (!got_m || !finite || open_lo || open_hi || klo == khi) {
-        // non-finite or (nearly) constant data, or a degenerate sample: the exact fallback takes the block
+    if (!got_m || !finite || open_lo || open_hi) {
+        // non-finite data or a degenerate sample: the exact fallback takes the block
         if (tid == 0) {
             s.lo_m = 1;
             s.hi_m = 0;
@@ -288,8 +292,11 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_sample(const T *__restrict__ 
         }
         return;
     }
-    const T mhat = lo_v + (hi_v - lo_v) / (T)2;
-    const double eps_v = fmax((double)hi_v - (double)mhat, (double)mhat - (double)lo_v);
+    // klo == khi: so many coefficients tie around the median (silence, quantised quiet passages) that the
+    // bracket is ONE value; it is then the median itself if the counts of the pass confirm it
+    const bool tie_m = klo == khi;
+    const T mhat = tie_m ? lo_v : lo_v + (hi_v - lo_v) / (T)2;
+    const double eps_v = tie_m ? 0.0 : fmax((double)hi_v - (double)mhat, (double)mhat - (double)lo_v);
     // the same sample as |d - mhat|
     __syncthreads();
     if (tid == 0) {
@@ -335,11 +342,15 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_sample(const T *__restrict__ 
         const double a_lo = (double)val_of(kalo), a_hi = open_above ? 0.0 : (double)val_of(kahi);
         const double slop = 16.0 * eps_t * (a_hi + fabs((double)mhat) + eps_v) + 1e-300;
         const double alo = a_lo - eps_v - slop, ahi = a_hi + eps_v + slop;
+        // with the median pinned, tied absolute deviations are counted the same way
+        const bool tie_a = tie_m && kalo == kahi && !open_above;
         s.lo_m = (unsigned long long)klo;
         s.hi_m = (unsigned long long)khi;
         s.mhat = (double)mhat;
-        s.alo = alo <= 0.0 ? -1.0 : (double)(T)alo;
-        s.ahi = open_above ? __longlong_as_double(0x7FF0000000000000ll) : (double)(T)ahi;
+        s.alo = tie_a ? a_lo : (alo <= 0.0 ? -1.0 : (double)(T)alo);
+        s.ahi = tie_a ? a_lo : (open_above ? __longlong_as_double(0x7FF0000000000000ll) : (double)(T)ahi);
+        s.tie_m = tie_m ? 1 : 0;
+        s.tie_a = tie_a ? 1 : 0;
         s.usable = 1;
         st[b] = s;
     }
@@ -353,7 +364,7 @@ template <typename T, bool FULL>
 __device__ __forceinline__ void m1_classify(const T (&d)[16], const bool (&live_in)[16], typename KeyT<T>::type lo,
                                             typename KeyT<T>::type hi, T mhat, T alo, T ahi, T *stage_m, T *stage_a,
                                             unsigned int *s_fill_m, unsigned int *s_fill_a, unsigned int &below_m,
-                                            unsigned int &below_a, bool &saw_nan) {
+                                            unsigned int &below_a, bool &saw_nan, bool tie_m, bool tie_a) {
     using K = typename KeyT<T>::type;
     constexpr int SUB = 8;
     const int lane = threadIdx.x & 63;
@@ -384,7 +395,7 @@ __device__ __forceinline__ void m1_classify(const T (&d)[16], const bool (&live_
                 for (int u = 0; u < SUB; ++u) {
                     const unsigned int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal[u] >> 32),
                                                                               __builtin_amdgcn_mbcnt_lo((unsigned int)bal[u], 0u));
-                    if (keep[u] && pos < M1_STAGE_M) stage_m[pos] = d[h + u];
+                    if (keep[u] && pos < M1_STAGE_M && !tie_m) stage_m[pos] = d[h + u];
                     base += (unsigned int)__popcll(bal[u]);
                 }
             }
@@ -411,7 +422,7 @@ __device__ __forceinline__ void m1_classify(const T (&d)[16], const bool (&live_
                 for (int u = 0; u < SUB; ++u) {
                     const unsigned int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal[u] >> 32),
                                                                               __builtin_amdgcn_mbcnt_lo((unsigned int)bal[u], 0u));
-                    if (keep[u] && pos < M1_STAGE_A) stage_a[pos] = d[h + u];
+                    if (keep[u] && pos < M1_STAGE_A && !tie_a) stage_a[pos] = d[h + u];
                     base += (unsigned int)__popcll(bal[u]);
                 }
             }
@@ -507,7 +518,9 @@ __global__ __launch_bounds__(256) void k_m1_gather(const T *__restrict__ x, Bloc
         }
         return;
     }
-    m1_classify<T, FULL>(d, live, lo, hi, mhat, alo, ahi, stage_m, stage_a, &s_fill_m, &s_fill_a, below_m, below_a, saw_nan);
+    const bool tie_m = st[b].tie_m != 0, tie_a = st[b].tie_a != 0;
+    m1_classify<T, FULL>(d, live, lo, hi, mhat, alo, ahi, stage_m, stage_a, &s_fill_m, &s_fill_a, below_m, below_a, saw_nan,
+                         tie_m, tie_a);
     for (int dd = 32; dd >= 1; dd >>= 1) {
         below_m += __shfl_xor(below_m, dd);
         below_a += __shfl_xor(below_a, dd);
@@ -518,12 +531,14 @@ __global__ __launch_bounds__(256) void k_m1_gather(const T *__restrict__ x, Bloc
     }
     if (saw_nan) s_nan = 1;
     __syncthreads();
-    const unsigned int cm = s_fill_m < M1_STAGE_M ? s_fill_m : M1_STAGE_M;
-    const unsigned int ca = s_fill_a < M1_STAGE_A ? s_fill_a : M1_STAGE_A;
+    // tied brackets: the keys are only counted (n_m / n_a), nothing is written
+    const unsigned int cm = tie_m ? 0u : (s_fill_m < M1_STAGE_M ? s_fill_m : M1_STAGE_M);
+    const unsigned int ca = tie_a ? 0u : (s_fill_a < M1_STAGE_A ? s_fill_a : M1_STAGE_A);
     if (tid == 0) {
-        if (s_fill_m > M1_STAGE_M || s_fill_a > M1_STAGE_A) st[b].spill = 1;
-        s_base_m = cm ? atomicAdd(&st[b].n_m, cm) : 0u;
-        s_base_a = ca ? atomicAdd(&st[b].n_a, ca) : 0u;
+        if ((!tie_m && s_fill_m > M1_STAGE_M) || (!tie_a && s_fill_a > M1_STAGE_A)) st[b].spill = 1;
+        const unsigned int add_m = tie_m ? s_fill_m : cm, add_a = tie_a ? s_fill_a : ca;
+        s_base_m = add_m ? atomicAdd(&st[b].n_m, add_m) : 0u;
+        s_base_a = add_a ? atomicAdd(&st[b].n_a, add_a) : 0u;
         if (s_below_m) atomicAdd(&st[b].below_m, s_below_m);
         if (s_below_a) atomicAdd(&st[b].below_a, s_below_a);
         if (s_nan) st[b].has_nan = 1;
@@ -552,10 +567,14 @@ __global__ void k_m1_check(const M1State *st, const int64_t *frames, int64_t n_b
     const M1State s = st[b];
     const int64_t n = frames[b], r0 = (n - 1) / 2, r1 = n / 2;
     const double nan = __longlong_as_double(0x7FF8000000000000ll);
-    const bool ok_m = s.usable && !s.has_nan && !s.spill && (int64_t)s.n_m <= cap_m && r0 >= (int64_t)s.below_m &&
-                      r1 - (int64_t)s.below_m < (int64_t)s.n_m;
-    const bool ok_a = ok_m && (int64_t)s.n_a <= cap_a && r0 >= (int64_t)s.below_a &&
-                      r1 - (int64_t)s.below_a < (int64_t)s.n_a;
+    const bool in_m = r0 >= (int64_t)s.below_m && r1 - (int64_t)s.below_m < (int64_t)s.n_m;
+    const bool in_a = r0 >= (int64_t)s.below_a && r1 - (int64_t)s.below_a < (int64_t)s.n_a;
+    const bool sane = s.usable && !s.has_nan && !s.spill;
+    // tied median bracket: the counts alone prove the median; otherwise it is selected from the list
+    const bool known_m = sane && s.tie_m && in_m;
+    const bool ok_m = sane && !s.tie_m && (int64_t)s.n_m <= cap_m && in_m;
+    const bool known_a = known_m && s.tie_a && in_a;
+    const bool ok_a = (ok_m || known_m) && !s.tie_a && (int64_t)s.n_a <= cap_a && in_a;
     len_m[b] = ok_m ? (int64_t)s.n_m : 0;
     len_a[b] = ok_a ? (int64_t)s.n_a : 0;
     below_m[b] = s.below_m;
@@ -564,9 +583,9 @@ __global__ void k_m1_check(const M1State *st, const int64_t *frames, int64_t n_b
     valid_a[b] = ok_a ? 1 : 0;
     // a NaN anywhere in the block: both medians are NaN (numpy), nothing left to select
     const bool is_nan = s.usable && s.has_nan;
-    resolved[b] = is_nan ? 1 : 0;
-    med[b] = nan;
-    mad[b] = nan;
+    resolved[b] = (is_nan || known_a) ? 1 : 0;
+    med[b] = known_m ? s.mhat : nan;
+    mad[b] = known_a ? s.alo : nan;
 }
 
 // Per block: does the second selection stand now that the median is known?
@@ -586,76 +605,88 @@ __global__ void k_m1_verify(const M1State *st, int64_t n_blocks, const int *vali
     if (ok_lo && ok_hi && t0 == t0 && t1 == t1) resolved[b] = 1;
 }
 
-// Exact fallback: one workgroup per unresolved block, 8-bit MSD radix passes over the coefficients
-// computed on the fly.  Returns the key of `rank`; *nan_seen is set when the block holds a NaN.
+// Exact fallback: one workgroup per unresolved block streams the block's coefficients (computed on
+// the fly): 11-bit MSD radix passes find the key of rank r0; the key of rank r1 = r0 or r0 + 1 is the
+// same key when enough keys tie with it, else the smallest larger key (one more sweep, no atomics).
+// Visits every key of the block: f(i, key) for i in [0, n), whole waves take every step and the loads
+// of UB steps are in flight together.
+template <typename T, typename F>
+__device__ __forceinline__ void m1_sweep(const T *in, int64_t n, T w0, T w1, bool absdev, T c, F f) {
+    constexpr int UB = 8;
+    const int64_t span = (int64_t)UB * M1_THREADS;
+    const int64_t n_pad = (n + span - 1) / span * span;
+    for (int64_t i0 = threadIdx.x; i0 < n_pad; i0 += span) {
+        T a0[UB], a1[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int64_t i = i0 + (int64_t)u * M1_THREADS;
+            a0[u] = i < n ? in[2 * i] : (T)0;
+            a1[u] = i < n ? in[2 * i + 1] : (T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            T v = m1_d1(w0, w1, a0[u], a1[u]);
+            if (absdev) v = fabs(v - c);
+            f(i0 + (int64_t)u * M1_THREADS < n, m1_key(v));
+        }
+    }
+}
+
+// Keys of ranks r0 <= r1 <= r0 + 1 of the block (or of its absolute deviations from c).
 template <typename T>
-__device__ typename KeyT<T>::type m1_slow_rank(const T *in, int64_t n, T w0, T w1, bool absdev, T c, uint64_t rank,
-                                               uint32_t *hist, uint32_t *s_dig, uint32_t *s_bef, int *nan_seen) {
+__device__ void m1_slow_pair(const T *in, int64_t n, T w0, T w1, bool absdev, T c, uint64_t r0, uint64_t r1,
+                             uint32_t *hist, uint32_t *wtot, uint32_t *s_dig, uint32_t *s_bef, unsigned long long *s_min,
+                             int *nan_seen, typename KeyT<T>::type *k0, typename KeyT<T>::type *k1) {
     using K = typename KeyT<T>::type;
-    constexpr int BITS = KeyT<T>::bits;
+    constexpr int BITS = KeyT<T>::bits, PASSES = (BITS + 10) / 11;
     const int tid = threadIdx.x;
     K prefix = 0;
-    for (int shift = BITS - 8; shift >= 0; shift -= 8) {
-        if (tid < 256) hist[tid] = 0;
+    uint32_t rank = (uint32_t)r0, in_bin = 0;
+    for (int p = 0; p < PASSES; ++p) {
+        const int shift = 11 * (PASSES - 1 - p);
+        for (int i = tid; i < M1_BINS; i += M1_THREADS) hist[i] = 0;
         __syncthreads();
-        // whole waves take every step; the loads of UB steps are in flight together
-        constexpr int UB = 8;
-        const int64_t span = (int64_t)UB * M1_THREADS;
-        const int64_t n_pad = (n + span - 1) / span * span;
-        for (int64_t i0 = tid; i0 < n_pad; i0 += span) {
-            T a0[UB], a1[UB];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const int64_t i = i0 + (int64_t)u * M1_THREADS;
-                a0[u] = i < n ? in[2 * i] : (T)0;
-                a1[u] = i < n ? in[2 * i + 1] : (T)0;
-            }
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                const bool in_range = i0 + (int64_t)u * M1_THREADS < n;
-                T v = m1_d1(w0, w1, a0[u], a1[u]);
-                if (absdev) v = fabs(v - c);
-                const K k = m1_key(v);
-                if (in_range && k == ~(K)0) *nan_seen = 1;
-                const bool match = in_range && (shift == BITS - 8 || (K)((k ^ prefix) >> (shift + 8 < BITS ? shift + 8 : 0)) == 0);
-                m1_hist_add(hist, (uint32_t)(k >> shift) & 255u, match);
-            }
-        }
+        m1_sweep<T>(in, n, w0, w1, absdev, c, [&](bool live, K k) {
+            if (live && k == ~(K)0) *nan_seen = 1;
+            const bool match = live && (p == 0 || (K)(k >> (shift + 11)) == prefix);
+            m1_hist_add(hist, (uint32_t)(k >> shift) & (M1_BINS - 1), match);
+        });
         __syncthreads();
-        if (tid < 64) {
-            const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
-            const uint32_t sum = c0 + c1 + c2 + c3;
-            uint32_t incl = sum;
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(incl, d);
-                if (tid >= d) incl += o;
-            }
-            const unsigned long long m = __ballot((uint64_t)incl > rank);
-            if (m && tid == (int)__ffsll((unsigned long long)m) - 1) {
-                uint32_t r = (uint32_t)rank - (incl - sum);
-                int dgt = 4 * tid;
-                uint32_t bef = incl - sum;
-                if (r >= c0) { r -= c0; bef += c0; ++dgt;
-                    if (r >= c1) { r -= c1; bef += c1; ++dgt;
-                        if (r >= c2) { r -= c2; bef += c2; ++dgt; } } }
-                *s_dig = (uint32_t)dgt;
-                *s_bef = bef;
-            }
-        }
-        __syncthreads();
-        prefix |= (K)(*s_dig) << shift;
+        m1_find_bin(hist, rank, wtot, s_dig, s_bef);
+        prefix = (prefix << 11) | (K)(*s_dig);
         rank -= *s_bef;
+        in_bin = hist[*s_dig];
         __syncthreads();
     }
-    return prefix;
+    *k0 = prefix;
+    if (r1 == r0 || rank + 1 < in_bin) {        // enough keys tie with rank r0's
+        *k1 = prefix;
+        return;
+    }
+    if (tid == 0) *s_min = ~0ull;
+    __syncthreads();
+    unsigned long long mn = ~0ull;
+    m1_sweep<T>(in, n, w0, w1, absdev, c, [&](bool live, K k) {
+        if (live && k > prefix && (unsigned long long)k < mn) mn = (unsigned long long)k;
+    });
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(mn, d);
+        mn = o < mn ? o : mn;
+    }
+    if ((tid & 63) == 0) atomicMin(s_min, mn);
+    __syncthreads();
+    *k1 = (K)(*s_min);
+    __syncthreads();
 }
 
 template <typename T>
 __global__ __launch_bounds__(M1_THREADS) void k_m1_fallback(const T *__restrict__ x, BlockGeom g, T w0, T w1,
                                                             const int *__restrict__ resolved, double *med, double *mad) {
     using K = typename KeyT<T>::type;
-    __shared__ uint32_t hist[256];
+    __shared__ uint32_t hist[M1_BINS];
+    __shared__ uint32_t wtot[M1_THREADS / 64];
     __shared__ uint32_t s_dig, s_bef;
+    __shared__ unsigned long long s_min;
     __shared__ int s_nan;
     const int64_t b = blockIdx.x;
     if (resolved[b]) return;
@@ -672,8 +703,8 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_fallback(const T *__restrict_
         return;
     }
     const uint64_t r0 = (uint64_t)((n - 1) / 2), r1 = (uint64_t)(n / 2);
-    const K k0 = m1_slow_rank<T>(in, n, w0, w1, false, (T)0, r0, hist, &s_dig, &s_bef, &s_nan);
-    const K k1 = r1 == r0 ? k0 : m1_slow_rank<T>(in, n, w0, w1, false, (T)0, r1, hist, &s_dig, &s_bef, &s_nan);
+    K k0, k1;
+    m1_slow_pair<T>(in, n, w0, w1, false, (T)0, r0, r1, hist, wtot, &s_dig, &s_bef, &s_min, &s_nan, &k0, &k1);
     __syncthreads();
     if (s_nan) {
         if (threadIdx.x == 0) {
@@ -684,12 +715,12 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_fallback(const T *__restrict_
     }
     const T a = val_of(k0), bb = val_of(k1);
     const T m = r0 == r1 ? a : (T)((a + bb) / (T)2);
-    const K q0 = m1_slow_rank<T>(in, n, w0, w1, true, m, r0, hist, &s_dig, &s_bef, &s_nan);
-    const K q1 = r1 == r0 ? q0 : m1_slow_rank<T>(in, n, w0, w1, true, m, r1, hist, &s_dig, &s_bef, &s_nan);
+    K q0, q1;
+    m1_slow_pair<T>(in, n, w0, w1, true, m, r0, r1, hist, wtot, &s_dig, &s_bef, &s_min, &s_nan, &q0, &q1);
     if (threadIdx.x == 0) {
         const T ta = val_of(q0), tb = val_of(q1);
         med[b] = (double)m;
-        mad[b] = s_nan ? nan : (double)(r0 == r1 ? ta : (T)((ta + tb) / (T)2));
+        mad[b] = s_nan ? nan : (double)(r0 == r1 ? ta : (T)((ta + tb) / (T)2));     // inf - inf
     }
 }
 

@@ -1,0 +1,50 @@
+"""Phase 2 (stereo, db4 level 2) on inputs that stress the threshold statistics: Gaussian noise,
+PCM16-quantised low-level noise (+-2 LSB: heavy ties), digital silence, half-silent blocks and
+strongly autocorrelated material.  64 clips of 60 s at 48 kHz, fp32.  Prints one JSON line per
+input with the time of the single-pass route and of the plain route (coefficient array + two full
+selections)."""
+import json, os, sys, time
+import numpy as np
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "audio-denoising_amd"))
+from adn_hip import get_engine
+e = get_engine(0)
+SR, n, clips = 48000, 60 * 48000, 64
+bs = e.denoise_block_frames(SR, n)
+starts = np.arange(0, n, bs, dtype=np.int64)
+off = np.concatenate([c * n + starts for c in range(clips)]) * 2
+lens = np.concatenate([np.minimum(bs, n - starts) for c in range(clips)])
+d_off, d_len = e._i64(off), e._i64(lens)
+g = torch.Generator(device="cuda").manual_seed(3)
+
+
+def make(kind):
+    x = torch.randn(clips * n, 2, device="cuda", generator=g) * 0.1
+    if kind == "pcm_quiet":
+        x = torch.round(x * 20.0) / 32768.0
+    elif kind == "silence":
+        x.zero_()
+    elif kind == "half_silent":
+        x.view(clips, n, 2)[:, : n // 2] = 0.0
+    elif kind == "lowpass":
+        x = torch.cumsum(x.view(clips, n, 2), dim=1).reshape(-1, 2) * 0.01
+    return x.reshape(-1).contiguous()
+
+
+for kind in ("gauss", "pcm_quiet", "silence", "half_silent", "lowpass"):
+    x = make(kind)
+    y = torch.empty_like(x)
+    res = {"input": kind}
+    for label, generic in (("single_pass_ms", False), ("plain_ms", True)):
+        e.force_generic(generic)
+        def run():
+            e.wavelet_denoise(x, d_off, d_len, y, d_off, n_ch=2, wavelet="db4", level=2, max_frames=int(lens.max()))
+        run(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(4):
+            run()
+        torch.cuda.synchronize()
+        res[label] = round((time.perf_counter() - t0) / 4 * 1e3, 3)
+    e.force_generic(False)
+    print(json.dumps(res), flush=True)
