@@ -70,6 +70,11 @@ class Engine:
         """Test hook: run the shape-generic kernels instead of the specialised ones."""
         self._check(self.lib.adn_set_option(self._h, 1, int(bool(on))))
 
+    def force_exact_fallback(self, on=True):
+        """Test hook: the single-pass threshold statistics of stereo blocks send every block to
+        their exact per-block fallback selection."""
+        self._check(self.lib.adn_set_option(self._h, 1, 2 if on else 0))
+
     def synchronize(self):
         self._check(self.lib.adn_synchronize(self._h))
 

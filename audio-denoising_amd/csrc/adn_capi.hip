@@ -110,7 +110,10 @@ int adn_set_stream(adn_ctx *c, void *s) {
 int adn_set_option(adn_ctx *c, int option, int value) {
     ADN_REQUIRE(c != nullptr, "ctx is null");
     ADN_REQUIRE(option == ADN_OPT_FORCE_GENERIC || option == ADN_OPT_ABLATE, "unknown option %d", option);
-    if (option == ADN_OPT_FORCE_GENERIC) c->force_generic = value != 0;
+    if (option == ADN_OPT_FORCE_GENERIC) {
+        c->force_generic = value == 1;
+        c->force_fallback = value == 2;
+    }
     if (option == ADN_OPT_ABLATE) c->ablate = value;
     return ADN_OK;
 }

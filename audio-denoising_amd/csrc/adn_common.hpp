@@ -55,6 +55,7 @@ struct Ctx {
     size_t ws_used = 0;        // bump pointer, reset per call
     int num_cus = 256;
     bool force_generic = false;   // test hook: skip the specialised kernels
+    bool force_fallback = false;  // test hook: the single-pass threshold statistics send every block to their exact fallback
     int ablate = 0;               // diagnostics: stages the fused STFT kernel skips (timing only)
 };
 

@@ -561,10 +561,11 @@ __global__ __launch_bounds__(256) void k_m1_gather(const T *__restrict__ x, Bloc
 // Per block: are the wanted ranks inside the gathered lists?  Descriptors for the two selections.
 __global__ void k_m1_check(const M1State *st, const int64_t *frames, int64_t n_blocks, int64_t cap_m, int64_t cap_a,
                            int64_t *len_m, int64_t *len_a, unsigned long long *below_m, unsigned long long *below_a,
-                           int *valid_m, int *valid_a, int *resolved, double *med, double *mad) {
+                           int *valid_m, int *valid_a, int *resolved, double *med, double *mad, int all_to_fallback) {
     const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (b >= n_blocks) return;
-    const M1State s = st[b];
+    M1State s = st[b];
+    if (all_to_fallback) s.usable = 0;               // test hook
     const int64_t n = frames[b], r0 = (n - 1) / 2, r1 = n / 2;
     const double nan = __longlong_as_double(0x7FF8000000000000ll);
     const bool in_m = r0 >= (int64_t)s.below_m && r1 - (int64_t)s.below_m < (int64_t)s.n_m;
@@ -779,7 +780,7 @@ static int stereo_mad_single_pass(Ctx *c, const T *d_in, const BlockGeom &g, int
     hipLaunchKernelGGL((k_m1_gather<T, false>), dim3((unsigned)g.n_blocks), dim3(256), 0, c->stream, d_in, g, w0, w1, st,
                        cand_m, cap_m, cand_a, cap_a, (int64_t)1);
     hipLaunchKernelGGL(k_m1_check, dim3(nbk), dim3(256), 0, c->stream, st, g.frames, g.n_blocks, cap_m, cap_a, len_m, len_a,
-                       below_m, below_a, valid_m, valid_a, resolved, med, mad);
+                       below_m, below_a, valid_m, valid_a, resolved, med, mad, c->force_fallback ? 1 : 0);
     ADN_HIP(hipGetLastError());
     SubsetSelect sm;
     sm.n_seg = g.n_blocks;

@@ -54,9 +54,11 @@ int adn_destroy(adn_ctx *ctx);
 int adn_set_stream(adn_ctx *ctx, void *hip_stream);
 /* Blocks the host until everything enqueued on the context's stream is done. */
 int adn_synchronize(adn_ctx *ctx);
-/* Tuning / test knobs.  ADN_OPT_FORCE_GENERIC (value != 0): run the shape-generic
+/* Tuning / test knobs.  ADN_OPT_FORCE_GENERIC, value 1: run the shape-generic
  * kernels even where a specialised one exists (binary32, n_fft = 2048; fused wavelet
- * tiles), so that tests can cover both. */
+ * tiles; single-pass threshold statistics of stereo blocks), so that tests can cover
+ * both.  Value 2: specialised kernels, but the single-pass threshold statistics hand
+ * every block to their exact per-block fallback.  0 restores normal operation. */
 /* ADN_OPT_ABLATE (diagnostics, results become WRONG): bit mask of stages the fused
  * binary32 STFT kernel skips - 1 analysis, 2 synthesis, 4 overlap-add - so that the
  * cost of each stage can be timed.  0 restores normal operation. */

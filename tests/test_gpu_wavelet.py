@@ -355,10 +355,17 @@ def test_stereo_single_pass_statistics_exact(dt, longest):
             yg, s2 = _stereo_batch(e, blocks, dt, thr_mode)
         finally:
             e.force_generic(False)
-        for name, a, b in zip(("sigma", "thresh", "zeroed"), s1, s2):
+        e.force_exact_fallback(True)                 # every block through the exact per-block fallback
+        try:
+            yf, s3 = _stereo_batch(e, blocks, dt, thr_mode)
+        finally:
+            e.force_exact_fallback(False)
+        for name, a, b, f in zip(("sigma", "thresh", "zeroed"), s1, s2, s3):
             assert np.array_equal(a, b, equal_nan=True), (name, thr_mode, a, b)
-        for (n, k), y, g in zip(spec, ys, yg):
+            assert np.array_equal(a, f, equal_nan=True), (name, thr_mode, a, f)
+        for (n, k), y, g, f in zip(spec, ys, yg, yf):
             assert np.array_equal(y, g, equal_nan=True), (n, k)
+            assert np.array_equal(y, f, equal_nan=True), (n, k)
     # oracle: sigma of every block (binary64 restatement on the same inputs)
     for (n, k), blk, sg in zip(spec, blocks, s1[0]):
         _, s_or, _ = orc.denoise_block(blk.astype(np.float64), "db4", 2, "soft")
