@@ -1,6 +1,6 @@
 """Phase 2 (stereo, db4 level 2) on inputs that stress the threshold statistics: Gaussian noise,
 PCM16-quantised low-level noise (+-2 LSB: heavy ties), digital silence, half-silent blocks and
-strongly autocorrelated material.  64 clips of 60 s at 48 kHz, fp32.  Prints one JSON line per
+autocorrelated material (first-order autoregressive noise, a random walk).  64 clips of 60 s at 48 kHz, fp32.  Prints one JSON line per
 input with the time of the single-pass route and of the plain route (coefficient array + two full
 selections)."""
 import json, os, sys, time
@@ -29,10 +29,18 @@ def make(kind):
         x.view(clips, n, 2)[:, : n // 2] = 0.0
     elif kind == "lowpass":
         x = torch.cumsum(x.view(clips, n, 2), dim=1).reshape(-1, 2) * 0.01
+    elif kind.startswith("ar"):
+        # first-order autoregressive noise, coefficient rho (truncated impulse response)
+        rho = float(kind[2:])
+        k = torch.pow(torch.tensor(rho, device="cuda"), torch.arange(255, -1, -1, device="cuda")).view(1, 1, -1)
+        xt = x.view(clips, n, 2).permute(0, 2, 1).reshape(clips * 2, 1, n)
+        xt = torch.nn.functional.conv1d(torch.nn.functional.pad(xt, (255, 0)), k)
+        x = (xt.view(clips, 2, n).permute(0, 2, 1) * (1.0 - rho * rho) ** 0.5).reshape(-1, 2)
     return x.reshape(-1).contiguous()
 
 
-for kind in ("gauss", "pcm_quiet", "silence", "half_silent", "lowpass"):
+kinds = sys.argv[1:] or ["gauss", "pcm_quiet", "silence", "half_silent", "ar0.9", "ar0.99", "lowpass"]
+for kind in kinds:
     x = make(kind)
     y = torch.empty_like(x)
     res = {"input": kind}
