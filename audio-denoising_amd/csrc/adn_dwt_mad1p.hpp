@@ -613,20 +613,28 @@ __global__ void k_m1_verify(const M1State *st, int64_t n_blocks, const int *vali
 // of UB steps are in flight together.
 template <typename T, typename F>
 __device__ __forceinline__ void m1_sweep(const T *in, int64_t n, T w0, T w1, bool absdev, T c, F f) {
-    constexpr int UB = 8;
+    using V2 = T __attribute__((ext_vector_type(2)));
+    constexpr int UB = 16;
     const int64_t span = (int64_t)UB * M1_THREADS;
     const int64_t n_pad = (n + span - 1) / span * span;
+    const bool vec = (reinterpret_cast<uintptr_t>(in) & (sizeof(V2) - 1)) == 0;      // one load per frame
     for (int64_t i0 = threadIdx.x; i0 < n_pad; i0 += span) {
-        T a0[UB], a1[UB];
+        V2 q[UB];
+        if (vec && i0 - threadIdx.x + span <= n) {
+            const V2 *v2 = reinterpret_cast<const V2 *>(in);
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            const int64_t i = i0 + (int64_t)u * M1_THREADS;
-            a0[u] = i < n ? in[2 * i] : (T)0;
-            a1[u] = i < n ? in[2 * i + 1] : (T)0;
+            for (int u = 0; u < UB; ++u) q[u] = v2[i0 + (int64_t)u * M1_THREADS];
+        } else {
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const int64_t i = i0 + (int64_t)u * M1_THREADS;
+                q[u].x = i < n ? in[2 * i] : (T)0;
+                q[u].y = i < n ? in[2 * i + 1] : (T)0;
+            }
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-            T v = m1_d1(w0, w1, a0[u], a1[u]);
+            T v = m1_d1(w0, w1, q[u].x, q[u].y);
             if (absdev) v = fabs(v - c);
             f(i0 + (int64_t)u * M1_THREADS < n, m1_key(v));
         }
