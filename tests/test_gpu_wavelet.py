@@ -375,3 +375,32 @@ def test_stereo_single_pass_statistics_exact(dt, longest):
             # the coefficients are rounded in the block's dtype: a few ulps of the largest sample
             scale = max(float(np.max(np.abs(blk))), 1e-3)
             assert abs(sg - s_or) <= (1e-6 if dt == torch.float32 else 1e-14) * scale, (n, k, sg, s_or)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_stereo_single_pass_edge_lengths(dt):
+    """Block lengths around the single-pass route's internal sizes (sample size 16384, gather tile
+    4096): batches of only short blocks (no whole tile at all), exact multiples of a tile, one
+    frame more or less, and a batch whose longest block is just past the sample size."""
+    e = engine()
+    rng = np.random.default_rng(101)
+    npdt = np.float32 if dt == torch.float32 else np.float64
+    for lens in ([1, 2, 3, 5, 100, 4095], [4096, 8192, 12288, 16384, 4097, 8191], [16385, 16383, 20480, 1, 32768, 40961]):
+        blocks = [(0.2 * rng.standard_normal((n, 2))).astype(npdt) for n in lens]
+        ys, s1 = _stereo_batch(e, blocks, dt)
+        e.force_generic(True)
+        try:
+            yg, s2 = _stereo_batch(e, blocks, dt)
+        finally:
+            e.force_generic(False)
+        e.force_exact_fallback(True)
+        try:
+            yf, s3 = _stereo_batch(e, blocks, dt)
+        finally:
+            e.force_exact_fallback(False)
+        for a, b, f in zip(s1, s2, s3):
+            assert np.array_equal(a, b, equal_nan=True), (lens, a, b)
+            assert np.array_equal(a, f, equal_nan=True), (lens, a, f)
+        for n, y, g, f in zip(lens, ys, yg, yf):
+            assert np.array_equal(y, g, equal_nan=True), n
+            assert np.array_equal(y, f, equal_nan=True), n
