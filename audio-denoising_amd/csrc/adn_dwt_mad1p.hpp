@@ -17,9 +17,13 @@
 //   4. k_m1_verify proves the second selection: both order statistics must lie inside
 //      (alo + e, ahi - e) with e = |median - m^| + rounding slack; then every key counted as
 //      "below" really is below them and every key left out above really is above.
-//   5. k_m1_fallback: blocks that fail any check (bracket missed, list overflow, constant or
-//      non-finite data) are selected exactly by one workgroup streaming the block (radix passes
-//      over the on-the-fly coefficients).  Resolved blocks cost it one early exit.
+//   5. A bracket that is ONE value (silence, quantised quiet passages: so many coefficients tie
+//      that sample ranks lo and hi hold the same key) gathers nothing: the keys equal to it are
+//      counted, and the counts alone prove the median (and, with the median pinned, the deviation).
+//   6. k_m1_fallback: blocks that fail any check (bracket missed, list or stage overflow, non-finite
+//      data, strongly autocorrelated coefficients for which a run of 16 frames is worth few samples)
+//      are selected exactly by one workgroup streaming the block (11-bit radix passes over the
+//      on-the-fly coefficients).  Resolved blocks cost it one early exit.
 //
 // Every result is an exact order statistic of the same multiset the plain route selects from.
 #pragma once
