@@ -740,8 +740,10 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_fallback(const T *__restrict_
 // ---------------------------------------------------------------- host side
 template <typename T>
 static int64_t m1_cap(int64_t max_frames, double frac) {
+    // a block no longer than the sample is gathered whole; longer ones hold `frac` of their keys in the bracket
     const int64_t want = (int64_t)((double)max_frames * frac) + 1024;
-    return want > M1<T>::S ? want : M1<T>::S;
+    const int64_t whole = max_frames < M1<T>::S ? max_frames : M1<T>::S;
+    return want > whole ? want : whole;
 }
 // Blocks this long (and shorter) take the single-pass route: both candidate lists must fit the LDS select.
 template <typename T>
