@@ -745,7 +745,9 @@ static int64_t m1_cap(int64_t max_frames, double frac) {
     const int64_t whole = max_frames < M1<T>::S ? max_frames : M1<T>::S;
     return want > whole ? want : whole;
 }
-// Blocks this long (and shorter) take the single-pass route: both candidate lists must fit the LDS select.
+// Blocks this long (and shorter) take the single-pass route: both candidate lists must fit the subset select
+// (about a million frames; lists beyond the LDS capacity, i.e. blocks beyond ~299 K frames in binary32 and ~145 K
+// in binary64, are selected in memory).
 template <typename T>
 static bool m1_applicable(const Ctx *c, int64_t max_frames) {
     return !c->force_generic &&

@@ -41,7 +41,7 @@ size_t select_ws_bytes(int64_t n_seg, int64_t max_len);
 // Median of segments of which only a gathered SUBSET is at hand (the keys inside a value bracket): list s holds
 // d_len[s] keys at d_cand + s * cap; the ranks are those of the original segment (d_orig_len[s] keys) minus
 // d_below[s], the number of its keys below the bracket.  Lists with d_valid[s] == 0 are skipped (d_out untouched).
-// The whole list is staged in LDS: cap <= select_subset_max_keys(sizeof key).
+// cap <= select_subset_max_keys(sizeof key); lists that fit LDS are staged there whole.
 struct SubsetSelect {
     int64_t n_seg = 0, cap = 0;
     const int64_t *d_len = nullptr, *d_orig_len = nullptr;

@@ -92,7 +92,7 @@ struct SubsetRanks {
     const unsigned long long *below;      // keys of the original segment below the bracket
     const int *valid;                     // 0: skip this segment
     const unsigned long long *lohi;       // bracket keys [2*seg], [2*seg+1]: every key lies between them
-    double *pair = nullptr;               // optional (LDS kernel): the two order statistics, [2*seg], [2*seg+1]
+    double *pair = nullptr;               // optional: the two order statistics, [2*seg], [2*seg+1]
 };
 
 template <typename T, int XF>
@@ -384,6 +384,10 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
         } else {
             const T a = val_of(k0), b = val_of(k1);
             res = select_result<T>(a, b, r0 == r1, frac, mode);
+            if (sub.pair) {
+                sub.pair[2 * seg] = (double)a;
+                sub.pair[2 * seg + 1] = (double)b;
+            }
         }
         out[seg] = res;
         if (mm.out) {
@@ -1449,28 +1453,48 @@ int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {
 template int launch_select<float>(Ctx *, const float *, const SelectArgs &);
 template int launch_select<double>(Ctx *, const double *, const SelectArgs &);
 
-size_t select_subset_max_keys(size_t key_bytes) { return SUBSET_LDS_BYTES / key_bytes; }
+// Lists up to this many keys are staged whole in LDS (one workgroup per CU); longer ones, up to
+// select_subset_max_keys, are walked in memory by the general kernel (they sit in L2).
+static size_t subset_lds_keys(size_t key_bytes) { return SUBSET_LDS_BYTES / key_bytes; }
+size_t select_subset_max_keys(size_t key_bytes) { return (size_t)1 << 17; }
 
 template <typename T>
 int launch_select_subset(Ctx *c, const T *d_cand, const SubsetSelect &a) {
     using K = typename KeyT<T>::type;
     if (a.n_seg <= 0) return ADN_OK;
-    ADN_REQUIRE((size_t)a.cap <= select_subset_max_keys(sizeof(K)), "internal: candidate lists too long for the LDS select");
-    const size_t dyn = (size_t)a.cap * sizeof(K);
+    ADN_REQUIRE((size_t)a.cap <= select_subset_max_keys(sizeof(K)), "internal: candidate lists too long for the subset select");
     const MaskedMean mm{nullptr, 1, 0, nullptr};
     SubsetRanks sub{a.d_orig_len, 1, 0, a.d_below, a.d_valid, nullptr};
     sub.pair = a.d_pair;
-    constexpr int NT = 1024;                       // lists of tens of thousands of keys: few keys per lane in every sweep
-    if (a.xform == XF_ABSDEV) {
-        auto kern = k_select_lds<T, XF_ABSDEV, false, NT>;
-        ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        hipLaunchKernelGGL(kern, dim3((unsigned)a.n_seg), dim3(NT), dyn, c->stream, d_cand, (const int64_t *)nullptr, a.cap,
-                           a.d_len, (int64_t)1, (int64_t)0, (int)SEL_MEDIAN, 50.0, a.d_center, a.d_out, mm, sub);
+    const double *center = a.xform == XF_ABSDEV ? a.d_center : nullptr;
+    if ((size_t)a.cap <= subset_lds_keys(sizeof(K))) {
+        const size_t dyn = (size_t)a.cap * sizeof(K);
+        constexpr int NT = 1024;                   // lists of tens of thousands of keys: few keys per lane in every sweep
+        if (a.xform == XF_ABSDEV) {
+            auto kern = k_select_lds<T, XF_ABSDEV, false, NT>;
+            ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            hipLaunchKernelGGL(kern, dim3((unsigned)a.n_seg), dim3(NT), dyn, c->stream, d_cand, (const int64_t *)nullptr, a.cap,
+                               a.d_len, (int64_t)1, (int64_t)0, (int)SEL_MEDIAN, 50.0, center, a.d_out, mm, sub);
+        } else {
+            auto kern = k_select_lds<T, XF_NONE, false, NT>;
+            ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            hipLaunchKernelGGL(kern, dim3((unsigned)a.n_seg), dim3(NT), dyn, c->stream, d_cand, (const int64_t *)nullptr, a.cap,
+                               a.d_len, (int64_t)1, (int64_t)0, (int)SEL_MEDIAN, 50.0, center, a.d_out, mm, sub);
+        }
     } else {
-        auto kern = k_select_lds<T, XF_NONE, false, NT>;
-        ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        hipLaunchKernelGGL(kern, dim3((unsigned)a.n_seg), dim3(NT), dyn, c->stream, d_cand, (const int64_t *)nullptr, a.cap,
-                           a.d_len, (int64_t)1, (int64_t)0, (int)SEL_MEDIAN, 50.0, (const double *)nullptr, a.d_out, mm, sub);
+        const int lds_keys = (int)(SEL_LDS_BYTES / sizeof(K));
+        const size_t dyn = 2 * (size_t)lds_keys * sizeof(K);
+        if (a.xform == XF_ABSDEV) {
+            auto kern = k_select<T, XF_ABSDEV>;
+            ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            hipLaunchKernelGGL(kern, dim3((unsigned)a.n_seg), dim3(SEL_THREADS), dyn, c->stream, d_cand, (const int64_t *)nullptr,
+                               a.cap, a.d_len, (int64_t)1, (int64_t)0, (int)SEL_MEDIAN, 50.0, center, a.d_out, lds_keys, mm, sub);
+        } else {
+            auto kern = k_select<T, XF_NONE>;
+            ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+            hipLaunchKernelGGL(kern, dim3((unsigned)a.n_seg), dim3(SEL_THREADS), dyn, c->stream, d_cand, (const int64_t *)nullptr,
+                               a.cap, a.d_len, (int64_t)1, (int64_t)0, (int)SEL_MEDIAN, 50.0, center, a.d_out, lds_keys, mm, sub);
+        }
     }
     ADN_HIP(hipGetLastError());
     return ADN_OK;

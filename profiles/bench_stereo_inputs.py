@@ -1,6 +1,6 @@
 """Phase 2 (stereo, db4 level 2) on inputs that stress the threshold statistics: Gaussian noise,
 PCM16-quantised low-level noise (+-2 LSB: heavy ties), digital silence, half-silent blocks and
-autocorrelated material (first-order autoregressive noise, a random walk).  64 clips of 60 s at 48 kHz, fp32.  Prints one JSON line per
+autocorrelated material (first-order autoregressive noise, a random walk).  64 clips of 60 s at 48 kHz, fp32 (ADN_BENCH_DTYPE=fp64, ADN_BENCH_SECONDS=... change that).  Prints one JSON line per
 input with the time of the single-pass route and of the plain route (coefficient array + two full
 selections)."""
 import json, os, sys, time
@@ -10,7 +10,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, "audio-denoising_amd"))
 from adn_hip import get_engine
 e = get_engine(0)
-SR, n, clips = 48000, 60 * 48000, 64
+DT = torch.float64 if os.environ.get("ADN_BENCH_DTYPE", "fp32") == "fp64" else torch.float32
+SR, n, clips = 48000, int(os.environ.get("ADN_BENCH_SECONDS", "60")) * 48000, 64
 bs = e.denoise_block_frames(SR, n)
 starts = np.arange(0, n, bs, dtype=np.int64)
 off = np.concatenate([c * n + starts for c in range(clips)]) * 2
@@ -36,14 +37,14 @@ def make(kind):
         xt = x.view(clips, n, 2).permute(0, 2, 1).reshape(clips * 2, 1, n)
         xt = torch.nn.functional.conv1d(torch.nn.functional.pad(xt, (255, 0)), k)
         x = (xt.view(clips, 2, n).permute(0, 2, 1) * (1.0 - rho * rho) ** 0.5).reshape(-1, 2)
-    return x.reshape(-1).contiguous()
+    return x.reshape(-1).contiguous().to(DT)
 
 
 kinds = sys.argv[1:] or ["gauss", "pcm_quiet", "silence", "half_silent", "ar0.9", "ar0.99", "lowpass"]
 for kind in kinds:
     x = make(kind)
     y = torch.empty_like(x)
-    res = {"input": kind}
+    res = {"input": kind, "dtype": str(DT).split(".")[-1], "seconds": n // SR}
     for label, generic in (("single_pass_ms", False), ("plain_ms", True)):
         e.force_generic(generic)
         def run():

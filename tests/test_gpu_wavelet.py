@@ -309,13 +309,15 @@ def _stereo_batch(e, blocks, dt, thr_mode="soft"):
     return [o[a:a + 2 * l].reshape(l, 2) for a, l in zip(off, lens)], [host(s) for s in st]
 
 
-@pytest.mark.parametrize("dt,longest", [(torch.float32, 290000), (torch.float64, 120000)])
+@pytest.mark.parametrize("dt,longest", [(torch.float32, 290000), (torch.float32, 400000), (torch.float64, 120000),
+                                        (torch.float64, 200000)])
 def test_stereo_single_pass_statistics_exact(dt, longest):
     """Stereo blocks take their threshold statistics from one pass over the input (sample ->
     brackets -> gather -> exact selection among the gathered keys, verified, exact fallback).
     Sigma, threshold, zero counts and output must EQUAL those of the plain route (coefficient
     array + two full selections) for Gaussian, heavy-tailed, quantised, bimodal, half-silent,
-    constant, silent, NaN-carrying, short and one-frame blocks, and match the oracle."""
+    constant, silent, NaN-carrying, short and one-frame blocks, and match the oracle.  The longer
+    size of each dtype makes the candidate lists too long for LDS: they are then selected in memory."""
     e = engine()
     rng = np.random.default_rng(77)
     npdt = np.float32 if dt == torch.float32 else np.float64
