@@ -541,7 +541,7 @@ static int channel_denoise(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t
     // stereo at the reference's level 2 has three coefficients per frame: that shape is compiled in
     const bool three = NCH == 2 && m.n_coef == 3 && m.n_approx == 1 && m.n_d1 == 1;
     double *thresh = nullptr;
-    if (three && m1_applicable<T>(c, max_frames)) {
+    if (three && m1_applicable<T>(c, g.n_blocks, max_frames)) {
         // threshold statistics in one pass over the input, no coefficient array
         ADN_TRY(ws_reserve(c, m1_ws_bytes<T>(g.n_blocks, max_frames)));
         ADN_TRY(stereo_mad_single_pass<T>(c, d_in, g, max_frames, m.W[2][0], m.W[2][1], d_sigma, d_thresh, &thresh));

@@ -55,6 +55,7 @@ struct SubsetSelect {
 template <typename T>
 int launch_select_subset(Ctx *c, const T *d_cand, const SubsetSelect &a);
 size_t select_subset_max_keys(size_t key_bytes);
+size_t select_subset_lds_keys(size_t key_bytes);   // lists up to this length are staged in LDS
 
 // -------------------------------------------------------------- wavelets
 template <typename T>

@@ -1457,6 +1457,7 @@ template int launch_select<double>(Ctx *, const double *, const SelectArgs &);
 // select_subset_max_keys, are walked in memory by the general kernel (they sit in L2).
 static size_t subset_lds_keys(size_t key_bytes) { return SUBSET_LDS_BYTES / key_bytes; }
 size_t select_subset_max_keys(size_t key_bytes) { return (size_t)1 << 17; }
+size_t select_subset_lds_keys(size_t key_bytes) { return subset_lds_keys(key_bytes); }
 
 template <typename T>
 int launch_select_subset(Ctx *c, const T *d_cand, const SubsetSelect &a) {

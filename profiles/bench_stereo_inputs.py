@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(REPO, "audio-denoising_amd"))
 from adn_hip import get_engine
 e = get_engine(0)
 DT = torch.float64 if os.environ.get("ADN_BENCH_DTYPE", "fp32") == "fp64" else torch.float32
-SR, n, clips = 48000, int(os.environ.get("ADN_BENCH_SECONDS", "60")) * 48000, 64
+SR, n, clips = 48000, int(os.environ.get("ADN_BENCH_SECONDS", "60")) * 48000, int(os.environ.get("ADN_BENCH_CLIPS", "64"))
 bs = e.denoise_block_frames(SR, n)
 starts = np.arange(0, n, bs, dtype=np.int64)
 off = np.concatenate([c * n + starts for c in range(clips)]) * 2
