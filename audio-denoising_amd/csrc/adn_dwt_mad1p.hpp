@@ -14,7 +14,7 @@
 //      counted, keys inside gathered (~3.5 % and ~9 % of the block).
 //   3. Exact selection among the gathered keys (LDS radix select with rank offsets): the median,
 //      then |d - median| of the second list.
-//   4. k_m1_verify proves the second selection: both order statistics must lie inside
+//   4. m1_verified (first step of the last kernel) proves the second selection: both order statistics must lie inside
 //      (alo + e, ahi - e) with e = |median - m^| + rounding slack; then every key counted as
 //      "below" really is below them and every key left out above really is above.
 //   5. A bracket that is ONE value (silence, quantised quiet passages: so many coefficients tie
@@ -593,21 +593,16 @@ __global__ void k_m1_check(const M1State *st, const int64_t *frames, int64_t n_b
     mad[b] = known_a ? s.alo : nan;
 }
 
-// Per block: does the second selection stand now that the median is known?
+// Does the second selection of a block stand now that its median is known?
 template <typename T>
-__global__ void k_m1_verify(const M1State *st, int64_t n_blocks, const int *valid_a, const double *med,
-                            const double *pair_a, int *resolved) {
-    const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (b >= n_blocks || resolved[b] || !valid_a[b]) return;
-    const M1State s = st[b];
+__device__ __forceinline__ bool m1_verified(const M1State &s, double med, double t0, double t1) {
     const double eps_t = sizeof(T) == 4 ? 1.1920929e-7 : 2.220446049250313e-16;
-    const double c = (double)(T)med[b];
-    const double t0 = pair_a[2 * b], t1 = pair_a[2 * b + 1];
+    const double c = (double)(T)med;
     const double span = fabs(t1) + fabs(c) + fabs(s.mhat) + (s.ahi <= 1.7e308 ? fabs(s.ahi) : 0.0);
     const double e = fabs(c - s.mhat) * (1.0 + 4.0 * eps_t) + 8.0 * eps_t * span + 1e-300;
     const bool ok_lo = s.alo < 0.0 || t0 > s.alo + e;
     const bool ok_hi = !(s.ahi <= 1.7e308) || t1 < s.ahi - e;
-    if (ok_lo && ok_hi && t0 == t0 && t1 == t1) resolved[b] = 1;
+    return ok_lo && ok_hi && t0 == t0 && t1 == t1;
 }
 
 // Exact fallback: one workgroup per unresolved block streams the block's coefficients (computed on
@@ -692,9 +687,15 @@ __device__ void m1_slow_pair(const T *in, int64_t n, T w0, T w1, bool absdev, T 
     __syncthreads();
 }
 
+// Last kernel of the statistics, one workgroup per block: the block's second selection is verified;
+// a block that is not resolved by then is selected exactly here; the universal threshold
+// sigma * sqrt(2 ln frames) is written (frames == 1 gives 0).
 template <typename T>
 __global__ __launch_bounds__(M1_THREADS) void k_m1_fallback(const T *__restrict__ x, BlockGeom g, T w0, T w1,
-                                                            const int *__restrict__ resolved, double *med, double *mad) {
+                                                            const M1State *__restrict__ st, const int *__restrict__ resolved,
+                                                            const int *__restrict__ valid_a, const double *__restrict__ pair_a,
+                                                            double *med, double *mad, double *thresh, double *sigma_out,
+                                                            double *thresh_out) {
     using K = typename KeyT<T>::type;
     __shared__ uint32_t hist[M1_BINS];
     __shared__ uint32_t wtot[M1_THREADS / 64];
@@ -702,16 +703,27 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_fallback(const T *__restrict_
     __shared__ unsigned long long s_min;
     __shared__ int s_nan;
     const int64_t b = blockIdx.x;
-    if (resolved[b]) return;
     const int64_t n = g.frames[b];
-    const T *in = x + g.in_off[b];
     const double nan = __longlong_as_double(0x7FF8000000000000ll);
+    auto finish = [&](double sigma) {
+        const double t = sigma * sqrt(2.0 * log((double)n));
+        thresh[b] = t;
+        if (sigma_out) sigma_out[b] = sigma;
+        if (thresh_out) thresh_out[b] = t;
+    };
+    const bool done = resolved[b] || (valid_a[b] && m1_verified<T>(st[b], med[b], pair_a[2 * b], pair_a[2 * b + 1]));
+    if (done) {
+        if (threadIdx.x == 0) finish(mad[b]);
+        return;
+    }
+    const T *in = x + g.in_off[b];
     if (threadIdx.x == 0) s_nan = 0;
     __syncthreads();
     if (n <= 0) {
         if (threadIdx.x == 0) {
             med[b] = nan;
             mad[b] = nan;
+            finish(nan);
         }
         return;
     }
@@ -723,6 +735,7 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_fallback(const T *__restrict_
         if (threadIdx.x == 0) {
             med[b] = nan;
             mad[b] = nan;
+            finish(nan);
         }
         return;
     }
@@ -732,8 +745,10 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_fallback(const T *__restrict_
     m1_slow_pair<T>(in, n, w0, w1, true, m, r0, r1, hist, wtot, &s_dig, &s_bef, &s_min, &s_nan, &q0, &q1);
     if (threadIdx.x == 0) {
         const T ta = val_of(q0), tb = val_of(q1);
+        const double sg = s_nan ? nan : (double)(r0 == r1 ? ta : (T)((ta + tb) / (T)2));     // inf - inf
         med[b] = (double)m;
-        mad[b] = s_nan ? nan : (double)(r0 == r1 ? ta : (T)((ta + tb) / (T)2));     // inf - inf
+        mad[b] = sg;
+        finish(sg);
     }
 }
 
@@ -822,11 +837,8 @@ static int stereo_mad_single_pass(Ctx *c, const T *d_in, const BlockGeom &g, int
     sa.d_out = mad;
     sa.d_pair = pair_a;
     ADN_TRY(launch_select_subset<T>(c, cand_a, sa));
-    hipLaunchKernelGGL((k_m1_verify<T>), dim3(nbk), dim3(256), 0, c->stream, st, g.n_blocks, valid_a, med, pair_a, resolved);
-    hipLaunchKernelGGL((k_m1_fallback<T>), dim3((unsigned)g.n_blocks), dim3(M1_THREADS), 0, c->stream, d_in, g, w0, w1,
-                       resolved, med, mad);
-    hipLaunchKernelGGL(k_universal_threshold, dim3(nbk), dim3(256), 0, c->stream, g.frames, g.n_blocks, mad, thresh,
-                       d_sigma_out, d_thresh_out);
+    hipLaunchKernelGGL((k_m1_fallback<T>), dim3((unsigned)g.n_blocks), dim3(M1_THREADS), 0, c->stream, d_in, g, w0, w1, st,
+                       resolved, valid_a, pair_a, med, mad, thresh, d_sigma_out, d_thresh_out);
     ADN_HIP(hipGetLastError());
     *thresh_ws = thresh;
     return ADN_OK;
