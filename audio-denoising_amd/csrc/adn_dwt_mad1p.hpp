@@ -107,20 +107,45 @@ __device__ __forceinline__ void m1_find_bin(const uint32_t *hist, uint32_t rank,
     }
     __syncthreads();
 }
+// The bins of two ranks of the SAME histogram from one scan: results in dig[0..1], bef[0..1].
+__device__ __forceinline__ void m1_find_bin2(const uint32_t *hist, uint32_t ra, uint32_t rb, uint32_t *wtot,
+                                             uint32_t *dig, uint32_t *bef) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t c0 = hist[2 * tid], c1 = hist[2 * tid + 1], sum = c0 + c1;
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += wtot[w];
+    incl += base;
+    const uint32_t excl = incl - sum;
+    if (excl <= ra && ra < incl) {
+        const bool second = ra >= excl + c0;
+        dig[0] = (uint32_t)(2 * tid + (second ? 1 : 0));
+        bef[0] = excl + (second ? c0 : 0u);
+    }
+    if (excl <= rb && rb < incl) {
+        const bool second = rb >= excl + c0;
+        dig[1] = (uint32_t)(2 * tid + (second ? 1 : 0));
+        bef[1] = excl + (second ? c0 : 0u);
+    }
+    __syncthreads();
+}
 
-// Keys that bracket the ranks ra <= rb of the `count` keys sk[0], sk[stride], sk[2 stride], ...:
-// 11-bit MSD radix selection on key - kmin, both ranks in the same sweeps (a second histogram once
-// their prefixes part).  M1_PASSES digits are resolved (all of them while the two ranks share their
-// prefix: tied samples give ka == kb exactly); the bits below them are rounded
-// outwards (*ka <= key of rank ra, *kb >= key of rank rb), which widens a bracket by less than 2^-10
-// of an octave.  CLIP: only the keys inside [kmin, kmax] are histogrammed, the keys below kmin are
-// counted and taken off the ranks (most keys then cost a comparison instead of an LDS atomic).
-// Returns false when a rank falls outside [kmin, kmax] (CLIP only).
+// Keys that bracket the ranks ra <= rb of the S sample keys in LDS: 11-bit MSD radix selection on
+// key - kmin, both ranks in the same sweeps (a second histogram once their prefixes part).
+// M1_PASSES digits are resolved (all of them while the two ranks share their prefix: tied samples
+// give ka == kb exactly); the bits below them are rounded outwards (*ka <= key of rank ra,
+// *kb >= key of rank rb), which widens a bracket by less than 2^-10 of an octave.
 static constexpr int M1_PASSES = 2;
-template <typename K, bool CLIP>
-__device__ bool m1_select2(const K *sk, int count, int stride, K kmin, K kmax, uint32_t ra, uint32_t rb,
-                           uint32_t (*hist)[M1_BINS], uint32_t (*wtot)[M1_THREADS / 64], uint32_t *s_dig,
-                           uint32_t *s_bef, uint32_t *s_cnt, K *ka, K *kb) {
+template <typename K, int S>
+__device__ void m1_select2(const K *sk, K kmin, K kmax, uint32_t ra, uint32_t rb, uint32_t (*hist)[M1_BINS],
+                           uint32_t (*wtot)[M1_THREADS / 64], uint32_t *s_dig, uint32_t *s_bef, K *ka, K *kb) {
     constexpr int BITS = (int)sizeof(K) * 8;
     const int tid = threadIdx.x;
     const K width = kmax - kmin;
@@ -128,30 +153,6 @@ __device__ bool m1_select2(const K *sk, int count, int stride, K kmin, K kmax, u
     const int passes = (bits + 10) / 11;
     int done = 0;
     K pa = 0, pb = 0;
-    if (CLIP) {
-        if (tid < 2) s_cnt[tid] = 0;
-        __syncthreads();
-        uint32_t below = 0, inside = 0;
-        for (int j = tid; j < count; j += M1_THREADS) {
-            const K k = sk[(size_t)j * stride];
-            below += k < kmin;
-            inside += (K)(k - kmin) <= width;
-        }
-        for (int d = 32; d >= 1; d >>= 1) {
-            below += __shfl_xor(below, d);
-            inside += __shfl_xor(inside, d);
-        }
-        if ((tid & 63) == 0) {
-            atomicAdd(&s_cnt[0], below);
-            atomicAdd(&s_cnt[1], inside);
-        }
-        __syncthreads();
-        const uint32_t nb = s_cnt[0], ni = s_cnt[1];
-        __syncthreads();
-        if (ra < nb || rb - nb >= ni) return false;
-        ra -= nb;
-        rb -= nb;
-    }
     // beyond M1_PASSES digits only while both ranks still share their prefix (ties need the exact key)
     for (int p = 0; p < passes && (p < M1_PASSES || pa == pb); ++p) {
         done = p + 1;
@@ -159,17 +160,20 @@ __device__ bool m1_select2(const K *sk, int count, int stride, K kmin, K kmax, u
         const bool same = pa == pb;
         for (int i = tid; i < 2 * M1_BINS; i += M1_THREADS) (&hist[0][0])[i] = 0;
         __syncthreads();
-        for (int j = tid; j < count; j += M1_THREADS) {
-            const K u = sk[(size_t)j * stride] - kmin;
-            if (CLIP && u > width) continue;
+        for (int j = tid; j < S; j += M1_THREADS) {
+            const K u = sk[j] - kmin;
             const K top = p == 0 ? (K)0 : (K)(u >> (shift + 11));
             const uint32_t digit = (uint32_t)(u >> shift) & (M1_BINS - 1);
             if (top == pa) atomicAdd(&hist[0][digit], 1u);
             if (!same && top == pb) atomicAdd(&hist[1][digit], 1u);
         }
         __syncthreads();
-        m1_find_bin(hist[0], ra, wtot[0], &s_dig[0], &s_bef[0]);
-        m1_find_bin(hist[same ? 0 : 1], rb, wtot[1], &s_dig[1], &s_bef[1]);
+        if (same) {
+            m1_find_bin2(hist[0], ra, rb, wtot[0], s_dig, s_bef);
+        } else {
+            m1_find_bin(hist[0], ra, wtot[0], &s_dig[0], &s_bef[0]);
+            m1_find_bin(hist[1], rb, wtot[1], &s_dig[1], &s_bef[1]);
+        }
         pa = (pa << 11) | (K)s_dig[0];
         pb = (pb << 11) | (K)s_dig[1];
         ra -= s_bef[0];
@@ -180,29 +184,6 @@ __device__ bool m1_select2(const K *sk, int count, int stride, K kmin, K kmax, u
     *ka = kmin + (pa << rest);
     const K top_b = (pb << rest) | (rest ? (((K)1 << rest) - 1) : (K)0);
     *kb = top_b > width ? kmax : kmin + top_b;
-    return true;
-}
-
-// The bracket of sample ranks [want_lo, want_hi] among the S keys in LDS, in two steps: every
-// M1_COARSE-th key gives a coarse bracket (a few thousand ranks wide), then the full sample is
-// selected inside it.  False: a bracket missed (the caller leaves the block to the exact fallback).
-static constexpr int M1_COARSE = 16;
-template <typename K, int S>
-__device__ bool m1_bracket(const K *sk, K kmin, K kmax, int want_lo, int want_hi, uint32_t (*hist)[M1_BINS],
-                           uint32_t (*wtot)[M1_THREADS / 64], uint32_t *s_dig, uint32_t *s_bef, uint32_t *s_cnt,
-                           K *ka, K *kb) {
-    constexpr int SC = S / M1_COARSE;
-    const int dc = (int)(4.5 * sqrt((double)SC * 0.25)) + 3;
-    int c_lo = want_lo / M1_COARSE - dc, c_hi = want_hi / M1_COARSE + dc + 1;
-    K cl = kmin, ch = kmax;
-    if (c_lo >= 0 || c_hi < SC) {
-        K a, b;
-        const int qa = c_lo < 0 ? 0 : c_lo, qb = c_hi >= SC ? SC - 1 : c_hi;
-        m1_select2<K, false>(sk, SC, M1_COARSE, kmin, kmax, (uint32_t)qa, (uint32_t)qb, hist, wtot, s_dig, s_bef, s_cnt, &a, &b);
-        cl = c_lo < 0 ? kmin : a;
-        ch = c_hi >= SC ? kmax : b;
-    }
-    return m1_select2<K, true>(sk, S, 1, cl, ch, (uint32_t)want_lo, (uint32_t)want_hi, hist, wtot, s_dig, s_bef, s_cnt, ka, kb);
 }
 
 template <typename T>
@@ -214,7 +195,7 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_sample(const T *__restrict__ 
     K *sk = reinterpret_cast<K *>(smem);
     __shared__ uint32_t hist[2][M1_BINS];
     __shared__ uint32_t wtot[2][M1_THREADS / 64];
-    __shared__ uint32_t s_dig[2], s_bef[2], s_cnt[2];
+    __shared__ uint32_t s_dig[2], s_bef[2];
     __shared__ K s_kmin, s_kmax;
     const int64_t b = blockIdx.x;
     const int64_t n = g.frames[b];
@@ -281,10 +262,10 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_sample(const T *__restrict__ 
     want_lo = open_lo ? 0 : want_lo;
     want_hi = open_hi ? S - 1 : want_hi;
     K klo = 0, khi = 0;
-    const bool got_m = m1_bracket<K, S>(sk, s_kmin, s_kmax, want_lo, want_hi, hist, wtot, s_dig, s_bef, s_cnt, &klo, &khi);
+    m1_select2<K, S>(sk, s_kmin, s_kmax, (uint32_t)want_lo, (uint32_t)want_hi, hist, wtot, s_dig, s_bef, &klo, &khi);
     const T lo_v = val_of(klo), hi_v = val_of(khi);
     const bool finite = klo != ~(K)0 && khi != ~(K)0 && fabs(lo_v) <= (T)1e30 && fabs(hi_v) <= (T)1e30;
-    if (!got_m || !finite || open_lo || open_hi) {
+    if (!finite || open_lo || open_hi) {
         // non-finite data or a degenerate sample: the exact fallback takes the block
         if (tid == 0) {
             s.lo_m = 1;
@@ -328,18 +309,7 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_sample(const T *__restrict__ 
     }
     __syncthreads();
     K kalo = 0, kahi = 0;
-    const bool got_a = m1_bracket<K, S>(sk, s_kmin, s_kmax, want_lo, want_hi, hist, wtot, s_dig, s_bef, s_cnt, &kalo, &kahi);
-    if (!got_a) {
-        if (tid == 0) {
-            s.lo_m = 1;
-            s.hi_m = 0;
-            s.alo = 1.0;
-            s.ahi = 0.0;
-            s.usable = 0;
-            st[b] = s;
-        }
-        return;
-    }
+    m1_select2<K, S>(sk, s_kmin, s_kmax, (uint32_t)want_lo, (uint32_t)want_hi, hist, wtot, s_dig, s_bef, &kalo, &kahi);
     if (tid == 0) {
         const double eps_t = sizeof(T) == 4 ? 1.1920929e-7 : 2.220446049250313e-16;
         const bool open_above = kahi == ~(K)0 || !(fabs(val_of(kahi)) <= (T)1e30);
