@@ -706,6 +706,7 @@ struct BigState {            // per segment
     unsigned int n_cand;
     int overflow;                 // more candidates than the buffer holds
     int resolved;                 // both order statistics lie inside the bracket
+    int tie;                      // the bracket is ONE key and the counts prove that both order statistics equal it
 };
 
 __device__ __forceinline__ void big_ranks(int64_t n, int mode, double q, int64_t *r0, int64_t *r1, double *frac) {
@@ -926,7 +927,7 @@ __global__ void k_big_finish(const BigState *__restrict__ st, const int64_t *__r
         out[seg] = __longlong_as_double(0x7FF8000000000000ll);
         return;
     }
-    if (s.resolved) return;              // written by the selection over the gathered keys
+    if (s.resolved && !s.tie) return;    // written by the selection over the gathered keys
     int64_t r0, r1;
     double frac;
     big_ranks(n, mode, q, &r0, &r1, &frac);
@@ -1073,7 +1074,8 @@ __global__ __launch_bounds__(256) void k_big_gather(const T *__restrict__ vals, 
                                                     int64_t seg_stride, const int64_t *__restrict__ seg_len,
                                                     int64_t len_div, int64_t uniform_len,
                                                     const double *__restrict__ center, BigState *__restrict__ st,
-                                                    T *__restrict__ cand, int64_t cap, int64_t tiles_per_seg) {
+                                                    T *__restrict__ cand, int64_t cap, int64_t tiles_per_seg,
+                                                    int count_ties) {
     using K = typename KeyT<T>::type;
     constexpr int STAGE = 2048;                    // candidates staged per workgroup before one append
     __shared__ T stage[STAGE];
@@ -1086,6 +1088,8 @@ __global__ __launch_bounds__(256) void k_big_gather(const T *__restrict__ vals, 
     if (i0 >= n) return;
     const K lo = (K)st[seg].lo, hi = (K)st[seg].hi;
     if (lo > hi) return;
+    // a bracket of ONE key (constant or heavily tied segment): its keys are counted, not gathered
+    const bool tie = count_ties && lo == hi;
     const int tid = threadIdx.x, lane = tid & 63;
     if (tid == 0) {
         s_below = 0;
@@ -1161,6 +1165,7 @@ __global__ __launch_bounds__(256) void k_big_gather(const T *__restrict__ vals, 
         unsigned int base = 0;
         if (lane == 0) base = atomicAdd(&s_fill, total);
         base = __builtin_amdgcn_readfirstlane(base);
+        if (tie) continue;
         if (base + total <= STAGE) {
 #pragma unroll
             for (int u = 0; u < BATCH; ++u) {
@@ -1178,9 +1183,9 @@ __global__ __launch_bounds__(256) void k_big_gather(const T *__restrict__ vals, 
     if (saw_nan) s_nan = 1;
     if (spilled) st[seg].overflow = 1;
     __syncthreads();
-    const unsigned int cnt = s_fill < STAGE ? s_fill : STAGE;
+    const unsigned int cnt = tie ? 0u : (s_fill < STAGE ? s_fill : STAGE);
     if (tid == 0) {
-        s_base = cnt ? atomicAdd(&st[seg].n_cand, s_fill) : 0;     // s_fill (not cnt): overflow stays visible
+        s_base = s_fill ? atomicAdd(&st[seg].n_cand, s_fill) : 0;   // s_fill (not cnt): overflow stays visible
         if (s_below) atomicAdd(&st[seg].below, s_below);
         if (s_nan) st[seg].has_nan = 1;
     }
@@ -1200,14 +1205,26 @@ __global__ void k_big_check(BigState *st, const int64_t *seg_len, int64_t len_di
     if (seg >= n_seg) return;
     const int64_t n = seg_len ? seg_len[seg / len_div] : uniform_len;
     BigState s = st[seg];
-    int ok = 0;
-    if (n > 0 && s.lo <= s.hi && !s.overflow && (int64_t)s.n_cand <= cap && !s.has_nan) {
+    int ok = 0, tie = 0;
+    const bool one_key = rsrc.below == nullptr && s.lo == s.hi;     // first level only: counted, nothing gathered
+    if (n > 0 && s.lo <= s.hi && !s.has_nan && (one_key || (!s.overflow && (int64_t)s.n_cand <= cap))) {
         int64_t r0, r1;
         double frac;
         if (list_ranks(rsrc, seg, n, mode, q, &r0, &r1, &frac))
             ok = r0 >= 0 && (unsigned long long)r0 >= s.below && (unsigned long long)r1 < s.below + s.n_cand;
     }
-    st[seg].resolved = ok;
+    if (one_key) {
+        // both order statistics are that key (or the radix passes take the segment): no list to select from
+        tie = ok;
+        ok = 0;
+        if (tie) {
+            st[seg].k0 = s.lo;
+            st[seg].k1 = s.lo;
+            st[seg].need_extra = 0;
+            st[seg].tie = 1;
+        }
+    }
+    st[seg].resolved = ok || tie;
     valid[seg] = ok;
     cand_len[seg] = ok ? (int64_t)s.n_cand : 0;
     below[seg] = s.below + (rsrc.below ? rsrc.below[seg] : 0ull);   // keys of the ORIGINAL segment below this list
@@ -1226,7 +1243,7 @@ __global__ void k_big_init_level(BigState *st, int64_t n_seg) {
 // the radix passes (on the original segment) must run for everything the last level left open
 __global__ void k_big_resolve(BigState *st, const int *valid, int64_t n_seg) {
     const int64_t seg = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (seg < n_seg) st[seg].resolved = valid[seg];
+    if (seg < n_seg) st[seg].resolved = valid[seg] || st[seg].tie;
 }
 
 int64_t select_short_limit() { return BIG_THRESHOLD; }
@@ -1315,7 +1332,7 @@ static int launch_select_big(Ctx *c, const T *d_vals, const SelectArgs &a) {
         ADN_REQUIRE(a.n_seg * gtiles < (int64_t)0x7FFFFFFF, "select batch too large for one launch");
         hipLaunchKernelGGL((k_big_gather<T, XF>), dim3((unsigned)(a.n_seg * gtiles)), dim3(256), 0, c->stream, d_vals,
                            a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len, a.d_center, st, cand_l[0],
-                           caps[0], gtiles);
+                           caps[0], gtiles, 1);
         hipLaunchKernelGGL(k_big_check, dim3(nb), dim3(256), 0, c->stream, st, a.d_seg_len, a.len_div, a.uniform_len,
                            a.n_seg, a.mode, a.q, caps[0], none, len_l[0], valid_l[0], below_l[0], lohi_l[0]);
     }
@@ -1329,7 +1346,7 @@ static int launch_select_big(Ctx *c, const T *d_vals, const SelectArgs &a) {
                            (const double *)nullptr, st_l[l], a.mode, a.q, rs);
         hipLaunchKernelGGL((k_big_gather<T, XF_NONE>), dim3((unsigned)(a.n_seg * ltiles)), dim3(256), 0, c->stream,
                            cand_l[l - 1], (const int64_t *)nullptr, caps[l - 1], len_l[l - 1], (int64_t)1, (int64_t)0,
-                           (const double *)nullptr, st_l[l], cand_l[l], caps[l], ltiles);
+                           (const double *)nullptr, st_l[l], cand_l[l], caps[l], ltiles, 0);
         hipLaunchKernelGGL(k_big_check, dim3(nb), dim3(256), 0, c->stream, st_l[l], len_l[l - 1], (int64_t)1, (int64_t)0,
                            a.n_seg, a.mode, a.q, caps[l], rs, len_l[l], valid_l[l], below_l[l], lohi_l[l]);
     }

@@ -157,8 +157,9 @@ def test_error_reporting():
 
 
 def test_mad_long_segments_exact():
-    """Long segments take the sampled-bracket path and fall back to the radix passes when the
-    bracket cannot hold the statistics (constant data, heavy ties); results stay exact."""
+    """Long segments take the sampled-bracket path; a bracket of one key (constant data, heavy ties)
+    is resolved from the counts, and the radix passes take whatever a bracket cannot hold; results
+    stay exact."""
     e = engine()
     rng = np.random.default_rng(3)
     n = 200001
