@@ -610,43 +610,102 @@ __device__ __forceinline__ void m1_sweep(const T *in, int64_t n, T w0, T w1, boo
     }
 }
 
+// Visits the `cnt` keys of a list in memory: f(live, key), whole waves take every step.
+template <typename K, typename F>
+__device__ __forceinline__ void m1_list_sweep(const K *list, uint32_t cnt, F f) {
+    const uint32_t pad = (cnt + M1_THREADS - 1) / M1_THREADS * M1_THREADS;
+    for (uint32_t i = threadIdx.x; i < pad; i += M1_THREADS) f(i < cnt, i < cnt ? list[i] : (K)0);
+}
+
 // Keys of ranks r0 <= r1 <= r0 + 1 of the block (or of its absolute deviations from c).
+// The first sweep histograms the leading digit; when the keys of rank r0's bin fit `list`
+// (list_cap keys of scratch memory, normally a few percent of the block) a second sweep gathers
+// them and the remaining digits - and usually the neighbour key of rank r1 - are found on the list;
+// otherwise every digit is a sweep over the block.
 template <typename T>
 __device__ void m1_slow_pair(const T *in, int64_t n, T w0, T w1, bool absdev, T c, uint64_t r0, uint64_t r1,
                              uint32_t *hist, uint32_t *wtot, uint32_t *s_dig, uint32_t *s_bef, unsigned long long *s_min,
-                             int *nan_seen, typename KeyT<T>::type *k0, typename KeyT<T>::type *k1) {
+                             uint32_t *s_fill, int *nan_seen, typename KeyT<T>::type *list, int64_t list_cap,
+                             typename KeyT<T>::type *k0, typename KeyT<T>::type *k1) {
     using K = typename KeyT<T>::type;
     constexpr int BITS = KeyT<T>::bits, PASSES = (BITS + 10) / 11;
     const int tid = threadIdx.x;
     K prefix = 0;
-    uint32_t rank = (uint32_t)r0, in_bin = 0;
+    uint32_t rank = (uint32_t)r0, in_bin = 0, rank_top = 0, in_top = 0;
+    bool on_list = false;
+    uint32_t cnt = 0;
+    // digits of 11 bits from the top (the last one takes what is left: 10 bits of a 32-bit key), so that
+    // the leading bin is a quarter of an octave of values
+    int prev_shift = BITS;
     for (int p = 0; p < PASSES; ++p) {
-        const int shift = 11 * (PASSES - 1 - p);
+        const int shift = BITS - 11 * (p + 1) > 0 ? BITS - 11 * (p + 1) : 0;
+        const int width = prev_shift - shift;
+        const int up = prev_shift < BITS ? prev_shift : 0;      // keys match when (k >> up) == prefix (p > 0)
         for (int i = tid; i < M1_BINS; i += M1_THREADS) hist[i] = 0;
         __syncthreads();
-        m1_sweep<T>(in, n, w0, w1, absdev, c, [&](bool live, K k) {
-            if (live && k == ~(K)0) *nan_seen = 1;
-            const bool match = live && (p == 0 || (K)(k >> (shift + 11)) == prefix);
-            m1_hist_add(hist, (uint32_t)(k >> shift) & (M1_BINS - 1), match);
-        });
+        if (on_list) {
+            m1_list_sweep<K>(list, cnt, [&](bool live, K k) {
+                const bool match = live && (K)(k >> up) == prefix;
+                m1_hist_add(hist, (uint32_t)(k >> shift) & ((1u << width) - 1u), match);
+            });
+        } else {
+            m1_sweep<T>(in, n, w0, w1, absdev, c, [&](bool live, K k) {
+                if (live && k == ~(K)0) *nan_seen = 1;
+                const bool match = live && (p == 0 || (K)(k >> up) == prefix);
+                m1_hist_add(hist, (uint32_t)(k >> shift) & ((1u << width) - 1u), match);
+            });
+        }
         __syncthreads();
         m1_find_bin(hist, rank, wtot, s_dig, s_bef);
-        prefix = (prefix << 11) | (K)(*s_dig);
+        prefix = (prefix << width) | (K)(*s_dig);
+        prev_shift = shift;
         rank -= *s_bef;
         in_bin = hist[*s_dig];
         __syncthreads();
+        if (p == 0) {
+            rank_top = rank;
+            in_top = in_bin;
+            if (PASSES > 1 && (int64_t)in_bin <= list_cap) {
+                // gather the keys of the leading bin: the other digits are found among them
+                if (tid == 0) *s_fill = 0;
+                __syncthreads();
+                m1_sweep<T>(in, n, w0, w1, absdev, c, [&](bool live, K k) {
+                    const bool match = live && (K)(k >> shift) == prefix;
+                    const unsigned long long bal = __ballot(match);
+                    if (bal) {
+                        uint32_t base = 0;
+                        if ((tid & 63) == (int)__ffsll((long long)bal) - 1) base = atomicAdd(s_fill, (uint32_t)__popcll(bal));
+                        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__ffsll((long long)bal) - 1);
+                        if (match)
+                            list[base + __builtin_amdgcn_mbcnt_hi((unsigned int)(bal >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo((unsigned int)bal, 0u))] = k;
+                    }
+                });
+                __syncthreads();
+                cnt = *s_fill;
+                on_list = true;
+                __syncthreads();
+            }
+        }
     }
     *k0 = prefix;
     if (r1 == r0 || rank + 1 < in_bin) {        // enough keys tie with rank r0's
         *k1 = prefix;
         return;
     }
+    // rank r1 holds the smallest key above k0: on the list when the leading bin has a key beyond rank r0
     if (tid == 0) *s_min = ~0ull;
     __syncthreads();
     unsigned long long mn = ~0ull;
-    m1_sweep<T>(in, n, w0, w1, absdev, c, [&](bool live, K k) {
-        if (live && k > prefix && (unsigned long long)k < mn) mn = (unsigned long long)k;
-    });
+    if (on_list && rank_top + 1 < in_top) {
+        m1_list_sweep<K>(list, cnt, [&](bool live, K k) {
+            if (live && k > prefix && (unsigned long long)k < mn) mn = (unsigned long long)k;
+        });
+    } else {
+        m1_sweep<T>(in, n, w0, w1, absdev, c, [&](bool live, K k) {
+            if (live && k > prefix && (unsigned long long)k < mn) mn = (unsigned long long)k;
+        });
+    }
     for (int d = 32; d >= 1; d >>= 1) {
         const unsigned long long o = __shfl_xor(mn, d);
         mn = o < mn ? o : mn;
@@ -665,11 +724,11 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_fallback(const T *__restrict_
                                                             const M1State *__restrict__ st, const int *__restrict__ resolved,
                                                             const int *__restrict__ valid_a, const double *__restrict__ pair_a,
                                                             double *med, double *mad, double *thresh, double *sigma_out,
-                                                            double *thresh_out) {
+                                                            double *thresh_out, T *__restrict__ scratch, int64_t scratch_cap) {
     using K = typename KeyT<T>::type;
     __shared__ uint32_t hist[M1_BINS];
     __shared__ uint32_t wtot[M1_THREADS / 64];
-    __shared__ uint32_t s_dig, s_bef;
+    __shared__ uint32_t s_dig, s_bef, s_fill;
     __shared__ unsigned long long s_min;
     __shared__ int s_nan;
     const int64_t b = blockIdx.x;
@@ -699,7 +758,10 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_fallback(const T *__restrict_
     }
     const uint64_t r0 = (uint64_t)((n - 1) / 2), r1 = (uint64_t)(n / 2);
     K k0, k1;
-    m1_slow_pair<T>(in, n, w0, w1, false, (T)0, r0, r1, hist, wtot, &s_dig, &s_bef, &s_min, &s_nan, &k0, &k1);
+    // the block's own candidate list (useless now) is the scratch of the exact selection
+    K *list = reinterpret_cast<K *>(scratch + blockIdx.x * scratch_cap);
+    m1_slow_pair<T>(in, n, w0, w1, false, (T)0, r0, r1, hist, wtot, &s_dig, &s_bef, &s_min, &s_fill, &s_nan, list, scratch_cap,
+                    &k0, &k1);
     __syncthreads();
     if (s_nan) {
         if (threadIdx.x == 0) {
@@ -712,7 +774,8 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_fallback(const T *__restrict_
     const T a = val_of(k0), bb = val_of(k1);
     const T m = r0 == r1 ? a : (T)((a + bb) / (T)2);
     K q0, q1;
-    m1_slow_pair<T>(in, n, w0, w1, true, m, r0, r1, hist, wtot, &s_dig, &s_bef, &s_min, &s_nan, &q0, &q1);
+    m1_slow_pair<T>(in, n, w0, w1, true, m, r0, r1, hist, wtot, &s_dig, &s_bef, &s_min, &s_fill, &s_nan, list, scratch_cap,
+                    &q0, &q1);
     if (threadIdx.x == 0) {
         const T ta = val_of(q0), tb = val_of(q1);
         const double sg = s_nan ? nan : (double)(r0 == r1 ? ta : (T)((ta + tb) / (T)2));     // inf - inf
@@ -808,7 +871,7 @@ static int stereo_mad_single_pass(Ctx *c, const T *d_in, const BlockGeom &g, int
     sa.d_pair = pair_a;
     ADN_TRY(launch_select_subset<T>(c, cand_a, sa));
     hipLaunchKernelGGL((k_m1_fallback<T>), dim3((unsigned)g.n_blocks), dim3(M1_THREADS), 0, c->stream, d_in, g, w0, w1, st,
-                       resolved, valid_a, pair_a, med, mad, thresh, d_sigma_out, d_thresh_out);
+                       resolved, valid_a, pair_a, med, mad, thresh, d_sigma_out, d_thresh_out, cand_a, cap_a);
     ADN_HIP(hipGetLastError());
     *thresh_ws = thresh;
     return ADN_OK;
