@@ -22,8 +22,10 @@
 //      counted, and the counts alone prove the median (and, with the median pinned, the deviation).
 //   6. k_m1_fallback: blocks that fail any check (bracket missed, list or stage overflow, non-finite
 //      data, strongly autocorrelated coefficients for which a run of 16 frames is worth few samples)
-//      are selected exactly by one workgroup streaming the block (11-bit radix passes over the
-//      on-the-fly coefficients).  Resolved blocks cost it one early exit.
+//      are selected exactly by one workgroup streaming the block: one sweep histograms the leading
+//      11 bits of the on-the-fly keys, a second gathers the rank's bin into the block's (now useless)
+//      candidate list, the remaining digits are found there.  Resolved blocks cost it one early exit;
+//      the same kernel writes the thresholds.
 //
 // Every result is an exact order statistic of the same multiset the plain route selects from.
 #pragma once
