@@ -3,7 +3,7 @@
 
 One "step" = one pass of the core chain (phase 1 noise profile, phase 2 wavelet,
 phase 2b spectral subtraction, phase 2c Wiener) over one batch of synthetic
-clips per GPU: BASELINE config 2 (60 s, 48 kHz, stereo clip + 5 s noise sample,
+clips per GPU: BASELINE.json config 2 (60 s, 48 kHz, stereo clip + 5 s noise sample,
 n_fft 2048, hop 512), `--clips` independent clips per rank.  Inputs are generated
 on the device before the timed region; every stage reads its input from HBM and
 writes its output to HBM like the reference's stage files.
@@ -239,7 +239,7 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": "core_pipeline phases 1/2/2b/2c on 60 s 48 kHz stereo clips + 5 s noise "
-                                   "samples, STFT n_fft=2048 hop=512 (BASELINE config 2), %d clips per GPU per step"
+                                   "samples, STFT n_fft=2048 hop=512 (BASELINE.json config 2), %d clips per GPU per step"
                                    % args.clips,
                        "clips_per_gpu": args.clips, "sharding": "clips round-robin over ranks, no collective"},
             "roofline": {"bound": "hbm", "kernel": "adn::fast::k_apply_fast<8, SUBTRACT, false> (phase 2b, one launch per step)"

@@ -148,7 +148,7 @@ def gen_denoise_files(tmp):
         meta.append({"tag": tag, "sr": sr, "shape": list(x.shape), "out_shape": list(y.shape),
                      "x_checksum": synth.bits_checksum(x)})
 
-    # C1: 10 s 16 kHz mono, db4/per/L2/soft (BASELINE config 1)
+    # C1: 10 s 16 kHz mono, db4/per/L2/soft (BASELINE.json config 1)
     one("c1", synth.noisy_speech(160000, 16000, seed=42, stream=0), 16000)
     # 11 blocks: 10 x 2000 + one of 7 frames (odd -> 8 out)
     one("short11", synth.noisy_speech(20007, 8000, seed=42, stream=3), 8000)

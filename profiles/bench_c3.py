@@ -1,4 +1,4 @@
-"""Secondary benchmark: BASELINE config 3 - batch of N x 30 s 48 kHz mono clips,
+"""Secondary benchmark: BASELINE.json config 3 - batch of N x 30 s 48 kHz mono clips,
 db8 level 8 VisuShrink (10 blocks per clip), one MI355X.  Prints one JSON line."""
 import json, os, sys, time
 import numpy as np

@@ -1,4 +1,4 @@
-"""Secondary benchmark: BASELINE config 4 shape on ONE rank - a shard of N x 30 s 48 kHz mono files,
+"""Secondary benchmark: BASELINE.json config 4 shape on ONE rank - a shard of N x 30 s 48 kHz mono files,
 spectral subtraction + Wiener back to back with one shared noise profile (learnt once from a 5 s noise
 sample, as the owner rank would before broadcasting it).  Files are independent, so N ranks each
 run this on their own shard.  Prints one JSON line."""

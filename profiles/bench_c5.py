@@ -1,4 +1,4 @@
-"""BASELINE config 5 shape on ONE GPU: a 24 h / 96 kHz mono recording (8 294 400 000 samples, fp64,
+"""BASELINE.json config 5 shape on ONE GPU: a 24 h / 96 kHz mono recording (8 294 400 000 samples, fp64,
 66 GB) through the wavelet stage (10 % blocks of 829 440 000 samples, db4 level 2) in one C-ABI
 call: the signal, the output and the workspace fit the 288 GB of one MI355X, so no time chunking
 is needed for this stage.  Also cross-checks the fused tile kernels against the level-by-level

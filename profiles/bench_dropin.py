@@ -1,5 +1,5 @@
 """Wall time of the drop-in orchestrator (src/core_pipeline.py) on ONE 60 s, 48 kHz stereo clip +
-5 s noise sample (BASELINE config 2 as a user runs it: files in, files out), with one interpreter
+5 s noise sample (BASELINE.json config 2 as a user runs it: files in, files out), with one interpreter
 per stage like the reference (ADN_CHAIN=process) and with the stages chained in one process
 (default).  Prints one JSON line."""
 import json, os, subprocess, sys, tempfile, time

@@ -125,7 +125,7 @@ def test_wavedec_waverec_primitives(golden):
 
 
 def test_round_trip_property_large():
-    """Size-independent property at a BASELINE-sized block: with a zero threshold the
+    """Size-independent property at a benchmark-sized block: with a zero threshold the
     analysis/synthesis pair is the identity (perfect reconstruction)."""
     e = engine()
     x = e.synth_noisy_speech(144000 * 8, 48000, stream=5)
