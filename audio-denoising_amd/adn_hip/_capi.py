@@ -27,6 +27,7 @@ _PLAIN = {
     "adn_synchronize": (_i, [_vp]),
     "adn_set_option": (_i, [_vp, _i, _i]),
     "adn_workspace_bytes": (_i64, [_vp]),
+    "adn_kernel_times": (_i64, [_vp, C.c_char_p, _i64]),
     "adn_wavelet_out_frames": (_i64, [_i64]),
     "adn_denoise_block_frames": (_i64, [_i64, _i64]),
     "adn_stft_num_frames": (_i64, [_i64, _i, _i, _i]),

@@ -71,9 +71,26 @@ class Engine:
         self._check(self.lib.adn_set_option(self._h, 1, int(bool(on))))
 
     def force_exact_fallback(self, on=True):
-        """Test hook: the single-pass threshold statistics of stereo blocks send every block to
-        their exact per-block fallback selection."""
-        self._check(self.lib.adn_set_option(self._h, 1, 2 if on else 0))
+        """Test hook: the single-pass threshold statistics send every block to their exact
+        per-block fallback selection (independent of force_generic)."""
+        self._check(self.lib.adn_set_option(self._h, 3, int(bool(on))))
+
+    def kernel_timing(self, on=True):
+        """Record HIP events on the library's stream around every kernel launch."""
+        self._check(self.lib.adn_set_option(self._h, 4, int(bool(on))))
+
+    def kernel_times(self):
+        """{launch site: {"count": launches, "total_ms": summed duration}} since the last report
+        (synchronises the stream)."""
+        buf = C.create_string_buffer(1 << 16)
+        n = int(self.lib.adn_kernel_times(self._h, buf, len(buf)))
+        if n < 0:
+            raise AdnError(n, "adn_kernel_times failed")
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, count, total = line.rsplit("\t", 2)
+            out[name] = {"count": int(count), "total_ms": float(total)}
+        return out
 
     def synchronize(self):
         self._check(self.lib.adn_synchronize(self._h))

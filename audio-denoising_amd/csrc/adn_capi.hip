@@ -37,6 +37,14 @@ int ws_reserve(Ctx *c, size_t bytes) {
     return ADN_OK;
 }
 
+void drop_kernel_records(Ctx *c) {
+    for (KernelRec &r : c->krecs) {
+        (void)hipEventDestroy(r.start);
+        (void)hipEventDestroy(r.stop);
+    }
+    c->krecs.clear();
+}
+
 }  // namespace adn
 
 template <typename T>
@@ -94,6 +102,7 @@ int adn_destroy(adn_ctx *c) {
     if (!c) return ADN_OK;
     adn::DeviceGuard dg(c->device);
     (void)hipStreamSynchronize(c->stream);
+    adn::drop_kernel_records(c);
     if (c->ws) (void)hipFree(c->ws);
     for (int i = 0; i < c->n_tables; ++i)
         if (c->tables[i].dev) (void)hipFree(c->tables[i].dev);
@@ -109,13 +118,50 @@ int adn_set_stream(adn_ctx *c, void *s) {
 
 int adn_set_option(adn_ctx *c, int option, int value) {
     ADN_REQUIRE(c != nullptr, "ctx is null");
-    ADN_REQUIRE(option == ADN_OPT_FORCE_GENERIC || option == ADN_OPT_ABLATE, "unknown option %d", option);
-    if (option == ADN_OPT_FORCE_GENERIC) {
-        c->force_generic = value == 1;
-        c->force_fallback = value == 2;
-    }
+    ADN_REQUIRE(option >= ADN_OPT_FORCE_GENERIC && option <= ADN_OPT_KERNEL_TIMING, "unknown option %d", option);
+    if (option == ADN_OPT_FORCE_GENERIC) c->force_generic = value != 0;
+    if (option == ADN_OPT_FORCE_FALLBACK) c->force_fallback = value != 0;
     if (option == ADN_OPT_ABLATE) c->ablate = value;
+    if (option == ADN_OPT_KERNEL_TIMING) {
+        adn::DeviceGuard dg(c->device);
+        if (!value) adn::drop_kernel_records(c);
+        c->ktime = value != 0;
+    }
     return ADN_OK;
+}
+
+int64_t adn_kernel_times(adn_ctx *c, char *buf, int64_t cap) {
+    if (!c || !buf || cap < 1) return -1;
+    adn::DeviceGuard dg(c->device);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    // aggregate by launch-site name, in order of first appearance
+    std::vector<const char *> names;
+    std::vector<double> total;
+    std::vector<long long> count;
+    for (const adn::KernelRec &r : c->krecs) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) continue;
+        size_t i = 0;
+        for (; i < names.size(); ++i)
+            if (strcmp(names[i], r.name) == 0) break;
+        if (i == names.size()) {
+            names.push_back(r.name);
+            total.push_back(0.0);
+            count.push_back(0);
+        }
+        total[i] += ms;
+        count[i] += 1;
+    }
+    adn::drop_kernel_records(c);
+    std::string out;
+    char line[384];
+    for (size_t i = 0; i < names.size(); ++i) {
+        snprintf(line, sizeof(line), "%s\t%lld\t%.6f\n", names[i], count[i], total[i]);
+        out += line;
+    }
+    if ((int64_t)out.size() + 1 > cap) return -(int64_t)(out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return (int64_t)out.size();
 }
 
 int adn_synchronize(adn_ctx *c) {

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <string>
+#include <vector>
 
 #include "../../include/adn.h"
 
@@ -45,6 +46,11 @@ struct StftTable {      // window / twiddle tables of one (n_fft, precision) pai
     double wsum = 0.0;  // sum of the window
 };
 
+struct KernelRec {      // one timed launch: events recorded on the context's stream
+    const char *name;
+    hipEvent_t start, stop;
+};
+
 struct Ctx {
     StftTable tables[16];
     int n_tables = 0;
@@ -57,7 +63,37 @@ struct Ctx {
     bool force_generic = false;   // test hook: skip the specialised kernels
     bool force_fallback = false;  // test hook: the single-pass threshold statistics send every block to their exact fallback
     int ablate = 0;               // diagnostics: stages the fused STFT kernel skips (timing only)
+    bool ktime = false;           // ADN_OPT_KERNEL_TIMING: event pairs around the launches
+    std::vector<KernelRec> krecs; // launches timed since the option was set / the last report
 };
+
+void drop_kernel_records(Ctx *c);
+
+// Event pair around one launch when kernel timing is on (costs nothing otherwise).
+struct KScope {
+    Ctx *c;
+    int idx = -1;
+    KScope(Ctx *ctx, const char *name) : c(ctx) {
+        if (!c->ktime) return;
+        KernelRec r{name, nullptr, nullptr};
+        if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+        (void)hipEventRecord(r.start, c->stream);
+        c->krecs.push_back(r);
+        idx = (int)c->krecs.size() - 1;
+    }
+    ~KScope() {
+        if (idx >= 0) (void)hipEventRecord(c->krecs[idx].stop, c->stream);
+    }
+};
+
+// Every kernel launch of the library goes through this macro (`c` is the context in scope).
+#define ADN_LAUNCH_NAMED(name, kern, grid, block, lds, stream, ...)            \
+    do {                                                                       \
+        adn::KScope ks_(c, name);                                              \
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);       \
+    } while (0)
+#define ADN_LAUNCH(kern, grid, block, lds, stream, ...) \
+    ADN_LAUNCH_NAMED(#kern, kern, grid, block, lds, stream, __VA_ARGS__)
 
 // Ensure the workspace holds at least `bytes`; growing synchronises the stream
 // (the old buffer may still be in use) and reallocates.

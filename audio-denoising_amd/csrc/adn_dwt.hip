@@ -502,7 +502,7 @@ static int mad_threshold(Ctx *c, const T *D, const BlockGeom &g, int F, int ext,
     double *sigma = ws_take<double>(c, g.n_blocks);
     double *thresh = ws_take<double>(c, g.n_blocks);
     const unsigned nb = (unsigned)ceil_div(g.n_blocks, 256);
-    hipLaunchKernelGGL(k_cd1_segments, dim3(nb), dim3(256), 0, c->stream, g, F, ext, per_frame,
+    ADN_LAUNCH(k_cd1_segments, dim3(nb), dim3(256), 0, c->stream, g, F, ext, per_frame,
                        seg_off, seg_len);
     SelectArgs a;
     a.n_seg = g.n_blocks;
@@ -516,7 +516,7 @@ static int mad_threshold(Ctx *c, const T *D, const BlockGeom &g, int F, int ext,
     a.d_center = med;
     a.d_out = sigma;
     ADN_TRY(launch_select<T>(c, D, a));
-    hipLaunchKernelGGL(k_universal_threshold, dim3(nb), dim3(256), 0, c->stream, g.frames,
+    ADN_LAUNCH(k_universal_threshold, dim3(nb), dim3(256), 0, c->stream, g.frames,
                        g.n_blocks, sigma, thresh, d_sigma_out, d_thresh_out);
     ADN_HIP(hipGetLastError());
     *thresh_ws = thresh;
@@ -549,16 +549,16 @@ static int channel_denoise(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t
         ADN_TRY(ws_reserve(c, ws_need((size_t)g.n_blocks * g.d_stride, sizeof(T)) +
                               mad_ws_bytes(g.n_blocks, max_frames * m.n_d1)));
         T *D = ws_take<T>(c, (size_t)g.n_blocks * g.d_stride);
-        if (three) hipLaunchKernelGGL((k_ch_stats<T, NCH, 3>), grid, block, 0, c->stream, d_in, D, g, m, tiles);
-        else hipLaunchKernelGGL((k_ch_stats<T, NCH, 0>), grid, block, 0, c->stream, d_in, D, g, m, tiles);
+        if (three) ADN_LAUNCH((k_ch_stats<T, NCH, 3>), grid, block, 0, c->stream, d_in, D, g, m, tiles);
+        else ADN_LAUNCH((k_ch_stats<T, NCH, 0>), grid, block, 0, c->stream, d_in, D, g, m, tiles);
         ADN_TRY(mad_threshold<T>(c, D, g, 8, ADN_EXT_PERIODIZATION, m.n_d1, max_frames * m.n_d1,
                                  d_sigma, d_thresh, &thresh));
     }
     if (three)
-        hipLaunchKernelGGL((k_ch_apply<T, NCH, 3>), grid, block, 0, c->stream, d_in, d_out, g, m, tiles, thresh,
+        ADN_LAUNCH((k_ch_apply<T, NCH, 3>), grid, block, 0, c->stream, d_in, d_out, g, m, tiles, thresh,
                            thr_mode, d_zeroed);
     else
-        hipLaunchKernelGGL((k_ch_apply<T, NCH, 0>), grid, block, 0, c->stream, d_in, d_out, g, m, tiles, thresh,
+        ADN_LAUNCH((k_ch_apply<T, NCH, 0>), grid, block, 0, c->stream, d_in, d_out, g, m, tiles, thresh,
                            thr_mode, d_zeroed);
     ADN_HIP(hipGetLastError());
     return ADN_OK;
@@ -578,14 +578,14 @@ static int general_denoise(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t
     T *A0 = ws_take<T>(c, nA), *A1 = ws_take<T>(c, nA), *D = ws_take<T>(c, nD);
     for (int l = 1; l <= level; ++l) {
         const int64_t tiles = ceil_div(band_len(max_frames, l, F, ext), 256);
-        hipLaunchKernelGGL((k_fwd_level<T>), dim3((unsigned)(tiles * g.n_blocks)), dim3(256), 0,
+        ADN_LAUNCH((k_fwd_level<T>), dim3((unsigned)(tiles * g.n_blocks)), dim3(256), 0,
                            c->stream, d_in, A0, A1, D, g, l, ext, tp, tiles);
     }
     double *thresh = nullptr;
     ADN_TRY(mad_threshold<T>(c, D, g, F, ext, 0, (max_frames + 1) / 2, d_sigma, d_thresh, &thresh));
     for (int l = level; l >= 1; --l) {
         const int64_t tiles = ceil_div(2 * band_len(max_frames, l, F, ext), 256);
-        hipLaunchKernelGGL((k_inv_level<T>), dim3((unsigned)(tiles * g.n_blocks)), dim3(256), 0,
+        ADN_LAUNCH((k_inv_level<T>), dim3((unsigned)(tiles * g.n_blocks)), dim3(256), 0,
                            c->stream, d_out, A0, A1, D, g, l, ext, tp, tiles, thresh, thr_mode,
                            d_zeroed);
     }
@@ -662,7 +662,7 @@ int wavedec(Ctx *c, const T *d_x, int64_t n, int wavelet, int level, int ext_mod
     BlockGeom g{desc, desc + 1, desc + 2, 1, a_stride, d_stride};
     for (int l = 1; l <= level; ++l) {
         const int64_t tiles = ceil_div(band_len(n, l, F, ext_mode), 256);
-        hipLaunchKernelGGL((k_fwd_level<T>), dim3((unsigned)tiles), dim3(256), 0, c->stream, d_x,
+        ADN_LAUNCH((k_fwd_level<T>), dim3((unsigned)tiles), dim3(256), 0, c->stream, d_x,
                            A0, A1, D, g, l, ext_mode, tp, tiles);
     }
     // output order [cA_L, cD_L, ..., cD_1]
@@ -721,7 +721,7 @@ int waverec(Ctx *c, const T *d_coeffs, const int64_t *h_band_len, int wavelet, i
         T *dst = i == level ? d_y : nxt;
         if (i == level) ADN_REQUIRE(n_out <= cap, "output buffer too small: need %lld", (long long)n_out);
         // level index 1 => a from A1 (l & 1), out to y; pass cur as A1 and detail pointer offset 0
-        hipLaunchKernelGGL((k_inv_level<T>), dim3((unsigned)tiles), dim3(256), 0, c->stream, dst,
+        ADN_LAUNCH((k_inv_level<T>), dim3((unsigned)tiles), dim3(256), 0, c->stream, dst,
                            (T *)nullptr, cur, d_coeffs + pos, g, 1, ext_mode, tp, tiles,
                            (const double *)nullptr, 0, (int64_t *)nullptr);
         ADN_HIP(hipGetLastError());

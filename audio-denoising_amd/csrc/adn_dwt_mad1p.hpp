@@ -839,16 +839,16 @@ static int stereo_mad_single_pass(Ctx *c, const T *d_in, const BlockGeom &g, int
         auto kern = k_m1_sample<T>;
         const size_t dyn = (size_t)M1<T>::S * sizeof(typename KeyT<T>::type);
         ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        hipLaunchKernelGGL(kern, dim3((unsigned)g.n_blocks), dim3(M1_THREADS), dyn, c->stream, d_in, g, w0, w1, st);
+        ADN_LAUNCH_NAMED("k_m1_sample", kern, dim3((unsigned)g.n_blocks), dim3(M1_THREADS), dyn, c->stream, d_in, g, w0, w1, st);
     }
     const int64_t tiles = max_frames / M1_TILE;            // whole tiles of the longest block
     ADN_REQUIRE(g.n_blocks * (tiles + 1) < (int64_t)0x7FFFFFFF, "wavelet batch too large for one launch");
     if (tiles > 0)
-        hipLaunchKernelGGL((k_m1_gather<T, true>), dim3((unsigned)(g.n_blocks * tiles)), dim3(256), 0, c->stream, d_in, g,
+        ADN_LAUNCH((k_m1_gather<T, true>), dim3((unsigned)(g.n_blocks * tiles)), dim3(256), 0, c->stream, d_in, g,
                            w0, w1, st, cand_m, cap_m, cand_a, cap_a, tiles);
-    hipLaunchKernelGGL((k_m1_gather<T, false>), dim3((unsigned)g.n_blocks), dim3(256), 0, c->stream, d_in, g, w0, w1, st,
+    ADN_LAUNCH((k_m1_gather<T, false>), dim3((unsigned)g.n_blocks), dim3(256), 0, c->stream, d_in, g, w0, w1, st,
                        cand_m, cap_m, cand_a, cap_a, (int64_t)1);
-    hipLaunchKernelGGL(k_m1_check, dim3(nbk), dim3(256), 0, c->stream, st, g.frames, g.n_blocks, cap_m, cap_a, len_m, len_a,
+    ADN_LAUNCH(k_m1_check, dim3(nbk), dim3(256), 0, c->stream, st, g.frames, g.n_blocks, cap_m, cap_a, len_m, len_a,
                        below_m, below_a, valid_m, valid_a, resolved, med, mad, c->force_fallback ? 1 : 0);
     ADN_HIP(hipGetLastError());
     SubsetSelect sm;
@@ -872,7 +872,7 @@ static int stereo_mad_single_pass(Ctx *c, const T *d_in, const BlockGeom &g, int
     sa.d_out = mad;
     sa.d_pair = pair_a;
     ADN_TRY(launch_select_subset<T>(c, cand_a, sa));
-    hipLaunchKernelGGL((k_m1_fallback<T>), dim3((unsigned)g.n_blocks), dim3(M1_THREADS), 0, c->stream, d_in, g, w0, w1, st,
+    ADN_LAUNCH((k_m1_fallback<T>), dim3((unsigned)g.n_blocks), dim3(M1_THREADS), 0, c->stream, d_in, g, w0, w1, st,
                        resolved, valid_a, pair_a, med, mad, thresh, d_sigma_out, d_thresh_out, cand_a, cap_a);
     ADN_HIP(hipGetLastError());
     *thresh_ws = thresh;

@@ -507,7 +507,7 @@ static void launch_tile(Ctx *c, const T *x, T *y, const BlockGeom &g, int64_t ma
     constexpr int S = TileS<T>::S;
     const int tiles = (int)ceil_div(max_frames + 1, S);
     const TapsF<T, F> tp = make_taps_f<T, F>(wavelet);
-    hipLaunchKernelGGL((k_tile<T, F, TL, S, MODE>), dim3((unsigned)(tiles * g.n_blocks)), dim3(THREADS),
+    ADN_LAUNCH((k_tile<T, F, TL, S, MODE>), dim3((unsigned)(tiles * g.n_blocks)), dim3(THREADS),
                        0, c->stream, x, y, g, tiles, tp, thresh, thr_mode, zeroed, d1, d1_stride, top,
                        top_stride, use_top, c->ablate);
 }
@@ -572,7 +572,7 @@ static int denoise_f(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_f
         if (deep_lds > 48 * 1024)
             ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_deep<T, F>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)deep_lds));
-        hipLaunchKernelGGL((k_deep<T, F>), dim3((unsigned)g.n_blocks), dim3(512), deep_lds, c->stream, top,
+        ADN_LAUNCH((k_deep<T, F>), dim3((unsigned)g.n_blocks), dim3(512), deep_lds, c->stream, top,
                            top_stride, g, TL, level, tp, thresh, thr_mode, d_zeroed);
     }
     launch_tile_tl<T, F, MODE_APPLY>(c, TL, d_in, d_out, g, max_frames, wavelet, thresh, thr_mode, d_zeroed,

@@ -413,16 +413,16 @@ int hpss_separate(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, con
     ADN_HIP(hipMemsetAsync(ymax, 0, sizeof(unsigned long long) * n_sig, c->stream));
     ADN_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 3 * n_sig, c->stream));
     Signals sg{d_off, d_len, n_ch, n_fft, hop, 1};
-    hipLaunchKernelGGL(k_frame_counts, dim3((unsigned)ceil_div(n_sig, 256)), dim3(256), 0, c->stream, sg, n_sig, Tn);
+    ADN_LAUNCH(k_frame_counts, dim3((unsigned)ceil_div(n_sig, 256)), dim3(256), 0, c->stream, sg, n_sig, Tn);
     ADN_TRY(rows_dispatch<T>(c, d_x, sg, tb, n_sig, Ts, 0, S, nullptr));
     hpss::BandTable bt{d_blo, d_bhi};
     {
         const dim3 grid((unsigned)ceil_div(Tmax, hpss::TT), (unsigned)ceil_div(F, hpss::TB), (unsigned)n_sig);
         if (kernel_size == 31)
-            hipLaunchKernelGGL((hpss::k_hpss_masks<T, 31>), grid, dim3(256), 0, c->stream, S, F, Ts, Tmax, Tn, bt,
+            ADN_LAUNCH((hpss::k_hpss_masks<T, 31>), grid, dim3(256), 0, c->stream, S, F, Ts, Tmax, Tn, bt,
                                kernel_size, (T)margin_h, (T)margin_p, (T)power, mask_type, Mh, Mp);
         else
-            hipLaunchKernelGGL((hpss::k_hpss_masks<T, 0>), grid, dim3(256), 0, c->stream, S, F, Ts, Tmax, Tn, bt,
+            ADN_LAUNCH((hpss::k_hpss_masks<T, 0>), grid, dim3(256), 0, c->stream, S, F, Ts, Tmax, Tn, bt,
                                kernel_size, (T)margin_h, (T)margin_p, (T)power, mask_type, Mh, Mp);
     }
     ADN_HIP(hipGetLastError());
@@ -443,16 +443,16 @@ int hpss_separate(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, con
     a.row = Mp;
     ADN_TRY((apply_dispatch<T, APPLY_GAIN>(c, a, n_sig, Tmax)));
     const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(max_len, 256 * 8), std::max<int64_t>(8, 4096 / n_sig));
-    hipLaunchKernelGGL((hpss::k_hpss_energy<T>), dim3((unsigned)ceil_div(max_frames, 4), (unsigned)n_sig), dim3(256), 0,
+    ADN_LAUNCH((hpss::k_hpss_energy<T>), dim3((unsigned)ceil_div(max_frames, 4), (unsigned)n_sig), dim3(256), 0,
                        c->stream, d_x, sg, d_yh, d_y_off, max_frames, eo, eh);
-    hipLaunchKernelGGL(hpss::k_hpss_emax, dim3((unsigned)n_sig), dim3(256), 0, c->stream, sg, max_frames, eo, eh, threshold,
+    ADN_LAUNCH(hpss::k_hpss_emax, dim3((unsigned)n_sig), dim3(256), 0, c->stream, sg, max_frames, eo, eh, threshold,
                        preserve_transients, eo_max, n_tr, cov);
-    hipLaunchKernelGGL((hpss::k_hpss_blend<T>), dim3(gx, (unsigned)n_sig), dim3(256), 0, c->stream, d_x, sg, d_yh, d_yp,
+    ADN_LAUNCH((hpss::k_hpss_blend<T>), dim3(gx, (unsigned)n_sig), dim3(256), 0, c->stream, d_x, sg, d_yh, d_yp,
                        d_y_off, max_frames, cov, blend, ymax);
-    hipLaunchKernelGGL((hpss::k_hpss_scale<T>), dim3(gx, (unsigned)n_sig), dim3(256), 0, c->stream, d_x, sg, d_yh, d_yp,
+    ADN_LAUNCH((hpss::k_hpss_scale<T>), dim3(gx, (unsigned)n_sig), dim3(256), 0, c->stream, d_x, sg, d_yh, d_yp,
                        d_y_off, ymax, sums);
     double *stats = d_stats ? d_stats : stats_ws;
-    hipLaunchKernelGGL(hpss::k_hpss_stats, dim3((unsigned)ceil_div(n_sig, 256)), dim3(256), 0, c->stream, sg, n_sig, sums,
+    ADN_LAUNCH(hpss::k_hpss_stats, dim3((unsigned)ceil_div(n_sig, 256)), dim3(256), 0, c->stream, sg, n_sig, sums,
                        ymax, n_tr, stats);
     ADN_HIP(hipGetLastError());
     return ADN_OK;

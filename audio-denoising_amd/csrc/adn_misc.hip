@@ -32,7 +32,7 @@ int window_rms(Ctx *c, const T *d_x, int64_t n_rows, int n_ch, int64_t win, doub
     ADN_REQUIRE(n_rows >= 1 && n_ch >= 1 && win >= 1, "n_rows, n_ch and win must be >= 1");
     DeviceGuard dg(c->device);
     const int64_t n_win = ceil_div(n_rows, win);
-    hipLaunchKernelGGL((k_window_rms<T>), dim3((unsigned)ceil_div(n_win, 4)), dim3(256), 0,
+    ADN_LAUNCH((k_window_rms<T>), dim3((unsigned)ceil_div(n_win, 4)), dim3(256), 0,
                        c->stream, d_x, n_rows, n_ch, win, n_win, d_rms);
     ADN_HIP(hipGetLastError());
     return ADN_OK;
@@ -85,10 +85,10 @@ int pcm_encode(Ctx *c, const T *d_x, int64_t n, int bits, void *d_q, T *d_xq) {
     constexpr int V = 16 / (int)sizeof(T);
     const unsigned nb = (unsigned)ceil_div(n, (int64_t)256 * V);
     if (bits == 16)
-        hipLaunchKernelGGL((k_pcm_encode<T, int16_t>), dim3(nb), dim3(256), 0, c->stream, d_x, n, bits,
+        ADN_LAUNCH((k_pcm_encode<T, int16_t>), dim3(nb), dim3(256), 0, c->stream, d_x, n, bits,
                            static_cast<int16_t *>(d_q), d_xq);
     else
-        hipLaunchKernelGGL((k_pcm_encode<T, int32_t>), dim3(nb), dim3(256), 0, c->stream, d_x, n, bits,
+        ADN_LAUNCH((k_pcm_encode<T, int32_t>), dim3(nb), dim3(256), 0, c->stream, d_x, n, bits,
                            static_cast<int32_t *>(d_q), d_xq);
     ADN_HIP(hipGetLastError());
     return ADN_OK;
@@ -146,7 +146,7 @@ int synth_noisy_speech(Ctx *c, T *d_x, int64_t n, int64_t start, int sample_rate
     if (n == 0) return ADN_OK;
     DeviceGuard dg(c->device);
     const uint64_t base = seed * 0x9E3779B97F4A7C15ull + stream * 0xD1B54A32D192ED03ull;
-    hipLaunchKernelGGL((k_synth<T>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, c->stream, d_x,
+    ADN_LAUNCH((k_synth<T>), dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, c->stream, d_x,
                        n, start, (double)sample_rate, base, sigma, speech_gain);
     ADN_HIP(hipGetLastError());
     return ADN_OK;

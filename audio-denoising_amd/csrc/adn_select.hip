@@ -1320,38 +1320,38 @@ static int launch_select_big(Ctx *c, const T *d_vals, const SelectArgs &a) {
     ADN_REQUIRE(a.n_seg * tiles < (int64_t)0x7FFFFFFF, "select batch too large for one launch");
     const unsigned nb = (unsigned)ceil_div(a.n_seg, 256);
     ADN_HIP(hipMemsetAsync(ghist, 0, sizeof(uint32_t) * a.n_seg * BIG_BINS, c->stream));
-    hipLaunchKernelGGL(k_big_init, dim3(nb), dim3(256), 0, c->stream, st, a.d_seg_len, a.len_div, a.uniform_len,
+    ADN_LAUNCH(k_big_init, dim3(nb), dim3(256), 0, c->stream, st, a.d_seg_len, a.len_div, a.uniform_len,
                        a.n_seg, a.mode, a.q);
     // ---- bracket fast path: sample, count + gather (repeated on the gathered keys while they do
     // not fit LDS), then the exact selection over the last list
     {
         const RankSrc none{nullptr, 1, 0, nullptr, nullptr};
-        hipLaunchKernelGGL((k_big_sample<T, XF>), dim3((unsigned)a.n_seg), dim3(SAMPLE_THREADS), 0, c->stream, d_vals, a.d_seg_off,
+        ADN_LAUNCH((k_big_sample<T, XF>), dim3((unsigned)a.n_seg), dim3(SAMPLE_THREADS), 0, c->stream, d_vals, a.d_seg_off,
                            a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len, a.d_center, st, a.mode, a.q, none);
         const int64_t gtiles = ceil_div(a.max_len, GATHER_TILE);
         ADN_REQUIRE(a.n_seg * gtiles < (int64_t)0x7FFFFFFF, "select batch too large for one launch");
-        hipLaunchKernelGGL((k_big_gather<T, XF>), dim3((unsigned)(a.n_seg * gtiles)), dim3(256), 0, c->stream, d_vals,
+        ADN_LAUNCH((k_big_gather<T, XF>), dim3((unsigned)(a.n_seg * gtiles)), dim3(256), 0, c->stream, d_vals,
                            a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len, a.d_center, st, cand_l[0],
                            caps[0], gtiles, 1);
-        hipLaunchKernelGGL(k_big_check, dim3(nb), dim3(256), 0, c->stream, st, a.d_seg_len, a.len_div, a.uniform_len,
+        ADN_LAUNCH(k_big_check, dim3(nb), dim3(256), 0, c->stream, st, a.d_seg_len, a.len_div, a.uniform_len,
                            a.n_seg, a.mode, a.q, caps[0], none, len_l[0], valid_l[0], below_l[0], lohi_l[0]);
     }
     for (int l = 1; l < n_levels; ++l) {
         const RankSrc rs{a.d_seg_len, a.len_div, a.uniform_len, below_l[l - 1], valid_l[l - 1]};
         const int64_t ltiles = ceil_div(caps[l - 1], GATHER_TILE);
         ADN_REQUIRE(a.n_seg * ltiles < (int64_t)0x7FFFFFFF, "select batch too large for one launch");
-        hipLaunchKernelGGL(k_big_init_level, dim3(nb), dim3(256), 0, c->stream, st_l[l], a.n_seg);
-        hipLaunchKernelGGL((k_big_sample<T, XF_NONE>), dim3((unsigned)a.n_seg), dim3(SAMPLE_THREADS), 0, c->stream, cand_l[l - 1],
+        ADN_LAUNCH(k_big_init_level, dim3(nb), dim3(256), 0, c->stream, st_l[l], a.n_seg);
+        ADN_LAUNCH((k_big_sample<T, XF_NONE>), dim3((unsigned)a.n_seg), dim3(SAMPLE_THREADS), 0, c->stream, cand_l[l - 1],
                            (const int64_t *)nullptr, caps[l - 1], len_l[l - 1], (int64_t)1, (int64_t)0,
                            (const double *)nullptr, st_l[l], a.mode, a.q, rs);
-        hipLaunchKernelGGL((k_big_gather<T, XF_NONE>), dim3((unsigned)(a.n_seg * ltiles)), dim3(256), 0, c->stream,
+        ADN_LAUNCH((k_big_gather<T, XF_NONE>), dim3((unsigned)(a.n_seg * ltiles)), dim3(256), 0, c->stream,
                            cand_l[l - 1], (const int64_t *)nullptr, caps[l - 1], len_l[l - 1], (int64_t)1, (int64_t)0,
                            (const double *)nullptr, st_l[l], cand_l[l], caps[l], ltiles, 0);
-        hipLaunchKernelGGL(k_big_check, dim3(nb), dim3(256), 0, c->stream, st_l[l], len_l[l - 1], (int64_t)1, (int64_t)0,
+        ADN_LAUNCH(k_big_check, dim3(nb), dim3(256), 0, c->stream, st_l[l], len_l[l - 1], (int64_t)1, (int64_t)0,
                            a.n_seg, a.mode, a.q, caps[l], rs, len_l[l], valid_l[l], below_l[l], lohi_l[l]);
     }
     const int L = n_levels - 1;
-    if (L > 0) hipLaunchKernelGGL(k_big_resolve, dim3(nb), dim3(256), 0, c->stream, st, valid_l[L], a.n_seg);
+    if (L > 0) ADN_LAUNCH(k_big_resolve, dim3(nb), dim3(256), 0, c->stream, st, valid_l[L], a.n_seg);
     {
         const int64_t cap = caps[L];
         T *cand = cand_l[L];
@@ -1361,7 +1361,7 @@ static int launch_select_big(Ctx *c, const T *d_vals, const SelectArgs &a) {
             const size_t dyn = (size_t)cap * sizeof(K);
             auto kern = k_select_lds<T, XF_NONE, false>;
             ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-            hipLaunchKernelGGL(kern, dim3((unsigned)a.n_seg), dim3(SEL_THREADS), dyn, c->stream, cand,
+            ADN_LAUNCH_NAMED("k_select_lds<T, XF_NONE, false>", kern, dim3((unsigned)a.n_seg), dim3(SEL_THREADS), dyn, c->stream, cand,
                                (const int64_t *)nullptr, cap, len_l[L], (int64_t)1, (int64_t)0, a.mode, a.q,
                                (const double *)nullptr, a.d_out, mm, sub);
         } else {
@@ -1369,7 +1369,7 @@ static int launch_select_big(Ctx *c, const T *d_vals, const SelectArgs &a) {
             const size_t dyn = 2 * (size_t)lds_keys * sizeof(K);
             auto kern = k_select<T, XF_NONE>;
             ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-            hipLaunchKernelGGL(kern, dim3((unsigned)a.n_seg), dim3(SEL_THREADS), dyn, c->stream, cand,
+            ADN_LAUNCH_NAMED("k_select<T, XF_NONE>", kern, dim3((unsigned)a.n_seg), dim3(SEL_THREADS), dyn, c->stream, cand,
                                (const int64_t *)nullptr, cap, len_l[L], (int64_t)1, (int64_t)0, a.mode, a.q,
                                (const double *)nullptr, a.d_out, lds_keys, mm, sub);
         }
@@ -1382,16 +1382,16 @@ static int launch_select_big(Ctx *c, const T *d_vals, const SelectArgs &a) {
         const int passes_left = (remaining + 10) / 11;
         const int width = (remaining + passes_left - 1) / passes_left;
         remaining -= width;
-        hipLaunchKernelGGL((k_big_hist<T, XF>), dim3((unsigned)(a.n_seg * tiles)), dim3(256), 0, c->stream, d_vals,
+        ADN_LAUNCH((k_big_hist<T, XF>), dim3((unsigned)(a.n_seg * tiles)), dim3(256), 0, c->stream, d_vals,
                            a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len, a.d_center, st, ghist,
                            tiles, remaining, width, first ? 1 : 0);
-        hipLaunchKernelGGL((k_big_scan<T>), dim3((unsigned)a.n_seg), dim3(256), 0, c->stream, st, ghist,
+        ADN_LAUNCH((k_big_scan<T>), dim3((unsigned)a.n_seg), dim3(256), 0, c->stream, st, ghist,
                            a.d_seg_len, a.len_div, a.uniform_len, width, remaining == 0 ? 1 : 0, a.mode, a.q);
         first = false;
     }
-    hipLaunchKernelGGL((k_big_next<T, XF>), dim3((unsigned)(a.n_seg * tiles)), dim3(256), 0, c->stream, d_vals,
+    ADN_LAUNCH((k_big_next<T, XF>), dim3((unsigned)(a.n_seg * tiles)), dim3(256), 0, c->stream, d_vals,
                        a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len, a.d_center, st, tiles);
-    hipLaunchKernelGGL((k_big_finish<T>), dim3(nb), dim3(256), 0, c->stream, st, a.d_seg_len, a.len_div,
+    ADN_LAUNCH((k_big_finish<T>), dim3(nb), dim3(256), 0, c->stream, st, a.d_seg_len, a.len_div,
                        a.uniform_len, a.n_seg, a.mode, a.q, a.d_out);
     ADN_HIP(hipGetLastError());
     return ADN_OK;
@@ -1420,7 +1420,7 @@ int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {
         auto kern = k_select_lds<T, XFV, MK, NTV>;                                                           \
         ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),                                    \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));                  \
-        hipLaunchKernelGGL(kern, grid, dim3(NTV), dyn, c->stream, d_vals, a.d_seg_off, a.seg_stride,         \
+        ADN_LAUNCH_NAMED("k_select_lds<" #XFV ", masked=" #MK ", " #NTV ">", kern, grid, dim3(NTV), dyn, c->stream, d_vals, a.d_seg_off, a.seg_stride,         \
                            a.d_seg_len, a.len_div, a.uniform_len, a.mode, a.q, a.d_center, a.d_out, mm, none); \
     } while (0)
         /* short segments: one wave per segment, more segments resident per CU and no cross-wave waits */   \
@@ -1455,11 +1455,11 @@ int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {
     }
     dim3 grid((unsigned)a.n_seg), block(SEL_THREADS);
     if (a.xform == XF_ABSDEV) {
-        hipLaunchKernelGGL((k_select<T, XF_ABSDEV>), grid, block, dyn, c->stream, d_vals,
+        ADN_LAUNCH((k_select<T, XF_ABSDEV>), grid, block, dyn, c->stream, d_vals,
                            a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len,
                            a.mode, a.q, a.d_center, a.d_out, lds_keys, mm, SubsetRanks{nullptr, 1, 0, nullptr, nullptr, nullptr});
     } else {
-        hipLaunchKernelGGL((k_select<T, XF_NONE>), grid, block, dyn, c->stream, d_vals,
+        ADN_LAUNCH((k_select<T, XF_NONE>), grid, block, dyn, c->stream, d_vals,
                            a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len,
                            a.mode, a.q, a.d_center, a.d_out, lds_keys, mm, SubsetRanks{nullptr, 1, 0, nullptr, nullptr, nullptr});
     }
@@ -1491,12 +1491,12 @@ int launch_select_subset(Ctx *c, const T *d_cand, const SubsetSelect &a) {
         if (a.xform == XF_ABSDEV) {
             auto kern = k_select_lds<T, XF_ABSDEV, false, NT>;
             ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-            hipLaunchKernelGGL(kern, dim3((unsigned)a.n_seg), dim3(NT), dyn, c->stream, d_cand, (const int64_t *)nullptr, a.cap,
+            ADN_LAUNCH_NAMED("k_select_lds<XF_ABSDEV, subset, 1024>", kern, dim3((unsigned)a.n_seg), dim3(NT), dyn, c->stream, d_cand, (const int64_t *)nullptr, a.cap,
                                a.d_len, (int64_t)1, (int64_t)0, (int)SEL_MEDIAN, 50.0, center, a.d_out, mm, sub);
         } else {
             auto kern = k_select_lds<T, XF_NONE, false, NT>;
             ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-            hipLaunchKernelGGL(kern, dim3((unsigned)a.n_seg), dim3(NT), dyn, c->stream, d_cand, (const int64_t *)nullptr, a.cap,
+            ADN_LAUNCH_NAMED("k_select_lds<XF_NONE, subset, 1024>", kern, dim3((unsigned)a.n_seg), dim3(NT), dyn, c->stream, d_cand, (const int64_t *)nullptr, a.cap,
                                a.d_len, (int64_t)1, (int64_t)0, (int)SEL_MEDIAN, 50.0, center, a.d_out, mm, sub);
         }
     } else {
@@ -1505,12 +1505,12 @@ int launch_select_subset(Ctx *c, const T *d_cand, const SubsetSelect &a) {
         if (a.xform == XF_ABSDEV) {
             auto kern = k_select<T, XF_ABSDEV>;
             ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-            hipLaunchKernelGGL(kern, dim3((unsigned)a.n_seg), dim3(SEL_THREADS), dyn, c->stream, d_cand, (const int64_t *)nullptr,
+            ADN_LAUNCH_NAMED("k_select<XF_ABSDEV, subset>", kern, dim3((unsigned)a.n_seg), dim3(SEL_THREADS), dyn, c->stream, d_cand, (const int64_t *)nullptr,
                                a.cap, a.d_len, (int64_t)1, (int64_t)0, (int)SEL_MEDIAN, 50.0, center, a.d_out, lds_keys, mm, sub);
         } else {
             auto kern = k_select<T, XF_NONE>;
             ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-            hipLaunchKernelGGL(kern, dim3((unsigned)a.n_seg), dim3(SEL_THREADS), dyn, c->stream, d_cand, (const int64_t *)nullptr,
+            ADN_LAUNCH_NAMED("k_select<XF_NONE, subset>", kern, dim3((unsigned)a.n_seg), dim3(SEL_THREADS), dyn, c->stream, d_cand, (const int64_t *)nullptr,
                                a.cap, a.d_len, (int64_t)1, (int64_t)0, (int)SEL_MEDIAN, 50.0, center, a.d_out, lds_keys, mm, sub);
         }
     }

@@ -899,7 +899,7 @@ static int launch_rows(Ctx *c, const T *d_x, const Signals &sg, const Tables<T> 
     auto kern = k_stft_rows<T, W>;
     ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(groups * n_sig)), dim3(W * 64), lds, c->stream, d_x, sg,
+    ADN_LAUNCH_NAMED("k_stft_rows", kern, dim3((unsigned)(groups * n_sig)), dim3(W * 64), lds, c->stream, d_x, sg,
                        tb, groups, ROW_FT, Tmax, power, S, sig_max);
     ADN_HIP(hipGetLastError());
     return ADN_OK;
@@ -958,7 +958,7 @@ static int launch_apply(Ctx *c, ApplyArgs<T> a, int64_t n_sig, int64_t Tmax) {
     auto kern = k_stft_apply<T, W, MODE>;
     ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.segs_per_sig * n_sig)), dim3(W * 64), lds, c->stream, a);
+    ADN_LAUNCH_NAMED((MODE == APPLY_SUBTRACT ? "k_stft_apply<SUBTRACT>" : "k_stft_apply<GAIN>"), kern, dim3((unsigned)(a.segs_per_sig * n_sig)), dim3(W * 64), lds, c->stream, a);
     ADN_HIP(hipGetLastError());
     return ADN_OK;
 }
@@ -1010,7 +1010,7 @@ int noise_psd(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const i
     double *P = ws_take<double>(c, (size_t)n_sig * F);
     Signals sg{d_off, d_len, n_ch, n_fft, hop, padded};
     ADN_HIP(hipMemsetAsync(sig_max, 0, sizeof(unsigned long long) * n_sig, c->stream));
-    hipLaunchKernelGGL(k_frame_counts, dim3((unsigned)ceil_div(n_sig, 256)), dim3(256), 0, c->stream, sg, n_sig, Tn);
+    ADN_LAUNCH(k_frame_counts, dim3((unsigned)ceil_div(n_sig, 256)), dim3(256), 0, c->stream, sg, n_sig, Tn);
     ADN_TRY(rows_dispatch<T>(c, d_x, sg, tb, n_sig, Ts, 0, S, sig_max));
     SelectArgs sa;
     sa.n_seg = n_sig * F;
@@ -1022,7 +1022,7 @@ int noise_psd(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const i
     sa.q = percentile;
     sa.d_out = P;
     ADN_TRY(launch_select<T>(c, S, sa));
-    hipLaunchKernelGGL((k_profile_finish<T>), dim3((unsigned)n_sig), dim3(256), 0, c->stream, P, sig_max, F,
+    ADN_LAUNCH((k_profile_finish<T>), dim3((unsigned)n_sig), dim3(256), 0, c->stream, P, sig_max, F,
                        spectral_floor, freq_bins, time_frames, d_baseline);
     ADN_HIP(hipGetLastError());
     return ADN_OK;
@@ -1096,11 +1096,11 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     unsigned char *speech = ws_take<unsigned char>(c, (size_t)n_sig * nv_max);
     unsigned char *vad = ws_take<unsigned char>(c, (size_t)n_sig * Ts);   // rows padded like S
     Signals sg{d_off, d_len, n_ch, n_fft, hop, 1};
-    hipLaunchKernelGGL(k_frame_counts, dim3((unsigned)ceil_div(n_sig, 256)), dim3(256), 0, c->stream, sg, n_sig, Tn);
+    ADN_LAUNCH(k_frame_counts, dim3((unsigned)ceil_div(n_sig, 256)), dim3(256), 0, c->stream, sg, n_sig, Tn);
     if (vad_guided) {
-        hipLaunchKernelGGL((k_vad_energy<T>), dim3((unsigned)ceil_div(n_sig * nv_max, 4)), dim3(256), 0, c->stream,
+        ADN_LAUNCH((k_vad_energy<T>), dim3((unsigned)ceil_div(n_sig * nv_max, 4)), dim3(256), 0, c->stream,
                            d_x, sg, n_sig, frame_len, nv_max, speech);
-        hipLaunchKernelGGL(k_vad_map, dim3((unsigned)ceil_div(n_sig * Ts, 256)), dim3(256), 0, c->stream, sg, n_sig,
+        ADN_LAUNCH(k_vad_map, dim3((unsigned)ceil_div(n_sig * Ts, 256)), dim3(256), 0, c->stream, sg, n_sig,
                            frame_len, nv_max, Ts, speech, vad);
     }
     ADN_TRY(rows_dispatch<T>(c, d_x, sg, tb, n_sig, Ts, 1, S, nullptr));
@@ -1125,14 +1125,14 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     sa.d_mask = nullptr;
     sa.d_masked_mean = nullptr;
     if (vad_guided && !fuse_mean) {
-        hipLaunchKernelGGL((k_masked_mean<T>), dim3((unsigned)ceil_div(n_sig * F, 4)), dim3(256), 0, c->stream, S, F,
+        ADN_LAUNCH((k_masked_mean<T>), dim3((unsigned)ceil_div(n_sig * F, 4)), dim3(256), 0, c->stream, S, F,
                            Ts, Ts, n_sig * F, Tn, vad, sraw);
     } else if (!vad_guided) {
         sa.mode = SEL_MEDIAN;
         sa.d_out = sraw;
         ADN_TRY(launch_select<T>(c, S, sa));
     }
-    hipLaunchKernelGGL((k_wiener_gain<T>), dim3((unsigned)n_sig), dim3(256), 3 * F * sizeof(double), c->stream, p10,
+    ADN_LAUNCH((k_wiener_gain<T>), dim3((unsigned)n_sig), dim3(256), 3 * F * sizeof(double), c->stream, p10,
                        sraw, F, kernel_bins, gain);
     ADN_HIP(hipGetLastError());
     ApplyArgs<T> a{};
@@ -1273,22 +1273,22 @@ int band_summary(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, cons
     int64_t *seg_off = ws_take<int64_t>(c, nseg), *seg_len = ws_take<int64_t>(c, nseg);
     double *sum = ws_take<double>(c, nseg);
     Signals sg{d_off, d_len, n_ch, n_fft, hop, padded};
-    hipLaunchKernelGGL(k_frame_counts, dim3((unsigned)ceil_div(n_sig, 256)), dim3(256), 0, c->stream, sg, n_sig, Tn);
+    ADN_LAUNCH(k_frame_counts, dim3((unsigned)ceil_div(n_sig, 256)), dim3(256), 0, c->stream, sg, n_sig, Tn);
     ADN_TRY(rows_dispatch<T>(c, d_x, sg, tb, n_sig, Ts, 0, S, nullptr));
     if (d_time_mean)
-        hipLaunchKernelGGL((k_time_mean<T>), dim3((unsigned)ceil_div(Tmax, 256), (unsigned)n_sig), dim3(256), 0, c->stream,
+        ADN_LAUNCH((k_time_mean<T>), dim3((unsigned)ceil_div(Tmax, 256), (unsigned)n_sig), dim3(256), 0, c->stream,
                            S, F, Ts, Tmax, Tn, d_time_mean);
     if (d_mag)      // the magnitude matrix itself (for the host-side plots), rows of T_max frames
         ADN_HIP(hipMemcpy2DAsync(d_mag, (size_t)Tmax * sizeof(T), S, (size_t)Ts * sizeof(T), (size_t)Tmax * sizeof(T),
                                  (size_t)n_sig * F, hipMemcpyDeviceToDevice, c->stream));
     if (n_bands > 0) {
         ADN_HIP(hipMemsetAsync(sum, 0, sizeof(double) * nseg, c->stream));
-        hipLaunchKernelGGL(k_band_segments, dim3((unsigned)ceil_div((int64_t)nseg, 256)), dim3(256), 0, c->stream, bd, Tn,
+        ADN_LAUNCH(k_band_segments, dim3((unsigned)ceil_div((int64_t)nseg, 256)), dim3(256), 0, c->stream, bd, Tn,
                            n_sig, Tmax, seg_off, seg_len);
         const unsigned gx = (unsigned)std::min<int64_t>(ceil_div(max_seg, 256 * 8), 1024);
-        hipLaunchKernelGGL((k_band_gather<T>), dim3(gx, (unsigned)n_bands, (unsigned)n_sig), dim3(256), 0, c->stream, S, F,
+        ADN_LAUNCH((k_band_gather<T>), dim3(gx, (unsigned)n_bands, (unsigned)n_sig), dim3(256), 0, c->stream, S, F,
                            Ts, bd, Tn, seg_off, B, sum);
-        hipLaunchKernelGGL(k_band_mean, dim3((unsigned)ceil_div((int64_t)nseg, 256)), dim3(256), 0, c->stream, sum, seg_len,
+        ADN_LAUNCH(k_band_mean, dim3((unsigned)ceil_div((int64_t)nseg, 256)), dim3(256), 0, c->stream, sum, seg_len,
                            (int64_t)nseg, d_mean_mag);
         for (int p = 0; p < n_perc; ++p) {
             SelectArgs sa;

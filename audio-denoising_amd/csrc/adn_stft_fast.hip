@@ -860,7 +860,7 @@ int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
     auto kern = a.dbg ? fast::k_apply_fast<W, MODE, true> : fast::k_apply_fast<W, MODE, false>;
     ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.segs_per_sig * n_sig)), dim3(W * 64), lds, c->stream, a);
+    ADN_LAUNCH_NAMED((MODE == APPLY_SUBTRACT ? "k_apply_fast<SUBTRACT>" : "k_apply_fast<GAIN>"), kern, dim3((unsigned)(a.segs_per_sig * n_sig)), dim3(W * 64), lds, c->stream, a);
     ADN_HIP(hipGetLastError());
     if (a.dbg) {
         unsigned long long hp[12];
@@ -892,7 +892,7 @@ int rows_fast(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &
     ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t wgs = ceil_div(groups, (int64_t)fast::ROWS_GPW);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(wgs * n_sig)), dim3(W * 64), lds, c->stream, d_x, sg, tb,
+    ADN_LAUNCH_NAMED("k_rows_fast", kern, dim3((unsigned)(wgs * n_sig)), dim3(W * 64), lds, c->stream, d_x, sg, tb,
                        groups, FT, Tmax, power, S, sig_max);
     ADN_HIP(hipGetLastError());
     return ADN_OK;

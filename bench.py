@@ -9,14 +9,19 @@ on the device before the timed region; every stage reads its input from HBM and
 writes its output to HBM like the reference's stage files.
 
 Multi-GPU: clips are independent, so ranks shard them with no data-path
-collective (weak scaling: the per-GPU batch is fixed).  One rank per GPU, launched
-by torch.distributed.run; RCCL is used only for the barrier / max-time reduction.
+collective (weak scaling: the per-GPU batch is fixed).  One rank per GPU.  Started
+as `python bench.py --gpus N` the script launches the N ranks itself (children
+under torch.distributed.run, before this process touches a GPU) and relays rank
+0's line; started under torch.distributed.run it is one of the ranks.  RCCL is
+used only for the barrier / max-time reduction.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,7 +38,7 @@ N_FFT, HOP = 2048, 512
 HBM_PEAK_GBS = 8000.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -41,12 +46,47 @@ def parse():
     ap.add_argument("--clips", type=int, default=64, help="clips per GPU per step")
     ap.add_argument("--dtype", choices=["f32", "f64"], default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary blocks (fp64 chain, mono filter-bank shapes)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="process-group backend; gloo lets several ranks rehearse on one GPU")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline time budget")
-    return ap.parse_args()
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="time budget of each CPU baseline leg")
+    ap.add_argument("--rehearse-host", action="store_true",
+                    help="no device work at all: launcher, rendezvous, barrier and the max-over-ranks "
+                         "reduction only (what the CPU tests of the multi-rank path run); the line says so")
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------ launcher
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`--gpus N` without a rendezvous in the environment: start N fresh ranks as children.  This
+    process has not initialised a GPU (importing torch does not), and it starts a child instead of
+    replacing itself."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print("bench.py: the %d-rank run failed (exit code %d)" % (args.gpus, proc.returncode), file=sys.stderr)
+        return proc.returncode or 1
+    print(line)
+    return 0
+
+
+# ------------------------------------------------------------------ workload
 class Workload:
     """Device buffers and descriptors of one rank's batch (built once, outside the timed region)."""
 
@@ -117,117 +157,183 @@ class Workload:
                 b.record()
                 events.setdefault(name, []).append((a, b))
 
-    def algorithmic_bytes(self):
+    def algorithmic_bytes(self, realistic=False):
         """Compulsory HBM bytes per step and stage with the stage interface preserved: every stage
         reads its input once and writes its output once; B bytes per value.  Phase 2: 2*B per
         sample-frame-channel; phase 2b and 2c: 2*B per mono sample; phase 1: 1*B per noise sample.
         (Phase 2b actually reads a stereo input, 3*B per frame in total: reported separately as
-        `io_bytes`, not used for the roofline fraction.)"""
+        `io_bytes`, not used for the roofline fraction.)  `realistic`: the two-pass figure, one
+        more read of the input for the statistics that must precede the apply pass (phase 2: the
+        threshold of each block; phase 2c: the per-bin statistics)."""
         bts = 4 if self.dtype == torch.float32 else 8
+        extra = 1 if realistic else 0
         return {"phase1": self.B * self.nn * bts,
-                "phase2": self.B * self.n * 2 * 2 * bts,
+                "phase2": self.B * self.n * 2 * (2 + extra) * bts,
                 "phase2b": self.B * self.n * 2 * bts,
-                "phase2c": self.B * self.l2b * 2 * bts}
+                "phase2c": self.B * self.l2b * (2 + extra) * bts}
+
+    def kernel_algorithmic_bytes(self, kernel):
+        """Algorithmic bytes one launch of `kernel` accounts for: the fused apply kernels carry
+        their stage's compulsory traffic (input read once + output written once); any other
+        kernel is a statistics pass whose algorithmic traffic is one read of its stage's input."""
+        bts = 4 if self.dtype == torch.float32 else 8
+        alg = self.algorithmic_bytes()
+        if "SUBTRACT" in kernel or "Subtract" in kernel:
+            return alg["phase2b"], "phase 2b: 2*B per mono sample (input once + output once)"
+        if "GAIN" in kernel or "Gain" in kernel:
+            return alg["phase2c"], "phase 2c: 2*B per mono sample (input once + output once)"
+        if "ch_apply" in kernel:
+            return alg["phase2"], "phase 2: 2*B per sample-frame-channel"
+        if "rows" in kernel or "select" in kernel or "vad" in kernel:
+            return self.B * self.l2b * bts, "statistics pass of phase 2c: 1*B per mono sample"
+        return self.B * self.n * 2 * bts, "statistics pass of phase 2: 1*B per sample-frame-channel"
 
     def io_bytes_2b(self):
         bts = 4 if self.dtype == torch.float32 else 8
         return self.B * (self.n * 2 + self.l2b) * bts
 
 
-def measured_traffic(kernel_key, clips):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/r1_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this
-    script, FETCH_SIZE doubled as gfx950 requires), scaled from the profiled batch to this one;
-    None when no profile is committed for this kernel."""
-    path = os.path.join(REPO, "profiles", "r1_pmc_traffic.json")
-    try:
-        prof = json.load(open(path))
-        k = prof["kernels"][kernel_key]
-        return k["hbm_bytes_per_clip"] * clips
-    except (OSError, KeyError, ValueError):
-        return None
+class HostRehearsal:
+    """Stands in for Workload under --rehearse-host: no device, no arithmetic."""
+    STAGES = ()
+
+    def step(self, events=None):
+        time.sleep(0.001)
 
 
 def cpu_baseline(budget_s):
-    """The CPU restatement of the same chain (oracle/adn_oracle.py, numpy, one thread) on a
-    bounded sample of the workload: whole 60 s stereo clips + 5 s noise until the budget is spent."""
-    sys.path.insert(0, os.path.join(REPO, "oracle"))
-    import adn_oracle as orc
-    import synth
-    n, nn = CLIP_S * SR, NOISE_S * SR
-    x = synth.stereo_noisy_speech(n, SR, 42, 0)
-    noise = synth.white_noise(nn, 42, 100000)
-    done, t0 = 0, time.perf_counter()
-    while True:
-        base, _ = orc.noise_profile(noise)
-        y2, _, _ = orc.denoise_signal(x, SR)
-        y2b = orc.spectral_subtract(y2, base.astype(np.float32).astype(np.float64))
-        orc.wiener(y2b, SR)
-        done += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or done >= 16:
-            break
-    return {"value": done * CLIP_S / el, "unit": "audio-sec/sec", "cores": 1, "kind": "port",
-            "sample": "%d x (60 s 48 kHz stereo clip + 5 s noise), fp64 numpy restatement, %.1f s of CPU work"
-                      % (done, el)}
+    """The CPU restatement of the same chain (oracle/adn_oracle.py, numpy) on a bounded sample of
+    the workload, single thread and all host cores: oracle/cpu_baseline.py in its own process."""
+    out = subprocess.run([sys.executable, os.path.join(REPO, "oracle", "cpu_baseline.py"),
+                          "--seconds", str(budget_s)], stdout=subprocess.PIPE, text=True, check=True)
+    return json.loads(out.stdout.strip().splitlines()[-1])
 
 
-def main():
-    args = parse()
+def timed_steps(step, steps, barrier):
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def secondary_blocks(eng, args):
+    """Measured beside the headline (1 GPU only): the fp64 chain (the reference's own precision,
+    the drop-in's default) and the mono filter-bank path on BASELINE.json config 3's shape."""
+    out = {}
+
+    def sync():
+        torch.cuda.synchronize()
+
+    # fp64 chain
+    clips = max(1, min(args.clips, 16))
+    wl = Workload(eng, clips, torch.float64, 0)
+    wl.step()
+    ev = {}
+    el = timed_steps(lambda: wl.step(ev), 3, sync)
+    alg = wl.algorithmic_bytes()
+    ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+    out["fp64_chain"] = {
+        "clips": clips, "ms_per_step": 1e3 * el / 3, "audio_sec_per_sec": clips * CLIP_S * 3 / el,
+        "hbm_frac": round(sum(alg.values()) / (el / 3) / 1e9 / HBM_PEAK_GBS, 4),
+        "stages_ms": {k: round(v, 4) for k, v in ms.items()}}
+    del wl
+    torch.cuda.empty_cache()
+
+    # mono blocks: 256 clips x 30 s x 48 kHz, 10 blocks per clip (config 3 is 1024 such clips)
+    clips, n = 256, 30 * SR
+    x = torch.empty(clips * n, dtype=torch.float32, device=eng.torch_device)
+    tmp = torch.empty(n, dtype=torch.float64, device=eng.torch_device)
+    for c in range(16):
+        eng.synth_noisy_speech(n, SR, stream=c, out=tmp)
+        x[c * n:(c + 1) * n] = tmp.float()
+    for c in range(16, clips):
+        x[c * n:(c + 1) * n] = x[(c % 16) * n:(c % 16 + 1) * n]
+    bs = eng.denoise_block_frames(SR, n)
+    starts = np.arange(0, n, bs, dtype=np.int64)
+    off = np.concatenate([c * n + starts for c in range(clips)])
+    d_off, d_len = eng._i64(off), eng._i64(np.full(off.shape, bs, dtype=np.int64))
+    y = torch.empty_like(x)
+    mono = {}
+    for wavelet, level in (("db4", 2), ("db8", 8)):
+        def run():
+            eng.wavelet_denoise(x, d_off, d_len, y, d_off, n_ch=1, wavelet=wavelet, level=level, max_frames=bs)
+        run()
+        el = timed_steps(run, 5, sync) / 5
+        algb = 2 * 4 * clips * n
+        mono["%s_level%d" % (wavelet, level)] = {
+            "ms": round(1e3 * el, 4), "audio_sec_per_sec": clips * 30 / el,
+            "algorithmic_GBps": round(algb / el / 1e9, 1), "hbm_frac": round(algb / el / 1e9 / HBM_PEAK_GBS, 4)}
+    out["mono_wavelet"] = {"workload": "%d x 30 s 48 kHz mono clips, 10 blocks of 144000 samples per clip "
+                                       "(BASELINE.json config 3 shape), fp32" % clips, **mono}
+    return out
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.backend == "gloo":
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world), file=sys.stderr)
+        return 2
+
+    # the CPU leg runs first, in its own process, before this one creates a GPU context
+    cpu = None
+    if not args.no_cpu_baseline and world == 1 and not args.rehearse_host:
+        cpu = cpu_baseline(args.cpu_seconds)
+
+    on_gpu = not args.rehearse_host
+    if on_gpu and args.backend == "gloo":
         local = local % max(torch.cuda.device_count(), 1)       # rehearsal: ranks may share a GPU
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        if args.backend == "nccl":
+        if on_gpu:
+            torch.cuda.set_device(local)
+        if args.backend == "nccl" and on_gpu:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group("gloo")
-    else:
-        dist = None
-    torch.cuda.set_device(local)
-    from adn_hip import get_engine
-    eng = get_engine(local)
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
-    wl = Workload(eng, args.clips, dtype, rank)
+    if on_gpu:
+        torch.cuda.set_device(local)
+        from adn_hip import get_engine
+        eng = get_engine(local)
+        wl = Workload(eng, args.clips, dtype, rank)
+    else:
+        eng, wl = None, HostRehearsal()
 
     def barrier():
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if on_gpu:
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         wl.step()
-    barrier()
     events = {}
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step(events)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    if on_gpu:
+        eng.kernel_timing(True)          # HIP events around the big launches, on the library's stream
+    elapsed = timed_steps(lambda: wl.step(events if on_gpu else None), args.steps, barrier)
+    ktimes = eng.kernel_times() if on_gpu else {}
+    if on_gpu:
+        eng.kernel_timing(False)
     from adn_hip import dist as adist
-    elapsed = adist.max_over_ranks(elapsed, device="cuda" if args.backend == "nccl" else "cpu")
+    elapsed = adist.max_over_ranks(elapsed, device="cuda" if (args.backend == "nccl" and on_gpu) else "cpu")
 
     if rank == 0:
-        ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in events.items()}
-        alg = wl.algorithmic_bytes()
-        stages = {k: {"ms": round(ms[k], 4), "algorithmic_bytes": alg[k],
-                      "GBps": round(alg[k] / ms[k] / 1e6, 1),
-                      "hbm_frac": round(alg[k] / ms[k] / 1e6 / HBM_PEAK_GBS, 4)} for k in ms}
-        # phase 2b is ONE launch of the fused STFT kernel per C-ABI call, so the event pair
-        # around the call times exactly that kernel: the dominant kernel of the chain
-        dom = "phase2b"
-        chain_bytes = sum(alg.values())
-        chain_ms = sum(ms.values())
         audio_s = args.clips * world * CLIP_S * args.steps
         out = {
             "metric": "audio-sec/sec (RTF) for 48 kHz denoise; % of HBM roofline",
-            "value": audio_s / elapsed,
+            "value": audio_s / elapsed if on_gpu else 0.0,
             "unit": "audio-sec/sec",
             "n_gpus": world,
             "steps": args.steps,
@@ -237,31 +343,57 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
-            "data": "synthetic",
+            "data": "synthetic" if on_gpu else "none (host rehearsal: no device work was done, value is not a measurement)",
             "config": {"workload": "core_pipeline phases 1/2/2b/2c on 60 s 48 kHz stereo clips + 5 s noise "
                                    "samples, STFT n_fft=2048 hop=512 (BASELINE.json config 2), %d clips per GPU per step"
                                    % args.clips,
                        "clips_per_gpu": args.clips, "sharding": "clips round-robin over ranks, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "adn::fast::k_apply_fast<8, SUBTRACT, false> (phase 2b, one launch per step)"
-                         if args.dtype == "f32" else "adn::k_stft_apply<double, 3, SUBTRACT> (phase 2b)",
-                         "achieved": stages[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": stages[dom]["hbm_frac"],
-                         "traffic": measured_traffic("void adn::fast::k_apply_fast<8, 0, false>", args.clips)
-                         if args.dtype == "f32" else None,
-                         "traffic_unit": "bytes per launch", "io_bytes_per_launch": wl.io_bytes_2b(),
-                         "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": stages[dom]["ms"]},
-            "chain": {"ms": round(chain_ms, 4), "algorithmic_bytes": chain_bytes,
-                      "GBps": round(chain_bytes / chain_ms / 1e6, 1),
-                      "hbm_frac": round(chain_bytes / chain_ms / 1e6 / HBM_PEAK_GBS, 4)},
-            "stages": stages,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        if on_gpu:
+            ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in events.items()}
+            alg, alg2 = wl.algorithmic_bytes(), wl.algorithmic_bytes(realistic=True)
+            stages = {k: {"ms": round(ms[k], 4), "algorithmic_bytes": alg[k],
+                          "GBps": round(alg[k] / ms[k] / 1e6, 1),
+                          "hbm_frac": round(alg[k] / ms[k] / 1e6 / HBM_PEAK_GBS, 4)} for k in ms}
+            chain_bytes, chain_ms = sum(alg.values()), sum(ms.values())
+            # the dominant kernel = the launch site with the largest total time in the timed region
+            kern = {k: {"launches_per_step": v["count"] / args.steps, "avg_ms": v["total_ms"] / v["count"],
+                        "ms_per_step": v["total_ms"] / args.steps} for k, v in ktimes.items()}
+            dom = max(kern, key=lambda k: kern[k]["ms_per_step"])
+            dom_bytes, dom_note = wl.kernel_algorithmic_bytes(dom)
+            dom_gbps = dom_bytes / kern[dom]["avg_ms"] / 1e6
+            out["roofline"] = {
+                "bound": "hbm", "kernel": dom, "achieved": round(dom_gbps, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(dom_gbps / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "traffic_note": "HBM bytes per launch from the PMC passes are kept in profiles/ (FETCH_SIZE / "
+                                "WRITE_SIZE runs of this command); not replayed here",
+                "algorithmic_bytes_per_launch": dom_bytes, "algorithmic_bytes_rule": dom_note,
+                "avg_launch_ms": round(kern[dom]["avg_ms"], 4),
+                "timing": "HIP events on the library's stream around every launch of this kernel in the timed region"}
+            if "SUBTRACT" in dom:
+                out["roofline"]["io_bytes_per_launch"] = wl.io_bytes_2b()
+            out["chain"] = {"ms": round(chain_ms, 4), "algorithmic_bytes": chain_bytes,
+                            "GBps": round(chain_bytes / chain_ms / 1e6, 1),
+                            "hbm_frac": round(chain_bytes / chain_ms / 1e6 / HBM_PEAK_GBS, 4),
+                            "hbm_frac_two_pass": round(sum(alg2.values()) / chain_ms / 1e6 / HBM_PEAK_GBS, 4),
+                            "two_pass_note": "not graded: phase 2 and 2c counted with the extra input read "
+                                             "their statistics need (3*B instead of 2*B per sample)"}
+            out["stages"] = stages
+            out["kernels"] = {k: {kk: round(vv, 4) for kk, vv in v.items()} for k, v in
+                              sorted(kern.items(), key=lambda kv: -kv[1]["ms_per_step"])}
+            if world == 1 and not args.no_secondary:
+                del wl
+                torch.cuda.empty_cache()
+                out["secondary"] = secondary_blocks(eng, args)
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -54,16 +54,24 @@ int adn_destroy(adn_ctx *ctx);
 int adn_set_stream(adn_ctx *ctx, void *hip_stream);
 /* Blocks the host until everything enqueued on the context's stream is done. */
 int adn_synchronize(adn_ctx *ctx);
-/* Tuning / test knobs.  ADN_OPT_FORCE_GENERIC, value 1: run the shape-generic
- * kernels even where a specialised one exists (binary32, n_fft = 2048; fused wavelet
- * tiles; single-pass threshold statistics of stereo blocks), so that tests can cover
- * both.  Value 2: specialised kernels, but the single-pass threshold statistics hand
- * every block to their exact per-block fallback.  0 restores normal operation. */
-/* ADN_OPT_ABLATE (diagnostics, results become WRONG): bit mask of stages the fused
- * binary32 STFT kernel skips - 1 analysis, 2 synthesis, 4 overlap-add - so that the
- * cost of each stage can be timed.  0 restores normal operation. */
-enum { ADN_OPT_FORCE_GENERIC = 1, ADN_OPT_ABLATE = 2 };
+/* Tuning / test knobs (value 0 restores normal operation).
+ * ADN_OPT_FORCE_GENERIC: run the shape-generic kernels even where a specialised one exists
+ *   (binary32, n_fft = 2048; fused wavelet tiles; single-pass threshold statistics), so that
+ *   tests can cover both.
+ * ADN_OPT_FORCE_FALLBACK: the single-pass threshold statistics hand every block to their exact
+ *   per-block fallback (independent of ADN_OPT_FORCE_GENERIC).
+ * ADN_OPT_ABLATE (diagnostics, results become WRONG): bit mask of stages the fused binary32
+ *   STFT kernel skips - 1 analysis, 2 synthesis, 4 overlap-add - so that the cost of each stage
+ *   can be timed.
+ * ADN_OPT_KERNEL_TIMING: record a HIP event pair on the context's stream around every kernel
+ *   launch; adn_kernel_times() reports them.  Switching it off drops unreported records. */
+enum { ADN_OPT_FORCE_GENERIC = 1, ADN_OPT_ABLATE = 2, ADN_OPT_FORCE_FALLBACK = 3, ADN_OPT_KERNEL_TIMING = 4 };
 int adn_set_option(adn_ctx *ctx, int option, int value);
+/* Measurement aid (no counterpart in the reference): synchronises the stream, then writes one
+ * line per launch site timed since the last report, "name<TAB>launches<TAB>total_ms<NEWLINE>",
+ * NUL-terminated, into buf and forgets the records.  Returns the text length, -1 on failure, or
+ * minus the capacity needed when cap is too small (records are dropped then too). */
+int64_t adn_kernel_times(adn_ctx *ctx, char *buf, int64_t cap);
 /* Bytes of device workspace currently held by the context. */
 int64_t adn_workspace_bytes(adn_ctx *ctx);
 

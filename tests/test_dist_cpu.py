@@ -49,3 +49,36 @@ def test_single_process_passthrough():
     p = torch.ones(4)
     assert adist.broadcast_profile(p, 4) is p
     assert list(adist.shard_indices(5, 1, 2)) == [1, 3]
+
+
+def _run_bench(*flags):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *flags], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    return out, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no rendezvous in the environment starts two ranks itself
+    (host rehearsal: no device work) and prints one line that says n_gpus = 2."""
+    out, line = _run_bench("--gpus", "2", "--backend", "gloo", "--rehearse-host", "--steps", "3", "--warmup", "1")
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert line is not None and line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["scaling"] == "weak" and "rehearsal" in line["data"]
+    assert len([ln for ln in out.stdout.splitlines() if ln.startswith("{")]) == 1     # rank 0 only
+
+
+def test_bench_single_rank_line_and_world_mismatch():
+    out, line = _run_bench("--rehearse-host", "--steps", "2", "--warmup", "0")
+    assert out.returncode == 0 and line["n_gpus"] == 1
+    # a rendezvous that disagrees with --gpus is an error, not a silent 1-rank run
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--rehearse-host"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
