@@ -106,7 +106,9 @@ class NoiseProfiler:
         self.cleanUp()
         if not parts:
             return []
-        return numpy.concatenate(parts, axis=0)
+        # a Python list like the reference's (one element per row: numpy scalars for mono
+        # input, channel rows for multi-channel input)
+        return list(numpy.concatenate(parts, axis=0))
 
     def getWindowsRMSasEnvelope(self):
         return numpy.concatenate([w.getRMSasArray() for w in self.windows]) if self.windows else numpy.array([])

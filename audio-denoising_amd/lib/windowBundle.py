@@ -63,10 +63,8 @@ class WindowBundle:
         return self.waveletPacket
 
     def getWaveletLeafData(self):
-        out = []
-        for node in self.waveletPacket.get_level(self.wlevels, "freq"):
-            out.extend(node.data)
-        return out
+        from lib import waveletHelper
+        return waveletHelper.waveletLeafData(self.waveletPacket)
 
     def setDenoisedData(self, denoisedData):
         self.denoisedData = denoisedData
