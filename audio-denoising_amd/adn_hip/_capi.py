@@ -13,6 +13,7 @@ OK, ERR_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_NOMEM, ERR_SHORT = 0, -1, -2, -3, -4,
 WAVELET = {"db4": 0, "db8": 1}
 EXT = {"per": 0, "periodization": 0, "sym": 1, "symmetric": 1}
 THR = {"soft": 0, "hard": 1}
+AXIS = {"reference": 0, "time": 1}
 MASK = {"soft": 0, "hard": 1, "binary": 2}
 
 _vp, _i, _i64, _d, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_uint64
@@ -35,7 +36,7 @@ _PLAIN = {
 }
 # per-precision symbols (suffix _f32 / _f64); every data pointer is passed as void*
 _TYPED = {
-    "adn_wavelet_denoise": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp, _vp],
+    "adn_wavelet_denoise": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp],
     "adn_mad": [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp],
     "adn_wavedec": [_vp, _vp, _i64, _i, _i, _i, _vp, _i64, C.POINTER(_i64)],
     "adn_waverec": [_vp, _vp, C.POINTER(_i64), _i, _i, _i, _vp, _i64, C.POINTER(_i64)],

@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from ._capi import AdnError, WAVELET, EXT, THR
+from ._capi import AdnError, WAVELET, EXT, THR, AXIS
 
 _ENGINES = {}
 
@@ -123,6 +123,9 @@ class Engine:
         return t
 
     def _call(self, base, dtype, *args):
+        # work goes to whatever stream torch has current now (callers may be inside a
+        # torch.cuda.stream(...) block): the buffers torch hands out are ordered on that stream
+        self.use_current_stream()
         fn = getattr(self.lib, base + _suffix(dtype))
         self._check(fn(self._h, *args))
 
@@ -141,23 +144,27 @@ class Engine:
 
     # --------------------------------------------------------------- phase 2
     def wavelet_denoise(self, x, in_off, frames, out, out_off, n_ch=1, wavelet="db4", level=2,
-                        thr_mode="soft", want_stats=False, max_frames=None):
+                        thr_mode="soft", want_stats=False, max_frames=None, mode="per", axis="reference"):
         """Batched VisuShrink block denoise.  x / out: flat device tensors; in_off, frames,
-        out_off: int64 device tensors (element offsets / frame counts per block)."""
+        out_off: int64 device tensors (element offsets / frame counts per block).  axis="time"
+        denoises every channel of a multi-channel block along time (statistics then hold one
+        value per block and channel); the default does what the reference does."""
         nb = int(frames.numel())
         if max_frames is None:
             max_frames = int(frames.max().item()) if nb else 1
         sigma = thresh = zeroed = None
         if want_stats:
-            sigma = torch.empty(nb, dtype=torch.float64, device=self.torch_device)
-            thresh = torch.empty(nb, dtype=torch.float64, device=self.torch_device)
-            zeroed = torch.empty(nb, dtype=torch.int64, device=self.torch_device)
+            nu = nb * n_ch if (n_ch > 1 and axis == "time") else nb
+            sigma = torch.empty(nu, dtype=torch.float64, device=self.torch_device)
+            thresh = torch.empty(nu, dtype=torch.float64, device=self.torch_device)
+            zeroed = torch.empty(nu, dtype=torch.int64, device=self.torch_device)
         self._call("adn_wavelet_denoise", x.dtype, _ptr(x), _ptr(out), nb, _ptr(in_off), _ptr(frames),
-                   _ptr(out_off), int(max_frames), int(n_ch), WAVELET[wavelet], int(level),
-                   THR[thr_mode], _ptr(sigma), _ptr(thresh), _ptr(zeroed))
+                   _ptr(out_off), int(max_frames), int(n_ch), AXIS[axis], WAVELET[wavelet], int(level),
+                   EXT[mode], THR[thr_mode], _ptr(sigma), _ptr(thresh), _ptr(zeroed))
         return (sigma, thresh, zeroed) if want_stats else None
 
-    def denoise_signal(self, x, rate, wavelet="db4", level=2, thr_mode="soft", want_stats=False):
+    def denoise_signal(self, x, rate, wavelet="db4", level=2, thr_mode="soft", want_stats=False, mode="per",
+                       axis="reference"):
         """AudioDeNoise.deNoise arithmetic on a device tensor of shape (frames,) or
         (frames, channels): blocks of int(rate * duration * 0.10) frames, each denoised
         independently.  Returns the concatenated blocks (and per-block stats)."""
@@ -168,7 +175,7 @@ class Engine:
             raise ValueError("input shorter than 10 frames: block size is zero")
         starts = np.arange(0, frames_total, bs, dtype=np.int64)
         lens = np.minimum(bs, frames_total - starts)
-        if n_ch == 1:
+        if n_ch == 1 or axis == "time":
             out_lens = 2 * ((lens + 1) // 2)
         else:
             out_lens = lens
@@ -178,7 +185,8 @@ class Engine:
         xc = x.contiguous()
         stats = self.wavelet_denoise(xc.view(-1), self._i64(starts * n_ch), self._i64(lens), out.view(-1),
                                      self._i64(out_starts * n_ch), n_ch=n_ch, wavelet=wavelet, level=level,
-                                     thr_mode=thr_mode, want_stats=want_stats, max_frames=int(lens.max()))
+                                     thr_mode=thr_mode, want_stats=want_stats, max_frames=int(lens.max()),
+                                     mode=mode, axis=axis)
         return (out, stats) if want_stats else out
 
     def wavedec(self, x, wavelet="db4", level=2, mode="per"):

@@ -3,7 +3,9 @@ manifest of the reference's src/pipeline.py:10-78 and src/pipeline_v2.py:17-435.
 
 Host-only: every stage is one subprocess of a script that lies next to the orchestrator script,
 so the orchestrators keep working when only some of the stage scripts are the MI355X ones.
-A phase whose script is not in that directory is recorded as skipped (an error in strict mode).
+A selected phase whose script is not in that directory fails the run, as launching the missing
+script does in the reference (src/pipeline_v2.py:123-135); ADN_ALLOW_MISSING_STAGES=1 records it as
+skipped instead (partial installs), and the run then still ends with a non-zero exit code.
 """
 import argparse
 import hashlib
@@ -222,7 +224,7 @@ def pipeline_v2_main(argv=None, src_dir=None):
     src = Path(src_dir) if src_dir else Path(__file__).resolve().parents[1] / "src"
     extra_args = {"mastering_chain.py": ["--profile", args.profile] if args.profile else [],
                   "metrics_eval.py": ["--reference", args.reference] if args.reference else []}
-    results = {}
+    results, missing = {}, []
     for phase in ALL_PHASES:
         if phase not in selected:
             continue
@@ -235,10 +237,11 @@ def pipeline_v2_main(argv=None, src_dir=None):
                 results[key] = {"status": "skipped", "reason": "missing_deps"}
                 continue
             if not (src / script).exists() and not dry_run:
-                if strict:
-                    raise RuntimeError(f"Stage script not found: {src / script}")
+                if strict or os.environ.get("ADN_ALLOW_MISSING_STAGES", "0") != "1":
+                    raise RuntimeError(f"Step failed: stage script not found: {src / script}")
                 print(f"[SKIP] {script} is not installed next to the orchestrator")
                 results[key] = {"status": "skipped", "reason": "script_missing"}
+                missing.append(script)
                 continue
             cmd = [sys.executable, str(src / script), "--config", args.config] + extra_args.get(script, [])
             results[key] = run_step(cmd, os.path.join(paths["logs_dir"], log), dry_run)
@@ -262,6 +265,8 @@ def pipeline_v2_main(argv=None, src_dir=None):
         print(f"Final output: {final_output}")
         print(f"Output size: {os.path.getsize(final_output) / (1024 * 1024):.2f} MB")
     print(rule)
+    if missing:
+        raise SystemExit("selected phases did not run, their scripts are missing: " + ", ".join(missing))
     return manifest
 
 

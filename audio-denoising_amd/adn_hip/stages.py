@@ -156,8 +156,6 @@ def analyze_audio_main(argv=None):
     bands, vad_cfg = ana["child_bands_hz"], ana["vad"]
     if str(st["window"]).lower() not in ("hann", "hanning"):
         raise NotImplementedError("only the Hann window of the reference configs is implemented")
-    if int(st["n_fft"]) != int(st["win_length"]):
-        raise NotImplementedError("n_fft must equal win_length (all reference configs)")
     x, sr_x = wavio.read(input_path)
     n, sr_n = wavio.read(noise_path)
     if sr_cfg and sr_x != sr_cfg:
@@ -391,58 +389,60 @@ def hpss_separate_main(argv=None):
     print(f"[INFO] Energy distribution: H={energy_harmonic:.3f}, P={energy_percussive:.3f}")
 
 
+class StageRunner:
+    """Runs one stage and leaves the log the orchestrators' users grep: the stage's merged
+    stdout / stderr, then `[elapsed_sec]: %.3f` and `[returncode]: %d` (log format of
+    src/core_pipeline.py:26-39).  A stage is either a command (one interpreter per stage, like the
+    reference) or a callable taking argv (same process: the GPU context, the kernels' tables and
+    the device-resident stage files are shared by the stages that follow).  A non-zero outcome
+    prints the captured output and ends the run with SystemExit, as the reference does."""
+
+    def __init__(self, log_path):
+        self.log_path = Path(log_path)
+        self.log_path.parent.mkdir(parents=True, exist_ok=True)
+
+    def _finish(self, what, text, rc, seconds):
+        with open(self.log_path, "w", encoding="utf-8") as fh:
+            fh.write(f"{text or ''}\n[elapsed_sec]: {seconds:.3f}\n[returncode]: {rc}\n")
+        if rc != 0:
+            print(text)
+            raise SystemExit(f"Step failed: {what} (see {self.log_path})")
+        print(f"[OK] ({seconds:.1f}s) -> {self.log_path}")
+
+    def command(self, cmd):
+        what = " ".join(cmd)
+        print(f"[RUN] {what}")
+        start = time.time()
+        done = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        self._finish(what, done.stdout, done.returncode, time.time() - start)
+
+    def call(self, label, fn, argv):
+        import contextlib
+        import io
+        import traceback
+        what = f"{label} {' '.join(argv)}"
+        print(f"[RUN] {what}")
+        captured, rc, start = io.StringIO(), 0, time.time()
+        with contextlib.redirect_stdout(captured), contextlib.redirect_stderr(captured):
+            try:
+                fn(argv)
+            except SystemExit as ex:
+                if ex.code not in (None, 0):
+                    rc = ex.code if isinstance(ex.code, int) else 1
+                    if not isinstance(ex.code, int):
+                        print(ex.code)
+            except Exception:  # noqa: BLE001 - a stage failure of any kind ends the run like a non-zero exit
+                traceback.print_exc(file=captured)
+                rc = 1
+        self._finish(what, captured.getvalue(), rc, time.time() - start)
+
+
 def run_step(cmd, log_path):
-    """One stage as a subprocess; same log format as src/core_pipeline.py:26-39."""
-    log_path = Path(log_path)
-    log_path.parent.mkdir(parents=True, exist_ok=True)
-    print(f"[RUN] {' '.join(cmd)}")
-    t0 = time.time()
-    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    dt = time.time() - t0
-    with open(log_path, "w", encoding="utf-8") as fh:
-        fh.write(proc.stdout or "")
-        fh.write(f"\n[elapsed_sec]: {dt:.3f}\n")
-        fh.write(f"[returncode]: {proc.returncode}\n")
-    if proc.returncode != 0:
-        print(proc.stdout)
-        raise SystemExit(f"Step failed: {' '.join(cmd)} (see {log_path})")
-    print(f"[OK] ({dt:.1f}s) -> {log_path}")
+    StageRunner(log_path).command(cmd)
 
 
 def run_step_inprocess(label, fn, argv, log_path):
-    """One stage as a function call in this process: the stage's prints and any traceback go to the
-    same log file, in the same format, as a subprocess run would leave (src/core_pipeline.py:26-39).
-    The GPU context, the kernels' tables and the device-resident stage files are shared by the
-    stages that follow."""
-    import contextlib
-    import io
-    import traceback
-    log_path = Path(log_path)
-    log_path.parent.mkdir(parents=True, exist_ok=True)
-    print(f"[RUN] {label} {' '.join(argv)}")
-    buf = io.StringIO()
-    rc = 0
-    t0 = time.time()
-    with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(buf):
-        try:
-            fn(argv)
-        except SystemExit as ex:
-            if ex.code not in (None, 0):
-                rc = ex.code if isinstance(ex.code, int) else 1
-                if not isinstance(ex.code, int):
-                    print(ex.code)
-        except Exception:  # noqa: BLE001 - a stage failure of any kind ends the run like a non-zero exit
-            traceback.print_exc(file=buf)
-            rc = 1
-    dt = time.time() - t0
-    with open(log_path, "w", encoding="utf-8") as fh:
-        fh.write(buf.getvalue())
-        fh.write(f"\n[elapsed_sec]: {dt:.3f}\n")
-        fh.write(f"[returncode]: {rc}\n")
-    if rc != 0:
-        print(buf.getvalue())
-        raise SystemExit(f"Step failed: {label} {' '.join(argv)} (see {log_path})")
-    print(f"[OK] ({dt:.1f}s) -> {log_path}")
+    StageRunner(log_path).call(label, fn, argv)
 
 
 def core_pipeline_main(argv=None, src_dir=None):

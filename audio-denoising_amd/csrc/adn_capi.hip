@@ -16,8 +16,38 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+int aux_reserve(Ctx *c, size_t bytes) {
+    if (bytes <= c->aux_bytes) return ADN_OK;
+    if (c->ws_fixed) {
+        set_error("this mode needs %zu bytes of device memory beyond the fixed scratch buffer; "
+                  "the entry point that allocates nothing does not support it", bytes);
+        return ADN_ERR_NOMEM;
+    }
+    if (c->aux) {
+        ADN_HIP(hipStreamSynchronize(c->stream));
+        ADN_HIP(hipFree(c->aux));
+        c->aux = nullptr;
+        c->aux_bytes = 0;
+    }
+    void *p = nullptr;
+    const size_t want = bytes + bytes / 8 + (1u << 20);
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        set_error("allocation of %zu bytes failed: %s", want, hipGetErrorString(e));
+        return ADN_ERR_NOMEM;
+    }
+    c->aux = static_cast<char *>(p);
+    c->aux_bytes = want;
+    return ADN_OK;
+}
+
 int ws_reserve(Ctx *c, size_t bytes) {
     if (bytes <= c->ws_bytes) return ADN_OK;
+    if (c->ws_fixed) {
+        set_error("input too large for the entry point that allocates nothing: it needs %zu bytes of "
+                  "scratch, the fixed scratch buffer holds %zu", bytes, c->ws_bytes);
+        return ADN_ERR_NOMEM;
+    }
     // round up generously so that slowly growing batches do not reallocate every call
     size_t want = bytes + bytes / 8 + (1u << 20);
     if (c->ws) {
@@ -104,6 +134,7 @@ int adn_destroy(adn_ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     adn::drop_kernel_records(c);
     if (c->ws) (void)hipFree(c->ws);
+    if (c->aux) (void)hipFree(c->aux);
     for (int i = 0; i < c->n_tables; ++i)
         if (c->tables[i].dev) (void)hipFree(c->tables[i].dev);
     delete c;
@@ -200,11 +231,12 @@ int64_t adn_istft_out_samples(int64_t n, int n_fft, int hop) {
     int adn_wavelet_denoise_##SUF(adn_ctx *c, const T *d_in, T *d_out, int64_t n_blocks,            \
                                   const int64_t *d_in_off, const int64_t *d_frames,                 \
                                   const int64_t *d_out_off, int64_t max_frames, int n_ch,           \
-                                  int wavelet, int level, int thr_mode, double *d_sigma,            \
-                                  double *d_thresh, int64_t *d_zeroed) {                            \
+                                  int axis_mode, int wavelet, int level, int ext_mode,              \
+                                  int thr_mode, double *d_sigma, double *d_thresh,                  \
+                                  int64_t *d_zeroed) {                                              \
         return adn::wavelet_denoise<T>(c, d_in, d_out, n_blocks, d_in_off, d_frames, d_out_off,     \
-                                       max_frames, n_ch, wavelet, level, thr_mode, d_sigma,         \
-                                       d_thresh, d_zeroed);                                         \
+                                       max_frames, n_ch, axis_mode, wavelet, level, ext_mode,       \
+                                       thr_mode, d_sigma, d_thresh, d_zeroed);                      \
     }                                                                                               \
     int adn_mad_##SUF(adn_ctx *c, const T *d_x, int64_t n_seg, const int64_t *d_off,                \
                       const int64_t *d_len, int64_t max_len, double *d_median, double *d_mad) {     \

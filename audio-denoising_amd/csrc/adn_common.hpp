@@ -59,6 +59,9 @@ struct Ctx {
     char *ws = nullptr;        // device workspace
     size_t ws_bytes = 0;
     size_t ws_used = 0;        // bump pointer, reset per call
+    bool ws_fixed = false;     // the workspace is a caller-independent fixed buffer: never grow, never allocate
+    char *aux = nullptr;       // second growable buffer (planar copies of the time-axis multi-channel mode)
+    size_t aux_bytes = 0;
     int num_cus = 256;
     bool force_generic = false;   // test hook: skip the specialised kernels
     bool force_fallback = false;  // test hook: the single-pass threshold statistics send every block to their exact fallback
@@ -98,6 +101,8 @@ struct KScope {
 // Ensure the workspace holds at least `bytes`; growing synchronises the stream
 // (the old buffer may still be in use) and reallocates.
 int ws_reserve(Ctx *c, size_t bytes);
+// Same for the second buffer (whole-buffer use, no bump allocator).
+int aux_reserve(Ctx *c, size_t bytes);
 // Reset the bump allocator (start of an entry point).
 inline void ws_reset(Ctx *c) { c->ws_used = 0; }
 // Carve `bytes` (256-B aligned) out of the reserved workspace.

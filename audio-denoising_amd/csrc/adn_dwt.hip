@@ -416,17 +416,9 @@ __global__ __launch_bounds__(256) void k_ch_stats(const T *__restrict__ x, T *__
     }
 }
 
-// Soft / hard shrink; binary32 uses the hardware reciprocal for t / |d| (same 0, inf and NaN cases as the
-// division: t * rcp(0) = inf -> factor clamped to 0; 0 * inf = NaN like 0 / 0).
-__device__ __forceinline__ float shrink_ch(float d, float t, int thr_mode) {
-    if (thr_mode == ADN_THR_SOFT) {
-        float f = 1.0f - t * __builtin_amdgcn_rcpf(fabsf(d));
-        f = f < 0.0f ? 0.0f : f;
-        return d * f;
-    }
-    return fabsf(d) < t ? 0.0f : d;
-}
-__device__ __forceinline__ double shrink_ch(double d, double t, int thr_mode) { return shrink(d, t, thr_mode); }
+// Soft / hard shrink of the channel-axis kernels: the same IEEE division as the mono path.
+template <typename T>
+__device__ __forceinline__ T shrink_ch(T d, T t, int thr_mode) { return shrink(d, t, thr_mode); }
 
 // Pass 2: analysis, shrink of every detail coefficient, synthesis, per frame.
 template <typename T, int NCH, int NC>
@@ -566,15 +558,19 @@ static int channel_denoise(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t
 
 template <typename T>
 static int general_denoise(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_frames,
-                           int wavelet, int level, int thr_mode, double *d_sigma,
+                           int wavelet, int level, int ext, int thr_mode, double *d_sigma,
                            double *d_thresh, int64_t *d_zeroed) {
     const Taps<T> tp = make_taps<T>(wavelet);
-    const int F = tp.F, ext = ADN_EXT_PERIODIZATION;
-    g.a_stride = (max_frames + 1) / 2 + 1;
-    g.d_stride = max_frames + level + 1;
+    const int F = tp.F;
+    // symmetric synthesis of level l writes 2 K - F + 2 values, one more than the band above
+    // keeps when that band's length is odd (pywt.waverec drops it): one spare slot per block
+    g.a_stride = band_len(max_frames, 1, F, ext) + 2;
+    g.d_stride = level + 1;
+    for (int l = 1; l <= level; ++l) g.d_stride += band_len(max_frames, l, F, ext);
+    const int64_t max_seg = band_len(max_frames, 1, F, ext);
     const size_t nA = (size_t)g.n_blocks * g.a_stride, nD = (size_t)g.n_blocks * g.d_stride;
     ADN_TRY(ws_reserve(c, 2 * ws_need(nA, sizeof(T)) + ws_need(nD, sizeof(T)) +
-                          mad_ws_bytes(g.n_blocks, (max_frames + 1) / 2)));
+                          mad_ws_bytes(g.n_blocks, max_seg)));
     T *A0 = ws_take<T>(c, nA), *A1 = ws_take<T>(c, nA), *D = ws_take<T>(c, nD);
     for (int l = 1; l <= level; ++l) {
         const int64_t tiles = ceil_div(band_len(max_frames, l, F, ext), 256);
@@ -582,7 +578,7 @@ static int general_denoise(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t
                            c->stream, d_in, A0, A1, D, g, l, ext, tp, tiles);
     }
     double *thresh = nullptr;
-    ADN_TRY(mad_threshold<T>(c, D, g, F, ext, 0, (max_frames + 1) / 2, d_sigma, d_thresh, &thresh));
+    ADN_TRY(mad_threshold<T>(c, D, g, F, ext, 0, max_seg, d_sigma, d_thresh, &thresh));
     for (int l = level; l >= 1; --l) {
         const int64_t tiles = ceil_div(2 * band_len(max_frames, l, F, ext), 256);
         ADN_LAUNCH((k_inv_level<T>), dim3((unsigned)(tiles * g.n_blocks)), dim3(256), 0,
@@ -593,30 +589,101 @@ static int general_denoise(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t
     return ADN_OK;
 }
 
+// Mono blocks (transform along time): fused tiles where they apply, level kernels otherwise.
+template <typename T>
+static int mono_denoise(Ctx *c, const T *d_in, T *d_out, const BlockGeom &g, int64_t max_frames,
+                        int wavelet, int level, int ext, int thr_mode, double *d_sigma,
+                        double *d_thresh, int64_t *d_zeroed) {
+    if (ext == ADN_EXT_PERIODIZATION) {
+        bool handled = false;
+        ADN_TRY(wavelet_denoise_fused<T>(c, d_in, d_out, g, max_frames, wavelet, level, thr_mode,
+                                         d_sigma, d_thresh, d_zeroed, &handled));
+        if (handled) return ADN_OK;
+    }
+    return general_denoise<T>(c, d_in, d_out, g, max_frames, wavelet, level, ext, thr_mode, d_sigma,
+                              d_thresh, d_zeroed);
+}
+
+// ADN_AXIS_TIME on interleaved multi-channel blocks: channel ch of block b becomes the mono block
+// b * n_ch + ch of a planar copy (plane stride pstride), and back.
+template <typename T>
+__global__ __launch_bounds__(256) void k_planar_split(const T *__restrict__ x, T *__restrict__ P, BlockGeom g,
+                                                      int n_ch, int64_t pstride, int64_t tiles_per_block) {
+    const int64_t b = blockIdx.x / tiles_per_block;
+    const int64_t e = (blockIdx.x % tiles_per_block) * 256 + threadIdx.x;    // element of the interleaved block
+    if (e >= g.frames[b] * n_ch) return;
+    const int64_t f = e / n_ch;
+    const int ch = (int)(e % n_ch);
+    P[(b * n_ch + ch) * pstride + f] = x[g.in_off[b] + e];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_planar_join(const T *__restrict__ Q, T *__restrict__ y, BlockGeom g,
+                                                     int n_ch, int64_t pstride, int64_t tiles_per_block) {
+    const int64_t b = blockIdx.x / tiles_per_block;
+    const int64_t e = (blockIdx.x % tiles_per_block) * 256 + threadIdx.x;
+    const int64_t out_frames = g.frames[b] + (g.frames[b] & 1);              // every synthesis returns an even length
+    if (e >= out_frames * n_ch) return;
+    const int64_t f = e / n_ch;
+    const int ch = (int)(e % n_ch);
+    y[g.out_off[b] + e] = Q[(b * n_ch + ch) * pstride + f];
+}
+
+__global__ void k_planar_desc(const int64_t *__restrict__ frames, int64_t n_blocks, int n_ch, int64_t pstride,
+                              int64_t *__restrict__ off2, int64_t *__restrict__ frames2) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= n_blocks * n_ch) return;
+    off2[i] = i * pstride;
+    frames2[i] = frames[i / n_ch];
+}
+
 template <typename T>
 int wavelet_denoise(Ctx *c, const T *d_in, T *d_out, int64_t n_blocks, const int64_t *d_in_off,
                     const int64_t *d_frames, const int64_t *d_out_off, int64_t max_frames,
-                    int n_ch, int wavelet, int level, int thr_mode, double *d_sigma,
-                    double *d_thresh, int64_t *d_zeroed) {
+                    int n_ch, int axis_mode, int wavelet, int level, int ext_mode, int thr_mode,
+                    double *d_sigma, double *d_thresh, int64_t *d_zeroed) {
     ADN_REQUIRE(c && d_in && d_out && d_in_off && d_frames && d_out_off, "null pointer argument");
     ADN_REQUIRE(n_blocks >= 0 && max_frames >= 1, "n_blocks must be >= 0 and max_frames >= 1");
     ADN_REQUIRE(wavelet == ADN_WAVELET_DB4 || wavelet == ADN_WAVELET_DB8, "unknown wavelet id %d", wavelet);
     ADN_REQUIRE(level >= 1 && level <= 16, "level must be in [1, 16], got %d", level);
     ADN_REQUIRE(thr_mode == ADN_THR_SOFT || thr_mode == ADN_THR_HARD, "unknown threshold mode %d", thr_mode);
+    ADN_REQUIRE(ext_mode == ADN_EXT_PERIODIZATION || ext_mode == ADN_EXT_SYMMETRIC, "unknown extension mode %d", ext_mode);
+    ADN_REQUIRE(axis_mode == ADN_AXIS_REFERENCE || axis_mode == ADN_AXIS_TIME, "unknown axis mode %d", axis_mode);
     ADN_REQUIRE(n_ch >= 1, "n_ch must be >= 1");
     if (n_blocks == 0) return ADN_OK;
-    ADN_REQUIRE(n_blocks * ceil_div(max_frames, 256) < (int64_t)0x7FFFFFFF, "batch too large for one launch");
+    ADN_REQUIRE(n_blocks * n_ch * ceil_div(max_frames, 256) < (int64_t)0x7FFFFFFF, "batch too large for one launch");
     DeviceGuard dg(c->device);
     ws_reset(c);
-    if (d_zeroed) ADN_HIP(hipMemsetAsync(d_zeroed, 0, sizeof(int64_t) * n_blocks, c->stream));
+    const int64_t n_units = (n_ch > 1 && axis_mode == ADN_AXIS_TIME) ? n_blocks * n_ch : n_blocks;
+    if (d_zeroed) ADN_HIP(hipMemsetAsync(d_zeroed, 0, sizeof(int64_t) * n_units, c->stream));
     BlockGeom g{d_in_off, d_frames, d_out_off, n_blocks, 0, 0};
-    if (n_ch == 1) {
-        bool handled = false;
-        ADN_TRY(wavelet_denoise_fused<T>(c, d_in, d_out, g, max_frames, wavelet, level, thr_mode,
-                                         d_sigma, d_thresh, d_zeroed, &handled));
-        if (handled) return ADN_OK;
-        return general_denoise<T>(c, d_in, d_out, g, max_frames, wavelet, level, thr_mode, d_sigma,
-                                  d_thresh, d_zeroed);
+    if (n_ch == 1)
+        return mono_denoise<T>(c, d_in, d_out, g, max_frames, wavelet, level, ext_mode, thr_mode, d_sigma,
+                               d_thresh, d_zeroed);
+    if (axis_mode == ADN_AXIS_TIME) {
+        // planar copies live in the context's second buffer: the mono path owns the workspace
+        const int64_t pstride = (max_frames + 2 + 63) & ~int64_t(63);
+        const size_t plane = ws_need((size_t)n_units * pstride, sizeof(T));
+        ADN_TRY(aux_reserve(c, 2 * plane + 2 * ws_need(n_units, sizeof(int64_t))));
+        T *P = reinterpret_cast<T *>(c->aux), *Q = reinterpret_cast<T *>(c->aux + plane);
+        int64_t *off2 = reinterpret_cast<int64_t *>(c->aux + 2 * plane);
+        int64_t *frames2 = reinterpret_cast<int64_t *>(c->aux + 2 * plane + ws_need(n_units, sizeof(int64_t)));
+        const int64_t tiles = ceil_div((max_frames + 1) * n_ch, 256);
+        ADN_LAUNCH(k_planar_desc, dim3((unsigned)ceil_div(n_units, 256)), dim3(256), 0, c->stream, d_frames, n_blocks,
+                   n_ch, pstride, off2, frames2);
+        ADN_LAUNCH((k_planar_split<T>), dim3((unsigned)(tiles * n_blocks)), dim3(256), 0, c->stream, d_in, P, g, n_ch,
+                   pstride, tiles);
+        BlockGeom g2{off2, frames2, off2, n_units, 0, 0};
+        ADN_TRY(mono_denoise<T>(c, P, Q, g2, max_frames, wavelet, level, ext_mode, thr_mode, d_sigma, d_thresh,
+                                d_zeroed));
+        ADN_LAUNCH((k_planar_join<T>), dim3((unsigned)(tiles * n_blocks)), dim3(256), 0, c->stream, Q, d_out, g, n_ch,
+                   pstride, tiles);
+        ADN_HIP(hipGetLastError());
+        return ADN_OK;
+    }
+    if (ext_mode != ADN_EXT_PERIODIZATION) {
+        set_error("the channel-axis transform of multi-channel blocks is built for periodization only");
+        return ADN_ERR_UNSUPPORTED;
     }
     if (n_ch % 2 != 0 || n_ch > 8) {
         set_error("n_ch = %d: the channel-axis transform needs an even channel count <= 8 "
@@ -739,7 +806,7 @@ int waverec(Ctx *c, const T *d_coeffs, const int64_t *h_band_len, int wavelet, i
 #define ADN_INST(T)                                                                               \
     template int wavelet_denoise<T>(Ctx *, const T *, T *, int64_t, const int64_t *,              \
                                     const int64_t *, const int64_t *, int64_t, int, int, int, int, \
-                                    double *, double *, int64_t *);                               \
+                                    int, int, double *, double *, int64_t *);                     \
     template int wavedec<T>(Ctx *, const T *, int64_t, int, int, int, T *, int64_t, int64_t *);   \
     template int waverec<T>(Ctx *, const T *, const int64_t *, int, int, int, T *, int64_t, int64_t *);
 ADN_INST(float)

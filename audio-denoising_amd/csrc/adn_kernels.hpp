@@ -61,8 +61,8 @@ size_t select_subset_lds_keys(size_t key_bytes);   // lists up to this length ar
 template <typename T>
 int wavelet_denoise(Ctx *c, const T *d_in, T *d_out, int64_t n_blocks, const int64_t *d_in_off,
                     const int64_t *d_frames, const int64_t *d_out_off, int64_t max_frames,
-                    int n_ch, int wavelet, int level, int thr_mode, double *d_sigma,
-                    double *d_thresh, int64_t *d_zeroed);
+                    int n_ch, int axis_mode, int wavelet, int level, int ext_mode, int thr_mode,
+                    double *d_sigma, double *d_thresh, int64_t *d_zeroed);
 template <typename T>
 int wavedec(Ctx *c, const T *d_x, int64_t n, int wavelet, int level, int ext_mode, T *d_coeffs,
             int64_t cap, int64_t *h_band_len);

@@ -44,6 +44,10 @@ enum {
 enum { ADN_WAVELET_DB4 = 0, ADN_WAVELET_DB8 = 1 };
 enum { ADN_EXT_PERIODIZATION = 0, ADN_EXT_SYMMETRIC = 1 };
 enum { ADN_THR_SOFT = 0, ADN_THR_HARD = 1 };
+/* Axis of the wavelet transform of multi-channel blocks.  ADN_AXIS_REFERENCE: what the reference
+ * does (pywt's default axis=-1 on a (frames, channels) block: across the channels of each frame).
+ * ADN_AXIS_TIME: every channel is denoised along time as a mono block of its own. */
+enum { ADN_AXIS_REFERENCE = 0, ADN_AXIS_TIME = 1 };
 
 /* ---------------------------------------------------------------- context */
 const char *adn_last_error(void);
@@ -99,24 +103,31 @@ int64_t adn_istft_out_samples(int64_t n, int n_fft, int hop);
  * d_out[d_out_off[b]] (element offsets).
  *   n_ch == 1 : the transform runs along time; the block comes back with
  *               adn_wavelet_out_frames(frames[b]) samples.
- *   n_ch >= 2 : like the reference (pywt default axis=-1 on a (frames, n_ch)
- *               block) the transform runs ACROSS THE CHANNEL AXIS of every
- *               frame; n_ch must be even and <= 8; output is frames[b]*n_ch.
+ *   n_ch >= 2, axis_mode ADN_AXIS_REFERENCE : like the reference (pywt default
+ *               axis=-1 on a (frames, n_ch) block) the transform runs ACROSS THE
+ *               CHANNEL AXIS of every frame; n_ch must be even and <= 8,
+ *               periodization only; output is frames[b]*n_ch.
+ *   n_ch >= 2, axis_mode ADN_AXIS_TIME : every channel is a mono block of its own
+ *               (own sigma and threshold); output is
+ *               adn_wavelet_out_frames(frames[b]) frames of n_ch samples.
+ * ext_mode: ADN_EXT_PERIODIZATION (the reference's mode='per') or
+ * ADN_EXT_SYMMETRIC (pywt's 'symmetric', level-by-level kernels).
  * d_in_off / d_frames / d_out_off: device arrays of n_blocks int64.
  * max_frames: an upper bound of frames[b] (sizes grids and workspace).
- * d_sigma / d_thresh (n_blocks doubles) and d_zeroed (n_blocks int64: detail
- * coefficients whose magnitude was below the threshold) may be NULL.
+ * d_sigma / d_thresh (doubles) and d_zeroed (int64: detail coefficients whose
+ * magnitude was below the threshold) may be NULL; they hold one value per block,
+ * or per block and channel ([b * n_ch + ch]) under ADN_AXIS_TIME with n_ch >= 2.
  */
 int adn_wavelet_denoise_f32(adn_ctx *ctx, const float *d_in, float *d_out, int64_t n_blocks,
                             const int64_t *d_in_off, const int64_t *d_frames,
-                            const int64_t *d_out_off, int64_t max_frames, int n_ch, int wavelet,
-                            int level, int thr_mode, double *d_sigma, double *d_thresh,
-                            int64_t *d_zeroed);
+                            const int64_t *d_out_off, int64_t max_frames, int n_ch, int axis_mode,
+                            int wavelet, int level, int ext_mode, int thr_mode, double *d_sigma,
+                            double *d_thresh, int64_t *d_zeroed);
 int adn_wavelet_denoise_f64(adn_ctx *ctx, const double *d_in, double *d_out, int64_t n_blocks,
                             const int64_t *d_in_off, const int64_t *d_frames,
-                            const int64_t *d_out_off, int64_t max_frames, int n_ch, int wavelet,
-                            int level, int thr_mode, double *d_sigma, double *d_thresh,
-                            int64_t *d_zeroed);
+                            const int64_t *d_out_off, int64_t max_frames, int n_ch, int axis_mode,
+                            int wavelet, int level, int ext_mode, int thr_mode, double *d_sigma,
+                            double *d_thresh, int64_t *d_zeroed);
 
 /* mad() of denoise.py:16-23 for a batch of segments: d_mad[s] = median(|x - median(x)|)
  * over the len[s] values at d_x[d_off[s]] (numpy semantics: even counts average the two

@@ -199,20 +199,21 @@ def threshold(c, t, mode="soft"):
     raise ValueError(mode)
 
 
-def denoise_block(block, wavelet="db4", level=2, thr_mode="soft", return_bands=False):
+def denoise_block(block, wavelet="db4", level=2, thr_mode="soft", return_bands=False, mode="per"):
     """One iteration of the reference block loop (denoise.py:77-89).
 
     The transform runs along the LAST axis, so a (frames, channels) block is
-    transformed across channels, exactly as the reference does.
+    transformed across channels, exactly as the reference does.  `mode` is the
+    reference's 'per'; 'sym' is pywt's 'symmetric' extension (1-D blocks only).
     Returns (clean, sigma, thresh).
     """
     block = np.asarray(block, dtype=np.float64)
-    coeffs = wavedec(block, wavelet, level, "per")
+    coeffs = wavedec(block, wavelet, level, mode)
     sigma = mad(coeffs[-1])
     with np.errstate(divide="ignore"):
         thresh = sigma * np.sqrt(2 * np.log(len(block)))
     shr = [coeffs[0]] + [threshold(c, thresh, thr_mode) for c in coeffs[1:]]
-    clean = waverec(shr, wavelet, "per")
+    clean = waverec(shr, wavelet, mode)
     if return_bands:
         return clean, sigma, thresh, coeffs
     return clean, sigma, thresh

@@ -1,0 +1,202 @@
+"""GPU parity at the sizes the benchmark and BASELINE.json's configurations use, through the C ABI:
+config 2 (one 60 s 48 kHz stereo clip + 5 s noise through phases 1 / 2 / 2b / 2c, fp32 and fp64),
+config 3's shape (a batch of 144 000-sample mono blocks, db8 level 8), a one-GPU rehearsal of
+config 4 (files sharded over pretend ranks, one shared noise profile), and the denoiser's
+optional modes (symmetric extension, per-channel time axis)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import adn_oracle as orc
+import synth
+from gpu_util import engine, dev, host, check64, check32
+
+pytestmark = pytest.mark.gpu
+SR = 48000
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_config2_full_size_chain(dtype):
+    """60 s stereo clip + 5 s noise, every stage against the oracle on the very input the stage
+    saw on the GPU (for fp32: those binary32 values, widened), so that errors do not compound."""
+    e = engine()
+    dt = torch.float32 if dtype == "f32" else torch.float64
+    chk = check32 if dtype == "f32" else check64
+    n, nn = 60 * SR, 5 * SR
+    x = synth.stereo_noisy_speech(n, SR, 42, 7)
+    noise = synth.white_noise(nn, 42, 100007)
+    xd, nd = dev(x, dt), dev(noise, dt)
+    as64 = lambda t: host(t).astype(np.float64)   # noqa: E731
+
+    # phase 1
+    base = e.noise_psd(nd, [nn])
+    b_or, _ = orc.noise_profile(as64(nd))
+    rel = np.max(np.abs(as64(base[0]) - b_or) / b_or)
+    assert rel <= (3e-6 if dtype == "f32" else 1e-12), rel
+
+    # phase 2 (stereo: the transform runs across the channel axis, like the reference)
+    y2, (sigma, thresh, zeroed) = e.denoise_signal(xd, SR, want_stats=True)
+    y2_or, s_or, t_or = orc.denoise_signal(as64(xd), SR)
+    chk(as64(y2), y2_or)
+    assert np.max(np.abs(host(sigma) - s_or) / s_or) <= (1e-6 if dtype == "f32" else 1e-12)
+    # threshold-boundary flips: coefficients whose |c| < t decision differs from the oracle's
+    d = (as64(xd)[:, 0] - as64(xd)[:, 1]) / np.sqrt(2.0)
+    bs = orc.denoise_block_size(SR, n)
+    z_or = np.array([int(np.sum(np.abs(d[s:s + bs]) < t_or[i])) for i, s in enumerate(range(0, n, bs))])
+    flips = np.abs(host(zeroed) - z_or)
+    print("config 2 %s: zeroed coefficients per block differ from the oracle's by %s (of %d)" % (dtype, flips.tolist(), bs))
+    assert flips.max() <= (bs // 2000 if dtype == "f32" else 0)
+
+    # phase 2b on the GPU's own phase-2 output, with the profile as the stage file holds it (float32)
+    b32 = as64(base[0]).astype(np.float32).astype(np.float64)
+    y2b, l2b = e.spectral_subtract(y2.view(-1), [n], dev(b32, dt), n_ch=2)
+    y2b_or = orc.spectral_subtract(as64(y2), b32)
+    chk(as64(y2b), y2b_or)
+    assert int(l2b[0]) == y2b_or.size == 2877952
+
+    # phase 2c on the GPU's own phase-2b output
+    y2c, l2c, gain = e.wiener(y2b, [int(l2b[0])], SR, want_gain=True)
+    y2c_or, g_or = orc.wiener(as64(y2b), SR)
+    chk(as64(y2c), y2c_or)
+    assert int(l2c[0]) == y2c_or.size == 2875904
+    assert np.max(np.abs(as64(gain[0]) - g_or)) <= (2e-4 if dtype == "f32" else 1e-10)
+
+
+def test_wiener_full_size_batch():
+    """Two 60 s signals in one call: the second equals its single-signal call bit for bit
+    (signals are independent) and the oracle."""
+    e = engine()
+    n = 60 * SR
+    x = e.synth_noisy_speech(2 * n, SR, stream=51).view(2, n)
+    y, lens = e.wiener(x.reshape(-1), [n, n], SR)
+    L = int(lens[0])
+    y1, _ = e.wiener(x[1].contiguous(), [n], SR)
+    assert torch.equal(y1, y[L:2 * L])
+    want, _ = orc.wiener(host(x[1]), SR)
+    check64(host(y1), want)
+
+
+@pytest.mark.parametrize("wavelet,level", [("db8", 8), ("db4", 2)])
+def test_config3_shape_batch(wavelet, level):
+    """256 mono blocks of 144 000 samples (30 s clips at 48 kHz, 10 blocks per clip) in one call,
+    fp32; a handful of blocks checked against the oracle, all of them for finiteness and for the
+    batch-independence property (a block's result does not depend on its neighbours)."""
+    e = engine()
+    nb, bl = 256, 144000
+    gen = 8                                         # distinct blocks; the rest repeat them
+    x = torch.empty(nb * bl, dtype=torch.float32, device="cuda:0")
+    for i in range(gen):
+        x[i * bl:(i + 1) * bl] = e.synth_noisy_speech(bl, SR, stream=600 + i, start=i * bl).float()
+    for i in range(gen, nb):
+        x[i * bl:(i + 1) * bl] = x[(i % gen) * bl:(i % gen + 1) * bl]
+    off = np.arange(nb, dtype=np.int64) * bl
+    out = torch.empty_like(x)
+    sigma, thresh, zeroed = e.wavelet_denoise(x, e._i64(off), e._i64(np.full(nb, bl)), out, e._i64(off),
+                                              wavelet=wavelet, level=level, want_stats=True, max_frames=bl)
+    y = host(out).reshape(nb, bl)
+    assert np.isfinite(y).all()
+    for i in range(gen, nb):                        # copies of a block give copies of its result
+        assert np.array_equal(y[i], y[i % gen]), i
+    xh = host(x[:gen * bl]).reshape(gen, bl).astype(np.float64)
+    tot_flips = 0
+    for i in (0, 3, 7):
+        want, s_or, t_or, bands = orc.denoise_block(xh[i], wavelet, level, return_bands=True)
+        check32(y[i], want)
+        assert abs(float(sigma[i]) - s_or) <= 2e-6 * s_or
+        z_or = sum(int(np.sum(np.abs(b) < t_or)) for b in bands[1:])
+        tot_flips += abs(int(zeroed[i]) - z_or)
+    print("config 3 shape %s level %d: threshold-boundary flips in 3 blocks: %d" % (wavelet, level, tot_flips))
+    assert tot_flips <= 300
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_config4_rehearsal_file_shards(world):
+    """Config 4 on one GPU: 16 mono files sharded round-robin over `world` pretend ranks, the noise
+    profile learnt once on "rank 0" and handed to every shard through the same function the ranks
+    use (its single-process path), phase 2b -> 2c per shard.  The merged outputs equal one call over
+    all files bit for bit, and the oracle for sampled files."""
+    from adn_hip import dist as adist
+    e = engine()
+    n_files, n = 16, 6 * SR
+    lens = [n - 700 * i for i in range(n_files)]                       # ragged, like real files
+    files = [synth.noisy_speech(lens[i], SR, 42, 700 + i).astype(np.float32) for i in range(n_files)]
+    noise = synth.white_noise(5 * SR, 42, 100700).astype(np.float32)
+    prof = e.noise_psd(dev(noise), [noise.size])[0]
+    # one call over all files
+    flat = dev(np.concatenate(files))
+    yb_all, lb_all = e.spectral_subtract(flat, lens, prof)
+    yc_all, lc_all = e.wiener(yb_all, [int(v) for v in lb_all], SR)
+    oc = np.concatenate([[0], np.cumsum(lc_all)])
+    merged = [None] * n_files
+    for rank in range(world):
+        idx = adist.shard_indices(n_files, rank, world)
+        shard_prof = adist.broadcast_profile(prof if rank == 0 else prof.clone(), 1025, src=0)
+        xs = dev(np.concatenate([files[i] for i in idx]))
+        yb, lb = e.spectral_subtract(xs, [lens[i] for i in idx], shard_prof)
+        yc, lc = e.wiener(yb, [int(v) for v in lb], SR)
+        o = np.concatenate([[0], np.cumsum(lc)])
+        for j, i in enumerate(idx):
+            merged[i] = host(yc[o[j]:o[j + 1]])
+    for i in range(n_files):
+        assert np.array_equal(merged[i], host(yc_all[oc[i]:oc[i + 1]])), i
+    p64 = host(prof).astype(np.float64)
+    for i in (0, 5, 15):
+        want_b = orc.spectral_subtract(files[i].astype(np.float64), p64)
+        yb_i, lb_i = e.spectral_subtract(dev(files[i]), [lens[i]], prof)
+        check32(host(yb_i), want_b)
+        want_c, _ = orc.wiener(host(yb_i).astype(np.float64), SR)
+        check32(merged[i], want_c)
+
+
+def test_symmetric_extension_blocks(golden):
+    """mode='symmetric' through the denoiser entry point against PyWavelets' own results."""
+    g = golden("denoise_modes")
+    e = engine()
+    for i, m in enumerate(json.loads(str(g["sym_meta_json"]))):
+        x = g["sym%d_x" % i]
+        for dt, chk in ((torch.float64, check64), (torch.float32, check32)):
+            xd = dev(x, dt)
+            n_out = x.size + (x.size & 1)
+            out = torch.empty(n_out, dtype=dt, device="cuda:0")
+            sigma, thresh, _ = e.wavelet_denoise(xd, e._i64([0]), e._i64([x.size]), out, e._i64([0]),
+                                                 wavelet=m["wavelet"], level=m["level"], thr_mode=m["thr"],
+                                                 mode="sym", want_stats=True, max_frames=x.size)
+            want = g["sym%d_y" % i] if dt == torch.float64 else \
+                orc.denoise_block(host(xd).astype(np.float64), m["wavelet"], m["level"], m["thr"], mode="sym")[0]
+            if m["thr"] == "hard" and dt == torch.float32:
+                continue          # a hard threshold is discontinuous: binary32 flips are not bounded by 1e-4
+            chk(host(out), want)
+            if dt == torch.float64:
+                assert abs(float(sigma[0]) - m["sigma"]) <= 1e-12 and abs(float(thresh[0]) - m["thresh"]) <= 1e-12
+
+
+def test_time_axis_stereo_blocks(golden):
+    """axis='time': every channel of a stereo block is a mono block of its own (the real DWT of a
+    stereo file, which the reference's default axis never gives)."""
+    g = golden("denoise_modes")
+    e = engine()
+    for i, m in enumerate(json.loads(str(g["time_meta_json"]))):
+        x = g["time%d_x" % i]
+        n = x.shape[0]
+        n_out = n + (n & 1)
+        for dt, chk in ((torch.float64, check64), (torch.float32, check32)):
+            xd = dev(x, dt)
+            out = torch.empty(n_out * 2, dtype=dt, device="cuda:0")
+            sigma, thresh, zeroed = e.wavelet_denoise(xd.view(-1), e._i64([0]), e._i64([n]), out, e._i64([0]),
+                                                      n_ch=2, wavelet=m["wavelet"], level=m["level"], axis="time",
+                                                      want_stats=True, max_frames=n)
+            y = host(out).reshape(n_out, 2)
+            if dt == torch.float64:
+                chk(y, g["time%d_y" % i])
+                assert np.max(np.abs(host(sigma) - np.array(m["sigma"]))) <= 1e-12
+            else:
+                xs = host(xd).astype(np.float64)
+                want = np.stack([orc.denoise_block(xs[:, ch], m["wavelet"], m["level"])[0] for ch in range(2)], axis=1)
+                chk(y, want)
+    # whole-file helper: blocks of 10 % of the file, both channels along time
+    x = synth.stereo_noisy_speech(40010, 16000, 42, 410)
+    y = host(e.denoise_signal(dev(x), 16000, axis="time"))
+    want = np.stack([orc.denoise_signal(x[:, ch], 16000)[0] for ch in range(2)], axis=1)
+    check64(y, want)

@@ -154,8 +154,8 @@ def test_core_chain_stereo_fp64(golden):
 def test_large_batch_properties():
     """benchmark-sized signals (60 s at 48 kHz): size-independent properties.  With a zero
     noise profile and beta = 1 the 2b stage is the identity up to the box filter, so with
-    smoothing 1x1 the output equals the input shifted by n_fft/2 (scipy's istft trim); the
-    Wiener stage with unit gain is the same identity."""
+    smoothing 1x1 the output equals the input shifted by n_fft/2 (scipy's istft trim).  (The
+    Wiener stage at this size is covered by test_gpu_fullsize.py.)"""
     e = engine()
     n = 60 * SR
     x = e.synth_noisy_speech(2 * n, SR, stream=50).view(2, n)

@@ -215,7 +215,17 @@ def test_pipeline_v2_manifest_and_logs(tmp_path, capsys):
     assert "[INFO] Phases to run: [1, 2]" in out and "Phases run: 5" in out and "PIPELINE COMPLETE" in out
 
     # explicit list with an invalid entry, a phase whose script is absent, the mastering profile, dry run
-    m = orc_.pipeline_v2_main(["--config", cfg, "--phases", "3,x,6", "--profile", "podcast"], src_dir=src)
+    # a missing script fails the run like the reference's launch of it would ...
+    with pytest.raises(RuntimeError, match="Step failed: stage script not found"):
+        orc_.pipeline_v2_main(["--config", cfg, "--phases", "3,x,6", "--profile", "podcast"], src_dir=src)
+    # ... unless partial installs are allowed: recorded as skipped, manifest written, exit code non-zero
+    os.environ["ADN_ALLOW_MISSING_STAGES"] = "1"
+    try:
+        with pytest.raises(SystemExit, match="mastering_chain.py"):
+            orc_.pipeline_v2_main(["--config", cfg, "--phases", "3,x,6", "--profile", "podcast"], src_dir=src)
+    finally:
+        del os.environ["ADN_ALLOW_MISSING_STAGES"]
+    m = json.loads((tmp_path / "reports" / "run_manifest.json").read_text())
     assert m["phases"]["phase3_hpss"]["status"] == "success"
     assert m["phases"]["phase6_mastering"] == {"status": "skipped", "reason": "script_missing"}
     assert m["configuration"]["phases_requested"] == ["3", "x", "6"]
@@ -223,7 +233,7 @@ def test_pipeline_v2_manifest_and_logs(tmp_path, capsys):
     m = orc_.pipeline_v2_main(["--config", cfg, "--phases", "all", "--dry-run"], src_dir=src)
     assert len(m["phases"]) == 10 and all(r["status"] == "dry-run" for r in m["phases"].values())
     assert m["total_elapsed_sec"] == 0
-    with pytest.raises(RuntimeError, match="Stage script not found"):
+    with pytest.raises(RuntimeError, match="stage script not found"):
         orc_.pipeline_v2_main(["--config", cfg, "--phases", "5", "--strict"], src_dir=src)
     with pytest.raises(RuntimeError, match="Missing required dependencies for phase 4"):
         orc_.pipeline_v2_main(["--config", cfg, "--phases", "4", "--strict"], src_dir=src)

@@ -261,3 +261,19 @@ def test_hpss_matches_reference(golden, tag):
     assert np.max(np.abs(yp - g[tag + "_yp"])) <= 1e-12
     for k, v in c["energy"].items():
         assert abs(met[k] - v) <= 1e-12, k
+
+
+def test_optional_denoiser_modes(golden):
+    """Symmetric extension and the per-channel time-axis transform, against PyWavelets itself
+    (tests/golden/denoise_modes.npz, written by oracle/gen_golden_modes.py)."""
+    g = golden("denoise_modes")
+    for i, m in enumerate(_meta(g, "sym_meta_json")):
+        y, s, t = orc.denoise_block(g["sym%d_x" % i], m["wavelet"], m["level"], m["thr"], mode="sym")
+        _close(y, g["sym%d_y" % i], 1e-12)
+        assert abs(s - m["sigma"]) <= 1e-15 and abs(t - m["thresh"]) <= 1e-14
+    for i, m in enumerate(_meta(g, "time_meta_json")):
+        x = g["time%d_x" % i]
+        for ch in range(2):
+            y, s, _ = orc.denoise_block(x[:, ch], m["wavelet"], m["level"])
+            _close(y, g["time%d_y" % i][:, ch], 1e-12)
+            assert abs(s - m["sigma"][ch]) <= 1e-15
