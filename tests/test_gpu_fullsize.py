@@ -44,7 +44,8 @@ def test_config2_full_size_chain(dtype):
     # threshold-boundary flips: coefficients whose |c| < t decision differs from the oracle's
     d = (as64(xd)[:, 0] - as64(xd)[:, 1]) / np.sqrt(2.0)
     bs = orc.denoise_block_size(SR, n)
-    z_or = np.array([int(np.sum(np.abs(d[s:s + bs]) < t_or[i])) for i, s in enumerate(range(0, n, bs))])
+    # per frame: cD2 is identically zero (always below the threshold) and cD1 = +-(L - R) / sqrt(2)
+    z_or = np.array([bs + int(np.sum(np.abs(d[s:s + bs]) < t_or[i])) for i, s in enumerate(range(0, n, bs))])
     flips = np.abs(host(zeroed) - z_or)
     print("config 2 %s: zeroed coefficients per block differ from the oracle's by %s (of %d)" % (dtype, flips.tolist(), bs))
     assert flips.max() <= (bs // 2000 if dtype == "f32" else 0)
