@@ -14,6 +14,7 @@ WAVELET = {"db4": 0, "db8": 1}
 EXT = {"per": 0, "periodization": 0, "sym": 1, "symmetric": 1}
 THR = {"soft": 0, "hard": 1}
 AXIS = {"reference": 0, "time": 1}
+NOALLOC_SCRATCH_BYTES = 32 << 20
 MASK = {"soft": 0, "hard": 1, "binary": 2}
 
 _vp, _i, _i64, _d, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_uint64
@@ -29,6 +30,8 @@ _PLAIN = {
     "adn_set_option": (_i, [_vp, _i, _i]),
     "adn_workspace_bytes": (_i64, [_vp]),
     "adn_kernel_times": (_i64, [_vp, C.c_char_p, _i64]),
+    "adn_wavelet_denoise_noalloc_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i,
+                                             _vp, _vp, _vp]),
     "adn_wavelet_out_frames": (_i64, [_i64]),
     "adn_denoise_block_frames": (_i64, [_i64, _i64]),
     "adn_stft_num_frames": (_i64, [_i64, _i, _i, _i]),

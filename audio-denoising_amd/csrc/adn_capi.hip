@@ -17,12 +17,12 @@ void set_error(const char *fmt, ...) {
 }
 
 int aux_reserve(Ctx *c, size_t bytes) {
-    if (bytes <= c->aux_bytes) return ADN_OK;
-    if (c->ws_fixed) {
+    if (c->ws_fixed) {      // also when an earlier ordinary call left a large enough buffer: same answer every time
         set_error("this mode needs %zu bytes of device memory beyond the fixed scratch buffer; "
                   "the entry point that allocates nothing does not support it", bytes);
         return ADN_ERR_NOMEM;
     }
+    if (bytes <= c->aux_bytes) return ADN_OK;
     if (c->aux) {
         ADN_HIP(hipStreamSynchronize(c->stream));
         ADN_HIP(hipFree(c->aux));
@@ -103,6 +103,11 @@ static int mad_impl(adn_ctx *c, const T *d_x, int64_t n_seg, const int64_t *d_of
 
 using adn::Ctx;
 
+// Scratch of the entry point that allocates nothing: one copy per GPU, alive until the process
+// ends.  In host code this name is only a handle for hipGetSymbolAddress; the device address of
+// each GPU's copy is looked up once in adn_create and kept in the context (Ctx::scratch).
+static __device__ __align__(256) unsigned char scratch[ADN_NOALLOC_SCRATCH_BYTES];
+
 extern "C" {
 
 const char *adn_last_error(void) { return adn::g_err; }
@@ -121,9 +126,12 @@ int adn_create(adn_ctx **out, int device) {
         adn::set_error("device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
         return ADN_ERR_UNSUPPORTED;
     }
+    void *scratch_dev = nullptr;          // this device is current (DeviceGuard above)
+    ADN_HIP(hipGetSymbolAddress(&scratch_dev, HIP_SYMBOL(scratch)));
     adn_ctx *c = new adn_ctx();
     c->device = device;
     c->num_cus = prop.multiProcessorCount;
+    c->scratch = static_cast<char *>(scratch_dev);
     *out = c;
     return ADN_OK;
 }
@@ -309,5 +317,29 @@ int64_t adn_istft_out_samples(int64_t n, int n_fft, int hop) {
 
 ADN_WRAP_T(f32, float)
 ADN_WRAP_T(f64, double)
+
+int adn_wavelet_denoise_noalloc_f32(adn_ctx *c, const float *d_in, float *d_out, int64_t n_blocks,
+                                    const int64_t *d_in_off, const int64_t *d_frames,
+                                    const int64_t *d_out_off, int64_t max_frames, int n_ch, int axis_mode,
+                                    int wavelet, int level, int ext_mode, int thr_mode, double *d_sigma,
+                                    double *d_thresh, int64_t *d_zeroed) {
+    ADN_REQUIRE(c != nullptr, "ctx is null");
+    ADN_REQUIRE(c->scratch != nullptr, "the static scratch buffer was not resolved for device %d", c->device);
+    // the same kernels as adn_wavelet_denoise_f32, their workspace carved from this GPU's static
+    // scratch instead of the growable allocation; requests beyond it fail in ws_reserve / aux_reserve
+    char *const ws = c->ws;
+    const size_t ws_bytes = c->ws_bytes;
+    const bool ws_fixed = c->ws_fixed;
+    c->ws = c->scratch;
+    c->ws_bytes = ADN_NOALLOC_SCRATCH_BYTES;
+    c->ws_fixed = true;
+    const int rc = adn::wavelet_denoise<float>(c, d_in, d_out, n_blocks, d_in_off, d_frames, d_out_off, max_frames,
+                                               n_ch, axis_mode, wavelet, level, ext_mode, thr_mode, d_sigma,
+                                               d_thresh, d_zeroed);
+    c->ws = ws;
+    c->ws_bytes = ws_bytes;
+    c->ws_fixed = ws_fixed;
+    return rc;
+}
 
 }  // extern "C"

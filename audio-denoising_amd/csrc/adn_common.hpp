@@ -60,6 +60,7 @@ struct Ctx {
     size_t ws_bytes = 0;
     size_t ws_used = 0;        // bump pointer, reset per call
     bool ws_fixed = false;     // the workspace is a caller-independent fixed buffer: never grow, never allocate
+    char *scratch = nullptr;   // this device's copy of the library's static scratch array (set by adn_create)
     char *aux = nullptr;       // second growable buffer (planar copies of the time-axis multi-channel mode)
     size_t aux_bytes = 0;
     int num_cus = 256;
@@ -77,7 +78,7 @@ struct KScope {
     Ctx *c;
     int idx = -1;
     KScope(Ctx *ctx, const char *name) : c(ctx) {
-        if (!c->ktime) return;
+        if (!c->ktime || c->ws_fixed) return;      // creating events allocates: never on the path that allocates nothing
         KernelRec r{name, nullptr, nullptr};
         if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
         (void)hipEventRecord(r.start, c->stream);

@@ -129,6 +129,25 @@ int adn_wavelet_denoise_f64(adn_ctx *ctx, const double *d_in, double *d_out, int
                             int wavelet, int level, int ext_mode, int thr_mode, double *d_sigma,
                             double *d_thresh, int64_t *d_zeroed);
 
+/* adn_wavelet_denoise_f32 for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
+ * reference.  Same arguments, same kernels, same results; the kernels' workspace (finest-band
+ * coefficients, candidate lists and counters of the threshold statistics) lives in a static
+ * device array of ADN_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the
+ * process ends.  The call makes no hipMalloc / hipFree and no other allocating call; a batch whose
+ * kernels need more scratch than that is rejected with ADN_ERR_NOMEM (the message states both
+ * byte counts), and so is ADN_AXIS_TIME with n_ch >= 2 (its planar copies need a second buffer).
+ * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two
+ * contexts, two streams) race; calls on one stream are safe.  Every call initialises what it
+ * reads, so nothing of an earlier call's contents leaks into a later one.  Kernel timing
+ * (ADN_OPT_KERNEL_TIMING) is not recorded for this entry point. */
+#define ADN_NOALLOC_SCRATCH_BYTES (32u << 20)
+int adn_wavelet_denoise_noalloc_f32(adn_ctx *ctx, const float *d_in, float *d_out, int64_t n_blocks,
+                                    const int64_t *d_in_off, const int64_t *d_frames,
+                                    const int64_t *d_out_off, int64_t max_frames, int n_ch,
+                                    int axis_mode, int wavelet, int level, int ext_mode, int thr_mode,
+                                    double *d_sigma, double *d_thresh, int64_t *d_zeroed);
+
 /* mad() of denoise.py:16-23 for a batch of segments: d_mad[s] = median(|x - median(x)|)
  * over the len[s] values at d_x[d_off[s]] (numpy semantics: even counts average the two
  * middle order statistics; no 0.6745 factor).  d_median (may be NULL) receives the medians.
