@@ -16,7 +16,14 @@
 namespace adn {
 namespace fast {
 
-typedef float2 c2;
+// A complex value is a native two-float vector, so that it occupies an aligned register pair and
+// the packed binary32 instructions (two lanes of the pair per instruction) apply to it directly.
+// Component swaps and sign changes of complex arithmetic (multiplication by +-i, the cross terms
+// of a complex product) are expressed with the instructions' own operand modifiers (op_sel picks
+// the half of a source each result half reads, neg_lo / neg_hi negate it), which costs nothing;
+// written as plain component arithmetic the same operations compile to separate moves.
+typedef float c2 __attribute__((ext_vector_type(2)));
+static_assert(sizeof(c2) == sizeof(float2), "c2 is layout-compatible with float2");
 static constexpr int NC = 1024;     // complex points per frame
 static constexpr int RS = 68;       // exchange row stride (float2): 64 + 4 keeps quads on distinct banks
 static constexpr int WBUF = 1088;   // float2 per wave buffer: 16 * RS >= padded natural image + 1
@@ -29,33 +36,91 @@ static constexpr int RAWPAD = 8;    // replicated bins kept beyond each end of a
 __device__ __forceinline__ int nat(int k) { return k + ((k >> 8) << 3); }        // float2 index
 __device__ __forceinline__ int natf(int s) { return s + ((s >> 9) << 4); }       // float index of sample s
 
-__device__ __forceinline__ c2 operator+(c2 a, c2 b) { return c2{a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ c2 operator-(c2 a, c2 b) { return c2{a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ c2 mul(c2 a, c2 b) { return c2{a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
-__device__ __forceinline__ c2 mulc(c2 a, c2 b) { return c2{a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y}; }
+__device__ __forceinline__ const c2 *as_c2(const float2 *p) { return reinterpret_cast<const c2 *>(p); }
+
+// a + (-i) b  (forward transforms: INV = false)  or  a + i b  (inverse)
+template <bool INV>
+__device__ __forceinline__ c2 add_rot(c2 a, c2 b) {
+    c2 r;
+    if (INV) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// a - (-i) b  (INV = false)  or  a - i b  (INV = true)
+template <bool INV>
+__device__ __forceinline__ c2 sub_rot(c2 a, c2 b) { return add_rot<!INV>(a, b); }
+
+// complex products: two packed instructions each
+__device__ __forceinline__ c2 mul(c2 v, c2 w) {            // v * w
+    c2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(v), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(v), "v"(w), "v"(t));
+    return r;
+}
+__device__ __forceinline__ c2 mulc(c2 v, c2 w) {           // v * conj(w)
+    c2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(t) : "v"(v), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(v), "v"(w), "v"(t));
+    return r;
+}
+// the same with the second factor in a scalar register pair (compile-time constants)
+__device__ __forceinline__ c2 mul_k(c2 v, c2 w) {
+    c2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]" : "=v"(t) : "v"(v), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(v), "s"(w), "v"(t));
+    return r;
+}
+__device__ __forceinline__ c2 mulc_k(c2 v, c2 w) {
+    c2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(t) : "v"(v), "s"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(v), "s"(w), "v"(t));
+    return r;
+}
+// (a.x + b.x, a.y - b.y)  and  (a.y + b.y, b.x - a.x): the even / odd parts of a real-signal spectrum pair
+__device__ __forceinline__ c2 add_conj(c2 a, c2 b) {
+    c2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ c2 odd_part(c2 a, c2 b) {
+    c2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// (a.x + b.y, b.x - a.y) = conj(a - i b)
+__device__ __forceinline__ c2 conj_sub_rot(c2 a, c2 b) {
+    c2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float norm2(c2 z) { return z.x * z.x + z.y * z.y; }
 
 // v * W16^M (forward) or its conjugate (inverse)
 template <int M, bool INV>
 __device__ __forceinline__ c2 mul_w16(c2 v) {
     constexpr float C1 = 0.9238795325112867f, S1 = 0.3826834323650898f, R = 0.7071067811865476f;
     if (M == 0) return v;
-    if (M == 4) return INV ? c2{-v.y, v.x} : c2{v.y, -v.x};
-    if (M == 2) return INV ? c2{(v.x - v.y) * R, (v.x + v.y) * R} : c2{(v.x + v.y) * R, (v.y - v.x) * R};
-    if (M == 6) return INV ? c2{-(v.x + v.y) * R, (v.x - v.y) * R} : c2{(v.y - v.x) * R, -(v.x + v.y) * R};
+    if (M == 4) {                                          // -i v  /  i v
+        c2 r;
+        if (INV) asm("v_pk_add_f32 %0, %1, 0 op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(r) : "v"(v));
+        else asm("v_pk_add_f32 %0, %1, 0 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(v));
+        return r;
+    }
+    if (M == 2) return add_rot<INV>(v, v) * R;             // (x + y, y - x) R  /  (x - y, x + y) R
+    if (M == 6) return add_rot<!INV>(v, v) * (-R);         // (y - x, -x - y) R  /  (-x - y, x - y) R
     // generic: W = (c, -s) forward
     constexpr float c = M == 1 ? C1 : (M == 3 ? S1 : -C1);     // M in {1, 3, 9}
-    constexpr float s = M == 1 ? S1 : (M == 3 ? C1 : -S1);
-    return INV ? c2{v.x * c - v.y * s, v.y * c + v.x * s} : c2{v.x * c + v.y * s, v.y * c - v.x * s};
+    constexpr float sn = M == 1 ? S1 : (M == 3 ? C1 : -S1);
+    return INV ? mulc_k(v, c2{c, -sn}) : mul_k(v, c2{c, -sn});
 }
 
 template <bool INV>
 __device__ __forceinline__ void bfly4(c2 &a0, c2 &a1, c2 &a2, c2 &a3) {
     const c2 s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
-    const c2 id = INV ? c2{-d13.y, d13.x} : c2{d13.y, -d13.x};
     a0 = s02 + s13;
-    a1 = d02 + id;
+    a1 = add_rot<INV>(d02, d13);
     a2 = s02 - s13;
-    a3 = d02 - id;
+    a3 = sub_rot<INV>(d02, d13);
 }
 
 // 16-point DFT in registers.  Input r[n]; output X[k] at r[P16(k)].
@@ -100,7 +165,7 @@ __device__ __forceinline__ c2 w1024(const c2 *__restrict__ tw, int k) {
 
 // Cooperative fill by the whole workgroup from the precomputed image (16-byte copies, the table
 // offset inside the blob is 16-byte aligned); the caller synchronises before first use.
-__device__ __forceinline__ void fill_tw_table(c2 *tab, const c2 *__restrict__ image, int tid, int nthreads) {
+__device__ __forceinline__ void fill_tw_table(c2 *tab, const float2 *__restrict__ image, int tid, int nthreads) {
     const float4 *src = reinterpret_cast<const float4 *>(image);
     float4 *dst = reinterpret_cast<float4 *>(tab);
     for (int i = tid; i < TWTAB / 2; i += nthreads) dst[i] = src[i];
@@ -249,16 +314,19 @@ struct Spec {
 };
 
 __device__ __forceinline__ void split_spectrum(Spec &s, const c2 *buf, const c2 (&rtw)[8], float scale, int lane) {
+    // Z[k] = E[k] + W^k O[k] with E = (z[k] + conj(z[N-k])) / 2, O = -i (z[k] - conj(z[N-k])) / 2;
+    // the halves are folded into the scale
+    const float hs = 0.5f * scale;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int k = lane + 64 * j;
         const c2 zk = buf[nat(k)];
         const c2 zm = buf[nat((1024 - k) & 1023)];
-        const c2 e = c2{(zk.x + zm.x) * 0.5f, (zk.y - zm.y) * 0.5f};
-        const c2 o = c2{(zk.y + zm.y) * 0.5f, (zm.x - zk.x) * 0.5f};
-        const c2 wo = mul(rtw[j], o);
-        s.lo[j] = c2{(e.x + wo.x) * scale, (e.y + wo.y) * scale};
-        s.hi[j] = c2{(e.x - wo.x) * scale, -(e.y - wo.y) * scale};
+        const c2 e = add_conj(zk, zm);                     // (zk.x + zm.x, zk.y - zm.y)
+        const c2 o = odd_part(zk, zm);                     // (zk.y + zm.y, zm.x - zk.x)
+        const c2 wo = mul(o, rtw[j]);
+        s.lo[j] = (e + wo) * hs;
+        s.hi[j] = (e - wo) * c2{hs, -hs};                  // conjugated
         if (j == 0 && lane == 0) {
             s.lo[0] = c2{(zk.x + zk.y) * scale, 0.0f};
             s.hi[0] = c2{(zk.x - zk.y) * scale, 0.0f};
@@ -277,17 +345,18 @@ __device__ __forceinline__ void merge_spectrum(const Spec &s, c2 *buf, const c2 
         if (j == 0 && lane == 0) {
             buf[0] = c2{(xk.x + xm.x) * 0.5f, (xk.x - xm.x) * 0.5f};
         } else {
-            const c2 e = c2{(xk.x + xm.x) * 0.5f, (xk.y - xm.y) * 0.5f};
-            const c2 d = c2{(xk.x - xm.x) * 0.5f, (xk.y + xm.y) * 0.5f};
-            const c2 o = mulc(d, rtw[j]);
-            buf[nat(k)] = c2{e.x - o.y, e.y + o.x};
-            buf[nat(1024 - k)] = c2{e.x + o.y, -(e.y - o.x)};
+            const c2 e = add_conj(xk, xm) * 0.5f;          // ((xk.x + xm.x) / 2, (xk.y - xm.y) / 2)
+            c2 d;                                          // ((xk.x - xm.x) / 2, (xk.y + xm.y) / 2)
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(d) : "v"(xk), "v"(xm));
+            const c2 o = mulc(d * 0.5f, rtw[j]);
+            buf[nat(k)] = add_rot<true>(e, o);             // e + i o = (e.x - o.y, e.y + o.x)
+            buf[nat(1024 - k)] = conj_sub_rot(e, o);       // conj(e - i o) = (e.x + o.y, o.x - e.y)
         }
     }
     if (lane == 0) buf[nat(512)] = c2{s.mid.x, -s.mid.y};
 }
 
-__device__ __forceinline__ void load_rtw(c2 (&rtw)[8], const c2 *__restrict__ tab, int lane) {
+__device__ __forceinline__ void load_rtw(c2 (&rtw)[8], const c2 *tab, int lane) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) rtw[j] = tab[lane + 64 * j];
 }
@@ -319,7 +388,7 @@ __global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ 
     __syncthreads();
     const LaneTw tw = lane_tw(twtab, lane);
     c2 rtw[8];
-    load_rtw(rtw, tb.rtw, lane);
+    load_rtw(rtw, as_c2(tb.rtw), lane);
     const float scale = (float)(1.0 / tb.wsum);
     const int ts = FT + 1;
     float vmax = 0.0f;
@@ -441,7 +510,7 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
     fill_tw_table(twtab, tb.fast_tw, tid, W * 64);
     const LaneTw tw = lane_tw(twtab, lane);
     c2 rtw[8];
-    load_rtw(rtw, tb.rtw, lane);
+    load_rtw(rtw, as_c2(tb.rtw), lane);
 
     for (int i = tid; i < 2048; i += W * 64) wtab[i] = tb.window[i];
     for (int i = tid; i < RING * H; i += W * 64) acc[i] = 0.0f;
@@ -829,6 +898,342 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
         for (int i = 0; i < 12; ++i) atomicAdd(&a.dbg[i], ph[i]);
 }
 
+// ------------------------------------ fused STFT -> modify -> ISTFT, one wave per run of hops
+// hop 512, four-fold overlap.  A wave owns a run of consecutive output hops of one signal and
+// walks its frames one after another, alone: no workgroup barrier after the tables are staged,
+// so the waves of a SIMD drift apart and one wave's LDS / memory round trips are covered by the
+// other's arithmetic.
+//   * overlap-add: the inverse transform leaves the four hop-quarters of a frame at the same
+//     in-hop positions of a lane (r[4 cc + d], d = quarter), so the three partial hops are
+//     twelve complex registers per lane and a finished hop leaves in four 8-byte stores; no
+//     accumulator ring in LDS, no pass over it.
+//   * SUBTRACT smooths over the two neighbouring frames: the frequency-smoothed magnitudes of a
+//     lane's own 17 bins stay in registers (the sum of the two previous rows and the previous
+//     row), and the spectrum of the newest frame, whose right neighbour is not known yet, is
+//     swapped with the one parked in the wave's LDS slot.
+//   * GAIN keeps the signal's gain row in the wave's LDS slot (per-frame gain rows are read from
+//     memory).
+// Everything that does not change from frame to frame and is not needed in every instruction
+// (real-FFT split factors, overlap norm, window) is read from LDS tables rather than held in
+// registers: the transform itself needs most of the 256 registers two waves per SIMD leave a wave.
+
+static constexpr int GROW = 1032;                 // floats of a wave's gain row slot (1025 used)
+
+template <int W, int MODE>
+__global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_apply_wave(ApplyArgs<float> a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int H = 512;
+    constexpr int SLOT = MODE == APPLY_SUBTRACT ? PARK : GROW / 2;                   // float2 per wave beside the exchange buffer
+    const Tables<float> &tb = a.tb;
+    c2 *bufs = reinterpret_cast<c2 *>(smem);                                          // [W][WBUF] exchange
+    c2 *slots = bufs + (size_t)W * WBUF;                                              // [W][SLOT] parked spectrum / gain row
+    c2 *twtab = slots + (size_t)W * SLOT;
+    c2 *rtab = twtab + TWTAB;                                                         // [512] real-FFT split factors
+    float *wtab = reinterpret_cast<float *>(rtab + 512);                              // [2048] window
+    float *ntab = wtab + 2048;                                                        // [512] scale / full-overlap norm
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
+    fill_tw_table(twtab, tb.fast_tw, tid, W * 64);
+    for (int i = tid; i < 512; i += W * 64) rtab[i] = as_c2(tb.rtw)[i];
+    for (int i = tid; i < 2048; i += W * 64) wtab[i] = tb.window[i];
+    const float fscale = (float)(1.0 / tb.wsum);
+    const float iscale = (float)(tb.wsum / 1024.0);
+    for (int i = tid; i < 512; i += W * 64) {
+        float sq = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float w = tb.window[i + q * H];
+            sq += w * w;
+        }
+        ntab[i] = iscale / (sq > 1e-10f ? sq : 1.0f);
+    }
+    __syncthreads();                                       // the only workgroup barrier: every wave reaches it
+
+    const int64_t gid = (int64_t)blockIdx.x * W + wave;
+    const int64_t sig = gid / a.segs_per_sig;
+    const int run = (int)(gid % a.segs_per_sig);
+    if (sig >= a.n_sig) return;
+    const int64_t n = a.sg.len[sig];
+    const int Tn = (int)stft_frames(n, 2048, H, 1);        // frame / hop indices of one signal fit 32 bits
+    // output hops are the padded hops j = 2 .. Tn (istft drops n_fft/2 at both ends); hop j is
+    // complete once frame min(j, Tn - 1) has been added
+    const int ja = 2 + run * a.seg_hops;
+    if (Tn < 2 || ja > Tn) return;
+    const int jb = (ja + a.seg_hops < Tn + 1) ? ja + a.seg_hops : Tn + 1;            // exclusive
+    const int ta = ja - 3 < 0 ? 0 : ja - 3;                // first frame synthesised (fills the partial hops)
+    const int tb_ = jb - 1 < Tn - 1 ? jb - 1 : Tn - 1;     // last frame synthesised
+    const float *xs = a.x + a.sg.off[sig];
+    float *ys = a.y + a.y_off[sig];
+    int16_t *ps = a.pcm ? a.pcm + a.y_off[sig] : nullptr;
+    const float *row = a.row + sig * a.row_stride;
+    c2 *buf = bufs + wave * WBUF;
+    float *bufr = reinterpret_cast<float *>(buf);
+    c2 *park = slots + wave * SLOT;
+    float *grow_lds = reinterpret_cast<float *>(park);
+    const LaneTw tw = lane_tw(twtab, lane);
+    const c2 *wv = reinterpret_cast<const c2 *>(wtab);
+    const c2 *nv = reinterpret_cast<const c2 *>(ntab);
+    const int mlane = (lane & 15) + 64 * (lane >> 4);      // packed point of r[4 cc + d] is mlane + 16 cc + 256 d
+    const bool y_vec = (reinterpret_cast<uintptr_t>(ys) & 7) == 0;
+    const bool p_vec = (reinterpret_cast<uintptr_t>(ps) & 3) == 0;
+    const bool gain_in_lds = MODE == APPLY_GAIN && a.row_t_stride == 0;
+    if (gain_in_lds) {
+        for (int k = lane; k <= 1024; k += 64) grow_lds[k] = row[k];
+        wave_sync();
+    }
+
+    // one finished hop: normalise, clip, optional PCM16, store
+    auto emit = [&](int j, const c2 (&v)[4]) {
+        const bool full = j >= 3 && j <= Tn - 1;
+        const int64_t base = (int64_t)(j - 2) * H;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int i = 2 * (mlane + 16 * cc);           // sample of the hop (and i + 1)
+            c2 o;
+            if (full) {
+                const c2 q = nv[mlane + 16 * cc];
+                o = c2{v[cc].x * q.x, v[cc].y * q.y};
+            } else {
+                float nx_ = 0.0f, ny_ = 0.0f;
+                int t_lo = j - 3;
+                t_lo = t_lo < 0 ? 0 : t_lo;
+                const int t_hi = j < Tn - 1 ? j : Tn - 1;
+#pragma unroll 1
+                for (int tt = t_lo; tt <= t_hi; ++tt) {
+                    const float w0 = wtab[(j - tt) * H + i], w1 = wtab[(j - tt) * H + i + 1];
+                    nx_ += w0 * w0;
+                    ny_ += w1 * w1;
+                }
+                o = c2{v[cc].x * iscale / (nx_ > 1e-10f ? nx_ : 1.0f), v[cc].y * iscale / (ny_ > 1e-10f ? ny_ : 1.0f)};
+            }
+            if (!a.no_clip) {
+                o.x = o.x < -1.0f ? -1.0f : (o.x > 1.0f ? 1.0f : o.x);
+                o.y = o.y < -1.0f ? -1.0f : (o.y > 1.0f ? 1.0f : o.y);
+            }
+            if (ps) {
+                const int k0 = pcm_int32(o.x) >> 16, k1 = pcm_int32(o.y) >> 16;
+                int16_t *pp = ps + base + i;
+                if (p_vec) {
+                    *reinterpret_cast<unsigned *>(pp) = (unsigned)(k0 & 0xFFFF) | ((unsigned)k1 << 16);
+                } else {
+                    pp[0] = (int16_t)k0;
+                    pp[1] = (int16_t)k1;
+                }
+                o = c2{(float)k0 * (1.0f / 32768.0f), (float)k1 * (1.0f / 32768.0f)};
+            }
+            float *yp = ys + base + i;
+            if (y_vec) {
+                *reinterpret_cast<c2 *>(yp) = o;
+            } else {
+                yp[0] = o.x;
+                yp[1] = o.y;
+            }
+        }
+    };
+
+    // frames analysed: SUBTRACT also needs the magnitude rows of the frames around [ta, tb_]
+    const int u0 = MODE == APPLY_SUBTRACT ? (ta > 0 ? ta - 1 : 0) : ta;
+    const int u1 = MODE == APPLY_SUBTRACT ? (tb_ + 1 < Tn - 1 ? tb_ + 1 : Tn - 1) : tb_;
+    c2 acc0[4], acc1[4], acc2[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) acc0[cc] = acc1[cc] = acc2[cc] = c2{0.0f, 0.0f};
+    // SUBTRACT: frequency-smoothed magnitude rows at the lane's bins (lo: k = lane + 64 j, hi: 1024 - k, mid: 512)
+    float m1_lo[8], m1_hi[8], m1_mid = 0.0f;               // row of the previous frame
+    float s2_lo[8], s2_hi[8], s2_mid = 0.0f;               // sum of the rows of the two previous frames
+    const int s_end = MODE == APPLY_SUBTRACT ? tb_ + 1 : tb_;
+
+#pragma unroll 1
+    for (int s = u0; s <= s_end; ++s) {
+        Spec sp;
+        const bool analyse = s <= u1;
+        if (analyse) {
+            // ---- frame s: load, window, forward transform, real-signal spectrum
+            c2 r[16];
+            load_frame(r, buf, xs, n, a.sg.n_ch, (int64_t)s * H, wtab, lane);
+            wave_fft1024<false>(r, buf, tw, lane);
+            store_natural(r, buf, lane);
+            wave_sync();
+            c2 rtw[8];
+            load_rtw(rtw, rtab, lane);
+            split_spectrum(sp, buf, rtw, fscale, lane);
+            wave_sync();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        int t = s;                                          // frame synthesised in this step
+        if (MODE == APPLY_SUBTRACT) {
+            float mc_lo[8], mc_hi[8], mc_mid;
+            if (analyse) {
+                // clean magnitudes of the lane's bins -> raw row in the wave's buffer (RAWPAD spare
+                // bins at both ends for the box filter's edge replication)
+                float *rawm = bufr + RAWPAD;
+                {
+                    const float *nlo = row + lane, *nhi = row + 1024 - lane;      // one address each, constant offsets
+                    float *wlo = rawm + lane, *whi = rawm + 1024 - lane;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float m0 = __builtin_amdgcn_sqrtf(norm2(sp.lo[j]));
+                        const float m1 = __builtin_amdgcn_sqrtf(norm2(sp.hi[j]));
+                        wlo[64 * j] = fmaxf(m0 - a.alpha * nlo[64 * j], a.beta * m0);
+                        whi[-64 * j] = fmaxf(m1 - a.alpha * nhi[-64 * j], a.beta * m1);
+                    }
+                }
+                if (lane == 0) {
+                    const float mm = __builtin_amdgcn_sqrtf(norm2(sp.mid));
+                    rawm[512] = fmaxf(mm - a.alpha * row[512], a.beta * mm);
+                }
+                // park the new spectrum, take the previous frame's
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const c2 plo = park[j * 64 + lane], phi = park[(8 + j) * 64 + lane];
+                    park[j * 64 + lane] = sp.lo[j];
+                    park[(8 + j) * 64 + lane] = sp.hi[j];
+                    sp.lo[j] = plo;
+                    sp.hi[j] = phi;
+                }
+                const c2 pm = park[1024];
+                wave_sync();
+                if (lane == 0) park[1024] = sp.mid;
+                sp.mid = pm;
+                if (lane < RAWPAD) {
+                    rawm[-1 - lane] = rawm[0];
+                    rawm[1025 + lane] = rawm[1024];
+                }
+                wave_sync();
+                __builtin_amdgcn_sched_barrier(0);
+                // box mean over five bins (the only frequency smoothing this kernel is launched for);
+                // same summation order as the shape-generic kernel
+                const float inv_sf = 1.0f / 5.0f;
+                const float *blo = rawm + lane, *bhi = rawm + 1024 - lane;
+                auto box = [&](const float *p) {
+                    float rv[5];
+#pragma unroll
+                    for (int d = 0; d < 5; ++d) rv[d] = p[d - 2];
+                    float fs = 0.0f;
+#pragma unroll
+                    for (int d = 0; d < 5; ++d) fs += rv[d];
+                    return fs * inv_sf;
+                };
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    mc_lo[j] = box(blo + 64 * j);
+                    mc_hi[j] = box(bhi - 64 * j);
+                    if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // at most 40 row values in flight
+                }
+                mc_mid = box(rawm + 512);
+                wave_sync();                                // the row has been read: the buffer is free again
+            } else {
+                // s == Tn: the row beyond the last frame is the last frame's (edge replication); its
+                // spectrum is the parked one
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    mc_lo[j] = m1_lo[j];
+                    mc_hi[j] = m1_hi[j];
+                    sp.lo[j] = park[j * 64 + lane];
+                    sp.hi[j] = park[(8 + j) * 64 + lane];
+                }
+                mc_mid = m1_mid;
+                sp.mid = park[1024];
+            }
+            if (s == u0) {                                  // the row before the first one: replicated if frame 0, unused otherwise
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    m1_lo[j] = mc_lo[j];
+                    m1_hi[j] = mc_hi[j];
+                    s2_lo[j] = s2_hi[j] = 0.0f;
+                }
+                m1_mid = mc_mid;
+                s2_mid = 0.0f;
+            }
+            t = s - 1;
+            if (t >= ta) {
+                // smoothed magnitude of frame t = (row[t-1] + row[t] + row[t+1]) / 3, phase of its spectrum kept:
+                // clean * exp(i angle(Z)) = clean * Z / |Z|, and angle(0) = 0
+                const float inv_st = 1.0f / (float)FAST_ST;
+                auto rephase = [&](c2 z, float sm) {
+                    const float p2 = norm2(z);
+                    const float g = sm * __builtin_amdgcn_rsqf(p2);
+                    return p2 > 0.0f ? z * g : c2{sm, 0.0f};
+                };
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    sp.lo[j] = rephase(sp.lo[j], (s2_lo[j] + mc_lo[j]) * inv_st);
+                    sp.hi[j] = rephase(sp.hi[j], (s2_hi[j] + mc_hi[j]) * inv_st);
+                }
+                sp.mid = rephase(sp.mid, (s2_mid + mc_mid) * inv_st);
+            }
+            // rows for the next step: s2 = row[s-1] + row[s], m1 = row[s]
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s2_lo[j] = m1_lo[j] + mc_lo[j];
+                s2_hi[j] = m1_hi[j] + mc_hi[j];
+                m1_lo[j] = mc_lo[j];
+                m1_hi[j] = mc_hi[j];
+            }
+            s2_mid = m1_mid + mc_mid;
+            m1_mid = mc_mid;
+        } else {
+            if (gain_in_lds) {
+                const float *glo = grow_lds + lane, *ghi = grow_lds + 1024 - lane;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float g0v = glo[64 * j], g1v = ghi[-64 * j];
+                    sp.lo[j] = c2{sp.lo[j].x * g0v, sp.lo[j].y * g0v};
+                    sp.hi[j] = c2{sp.hi[j].x * g1v, sp.hi[j].y * g1v};
+                }
+                const float gmv = grow_lds[512];
+                sp.mid = c2{sp.mid.x * gmv, sp.mid.y * gmv};
+            } else {
+                const float *grow = row + (int64_t)t * a.row_t_stride;     // per-frame gain rows (masks)
+                const float *glo = grow + lane, *ghi = grow + 1024 - lane;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float g0v = glo[64 * j], g1v = ghi[-64 * j];
+                    sp.lo[j] = c2{sp.lo[j].x * g0v, sp.lo[j].y * g0v};
+                    sp.hi[j] = c2{sp.hi[j].x * g1v, sp.hi[j].y * g1v};
+                }
+                const float gmv = grow[512];
+                sp.mid = c2{sp.mid.x * gmv, sp.mid.y * gmv};
+            }
+        }
+        if (t < ta) continue;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- frame t: back to the packed spectrum, inverse transform, synthesis window, overlap-add
+        {
+            c2 rtw[8];
+            load_rtw(rtw, rtab, lane);
+            merge_spectrum(sp, buf, rtw, lane);
+        }
+        wave_sync();
+        c2 r[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) r[j] = buf[nat(lane + 64 * j)];
+        wave_sync();
+        wave_fft1024<true>(r, buf, tw, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        c2 out[4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            c2 q[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const c2 w = wv[mlane + 16 * cc + 256 * d];
+                q[d] = c2{r[4 * cc + d].x * w.x, r[4 * cc + d].y * w.y};
+            }
+            out[cc] = acc0[cc] + q[0];                     // oldest frame first, like a sequential overlap-add
+            acc0[cc] = acc1[cc] + q[1];
+            acc1[cc] = acc2[cc] + q[2];
+            acc2[cc] = q[3];
+        }
+        if (t >= ja) emit(t, out);
+    }
+    // the hop after the last frame is complete without a frame of its own
+    if (jb == Tn + 1) emit(Tn, acc0);
+}
+
+static size_t apply_wave_lds(int W, int mode) {
+    return (size_t)W * WBUF * sizeof(c2) + (size_t)W * (mode == APPLY_SUBTRACT ? PARK : GROW / 2) * sizeof(c2) +
+           (size_t)(TWTAB + 512) * sizeof(c2) + (2048 + 512) * sizeof(float);
+}
+
 static size_t apply_lds(int W, int mode, int hop) {
     const int R = 2048 / hop;
     return (size_t)W * WBUF * sizeof(c2) +
@@ -839,8 +1244,34 @@ static size_t apply_lds(int W, int mode, int hop) {
 
 }  // namespace fast
 
+// hop 512: one wave per run of hops
+template <int MODE>
+static int apply_wave(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
+    constexpr int W = MODE == APPLY_SUBTRACT ? 8 : 4;
+    const int64_t out_hops = Tmax - 1;
+    if (out_hops <= 0) return ADN_OK;
+    // two rounds of runs over the waves a full chip holds; a run pays three warm-up frames (and two
+    // analysis-only frames in SUBTRACT mode), so it is not made shorter than 16 hops
+    int64_t run = ceil_div(n_sig * out_hops, (int64_t)c->num_cus * 8 * 2);
+    run = run < 16 ? 16 : (run > 1024 ? 1024 : run);
+    a.seg_hops = (int)run;
+    a.segs_per_sig = ceil_div(out_hops, run);
+    a.n_sig = n_sig;
+    const size_t lds = fast::apply_wave_lds(W, MODE);
+    auto kern = fast::k_apply_wave<W, MODE>;
+    ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t wgs = ceil_div(n_sig * a.segs_per_sig, (int64_t)W);
+    ADN_REQUIRE(wgs < (int64_t)0x7FFFFFFF, "batch too large for one launch");
+    ADN_LAUNCH_NAMED((MODE == APPLY_SUBTRACT ? "k_apply_wave<SUBTRACT>" : "k_apply_wave<GAIN>"), kern, dim3((unsigned)wgs),
+                     dim3(W * 64), lds, c->stream, a);
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
+
 template <int MODE>
 int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
+    if (a.sg.hop == 512 && c->ablate == 0 && (MODE == APPLY_GAIN || (a.sf == 5 && a.st == fast::FAST_ST)))
+        return apply_wave<MODE>(c, a, n_sig, Tmax);
     // 8 waves per workgroup.  4-wave workgroups, two per CU, measured the same in GAIN mode (the
     // overlap-add path handles W = 4 too) and do not fit LDS twice in SUBTRACT mode.
     constexpr int W = 8;

@@ -93,7 +93,8 @@ struct ApplyArgs {
     T alpha, beta;
     int st, sf;          // box sizes along time / frequency
     int64_t segs_per_sig;
-    int seg_hops;        // output hops per workgroup
+    int64_t n_sig;       // signals of the batch (kernels whose grid is not a multiple of it)
+    int seg_hops;        // output hops per workgroup (or per wave)
     int ablate;          // diagnostics: bit 0 skips the analysis, 1 the synthesis, 2 the overlap-add
     unsigned long long *dbg;   // diagnostics (ablate bit 4): per-phase shader-clock totals of wave 0
 };
