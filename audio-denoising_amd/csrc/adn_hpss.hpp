@@ -395,7 +395,8 @@ int hpss_separate(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, con
     const size_t nS = (size_t)n_sig * F * Ts, nM = (size_t)n_sig * Tmax * F;
     ADN_TRY(ws_reserve(c, ws_need(nS, sizeof(T)) + 2 * ws_need(nM, sizeof(T)) + ws_need(n_sig, 8) * 4 + 2 * ws_need(F, 4) +
                               2 * ws_need((size_t)n_sig * max_frames, 8) + ws_need((size_t)n_sig * 3, 8) +
-                              ws_need((size_t)n_sig * 5, 8) + ws_need((size_t)n_sig * (max_frames + 4), 1)));
+                              ws_need((size_t)n_sig * 5, 8) + ws_need((size_t)n_sig * (max_frames + 4), 1) +
+                              2 * APPLY_WS_BYTES));
     T *S = ws_take<T>(c, nS);
     T *Mh = ws_take<T>(c, nM), *Mp = ws_take<T>(c, nM);
     int64_t *Tn = ws_take<int64_t>(c, n_sig);

@@ -1044,6 +1044,7 @@ int spectral_subtract(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off,
     }
     DeviceGuard dg(c->device);
     ws_reset(c);
+    ADN_TRY(ws_reserve(c, APPLY_WS_BYTES));
     Tables<T> tb;
     ADN_TRY(get_tables<T>(c, n_fft, &tb));
     ApplyArgs<T> a{};
@@ -1088,7 +1089,7 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     const size_t nS = (size_t)n_sig * F * Ts, nR = (size_t)n_sig * F;
     ADN_TRY(ws_reserve(c, ws_need(nS, sizeof(T)) + ws_need(n_sig, 8) + 2 * ws_need(nR, 8) + ws_need(nR, sizeof(T)) +
                               ws_need((size_t)n_sig * nv_max, 1) + ws_need((size_t)n_sig * Ts, 1) + ws_need(n_sig, 4) +
-                              2 * select_ws_bytes(n_sig * F, Tmax)));
+                              2 * select_ws_bytes(n_sig * F, Tmax) + APPLY_WS_BYTES));
     T *S = ws_take<T>(c, nS);
     int64_t *Tn = ws_take<int64_t>(c, n_sig);
     double *p10 = ws_take<double>(c, nR), *sraw = ws_take<double>(c, nR);

@@ -313,46 +313,82 @@ struct Spec {
     c2 lo[8], hi[8], mid;
 };
 
+// Addresses of the two kinds of accesses to the natural (padded) spectrum image: bin lane + 64 j
+// and its mirror 1024 - lane - 64 j.  Both are one base address per lane plus compile-time
+// offsets (so that they cost two registers, not one per access): nat(lane + 64 j) = lane + 64 j +
+// 8 (j >> 2); for lane >= 1 the mirror is (64 - lane) + 64 (15 - j) + 8 ((15 - j) >> 2); lane 0
+// sits exactly on the padding steps and needs 8 more for j = 4, 8, 12 (its j = 0 mirror is bin 0,
+// handled by the callers, and the address formed for it stays inside the buffer).
+struct NatAddr {
+    const c2 *fwd;     // buf + lane
+    const c2 *mir;     // buf + 64 - lane
+    const c2 *mir4;    // the same, + 8 for lane 0: mirror base of j = 4, 8, 12
+};
+__device__ __forceinline__ NatAddr nat_addr(const c2 *buf, int lane) {
+    return NatAddr{buf + lane, buf + 64 - lane, buf + 64 - lane + (lane == 0 ? 8 : 0)};
+}
+template <int J> __device__ __forceinline__ int nat_fwd_off() { return 64 * J + 8 * (J >> 2); }
+template <int J> __device__ __forceinline__ int nat_mir_off() { return 64 * (15 - J) + 8 * ((15 - J) >> 2); }
+
+template <int J>
+__device__ __forceinline__ void split_bin(Spec &s, const NatAddr &na, const c2 (&rtw)[8], float hs, float scale, int lane) {
+    const c2 zk = na.fwd[nat_fwd_off<J>()];
+    const c2 zm = ((J & 3) == 0 ? na.mir4 : na.mir)[nat_mir_off<J>()];
+    const c2 e = add_conj(zk, zm);                         // (zk.x + zm.x, zk.y - zm.y)
+    const c2 o = odd_part(zk, zm);                         // (zk.y + zm.y, zm.x - zk.x)
+    const c2 wo = mul(o, rtw[J]);
+    s.lo[J] = (e + wo) * hs;
+    s.hi[J] = (e - wo) * c2{hs, -hs};                      // conjugated
+    if (J == 0 && lane == 0) {
+        s.lo[0] = c2{(zk.x + zk.y) * scale, 0.0f};
+        s.hi[0] = c2{(zk.x - zk.y) * scale, 0.0f};
+    }
+}
+
 __device__ __forceinline__ void split_spectrum(Spec &s, const c2 *buf, const c2 (&rtw)[8], float scale, int lane) {
     // Z[k] = E[k] + W^k O[k] with E = (z[k] + conj(z[N-k])) / 2, O = -i (z[k] - conj(z[N-k])) / 2;
     // the halves are folded into the scale
     const float hs = 0.5f * scale;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = lane + 64 * j;
-        const c2 zk = buf[nat(k)];
-        const c2 zm = buf[nat((1024 - k) & 1023)];
-        const c2 e = add_conj(zk, zm);                     // (zk.x + zm.x, zk.y - zm.y)
-        const c2 o = odd_part(zk, zm);                     // (zk.y + zm.y, zm.x - zk.x)
-        const c2 wo = mul(o, rtw[j]);
-        s.lo[j] = (e + wo) * hs;
-        s.hi[j] = (e - wo) * c2{hs, -hs};                  // conjugated
-        if (j == 0 && lane == 0) {
-            s.lo[0] = c2{(zk.x + zk.y) * scale, 0.0f};
-            s.hi[0] = c2{(zk.x - zk.y) * scale, 0.0f};
-        }
-    }
+    const NatAddr na = nat_addr(buf, lane);
+    split_bin<0>(s, na, rtw, hs, scale, lane);
+    split_bin<1>(s, na, rtw, hs, scale, lane);
+    split_bin<2>(s, na, rtw, hs, scale, lane);
+    split_bin<3>(s, na, rtw, hs, scale, lane);
+    split_bin<4>(s, na, rtw, hs, scale, lane);
+    split_bin<5>(s, na, rtw, hs, scale, lane);
+    split_bin<6>(s, na, rtw, hs, scale, lane);
+    split_bin<7>(s, na, rtw, hs, scale, lane);
     const c2 z = buf[nat(512)];
     s.mid = c2{z.x * scale, -z.y * scale};
 }
 
 // Inverse of split_spectrum: writes the packed spectrum Z' (natural, padded) into buf.
-__device__ __forceinline__ void merge_spectrum(const Spec &s, c2 *buf, const c2 (&rtw)[8], int lane) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int k = lane + 64 * j;
-        const c2 xk = s.lo[j], xm = s.hi[j];
-        if (j == 0 && lane == 0) {
-            buf[0] = c2{(xk.x + xm.x) * 0.5f, (xk.x - xm.x) * 0.5f};
-        } else {
-            const c2 e = add_conj(xk, xm) * 0.5f;          // ((xk.x + xm.x) / 2, (xk.y - xm.y) / 2)
-            c2 d;                                          // ((xk.x - xm.x) / 2, (xk.y + xm.y) / 2)
-            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(d) : "v"(xk), "v"(xm));
-            const c2 o = mulc(d * 0.5f, rtw[j]);
-            buf[nat(k)] = add_rot<true>(e, o);             // e + i o = (e.x - o.y, e.y + o.x)
-            buf[nat(1024 - k)] = conj_sub_rot(e, o);       // conj(e - i o) = (e.x + o.y, o.x - e.y)
-        }
+template <int J>
+__device__ __forceinline__ void merge_bin(const Spec &s, c2 *buf, const NatAddr &na, const c2 (&rtw)[8], int lane) {
+    const c2 xk = s.lo[J], xm = s.hi[J];
+    c2 *fwd = const_cast<c2 *>(na.fwd), *mir = const_cast<c2 *>((J & 3) == 0 ? na.mir4 : na.mir);
+    if (J == 0 && lane == 0) {
+        buf[0] = c2{(xk.x + xm.x) * 0.5f, (xk.x - xm.x) * 0.5f};
+    } else {
+        const c2 e = add_conj(xk, xm) * 0.5f;              // ((xk.x + xm.x) / 2, (xk.y - xm.y) / 2)
+        c2 d;                                              // (xk.x - xm.x, xk.y + xm.y)
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(d) : "v"(xk), "v"(xm));
+        const c2 o = mulc(d * 0.5f, rtw[J]);
+        fwd[nat_fwd_off<J>()] = add_rot<true>(e, o);       // e + i o = (e.x - o.y, e.y + o.x)
+        mir[nat_mir_off<J>()] = conj_sub_rot(e, o);        // conj(e - i o) = (e.x + o.y, o.x - e.y)
     }
+}
+
+__device__ __forceinline__ void merge_spectrum(const Spec &s, c2 *buf, const c2 (&rtw)[8], int lane) {
+    const NatAddr na = nat_addr(buf, lane);
+    merge_bin<0>(s, buf, na, rtw, lane);
+    merge_bin<1>(s, buf, na, rtw, lane);
+    merge_bin<2>(s, buf, na, rtw, lane);
+    merge_bin<3>(s, buf, na, rtw, lane);
+    merge_bin<4>(s, buf, na, rtw, lane);
+    merge_bin<5>(s, buf, na, rtw, lane);
+    merge_bin<6>(s, buf, na, rtw, lane);
+    merge_bin<7>(s, buf, na, rtw, lane);
     if (lane == 0) buf[nat(512)] = c2{s.mid.x, -s.mid.y};
 }
 
@@ -907,19 +943,92 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
 //     in-hop positions of a lane (r[4 cc + d], d = quarter), so the three partial hops are
 //     twelve complex registers per lane and a finished hop leaves in four 8-byte stores; no
 //     accumulator ring in LDS, no pass over it.
+//   * a finished hop is stored by the NEXT step, right after that step has requested its frame's
+//     samples: memory operations complete in order, so a wave that asked for its frame after the
+//     stores would wait for the stores' acknowledgement as well.
 //   * SUBTRACT smooths over the two neighbouring frames: the frequency-smoothed magnitudes of a
 //     lane's own 17 bins stay in registers (the sum of the two previous rows and the previous
 //     row), and the spectrum of the newest frame, whose right neighbour is not known yet, is
-//     swapped with the one parked in the wave's LDS slot.
+//     swapped with the one parked in the wave's LDS slot.  The waves of a workgroup work on one
+//     signal and share its noise row in LDS.
 //   * GAIN keeps the signal's gain row in the wave's LDS slot (per-frame gain rows are read from
 //     memory).
-// Everything that does not change from frame to frame and is not needed in every instruction
-// (real-FFT split factors, overlap norm, window) is read from LDS tables rather than held in
-// registers: the transform itself needs most of the 256 registers two waves per SIMD leave a wave.
+// LDS bandwidth is the scarcest resource of this kernel (six exchanges of a whole frame per frame),
+// so tables are kept out of it where arithmetic can stand in: only the first half of the periodic
+// Hann window is stored (w[n + 1024] = 1 - w[n], applied as x - x w), and the real-FFT split
+// factors of a lane are one value times compile-time constants.
+static constexpr int GROW = 1032;                 // floats of a gain / noise row slot (1025 used)
 
-static constexpr int GROW = 1032;                 // floats of a wave's gain row slot (1025 used)
+// exp(-2 pi i (lane + 64 j) / 2048) = rtw0 * exp(-i pi j / 16)
+__device__ __forceinline__ void derive_rtw(c2 (&rtw)[8], c2 rtw0) {
+    rtw[0] = rtw0;
+    rtw[1] = mul_k(rtw0, c2{0.9807852804032304f, -0.19509032201612825f});
+    rtw[2] = mul_k(rtw0, c2{0.9238795325112867f, -0.3826834323650898f});
+    rtw[3] = mul_k(rtw0, c2{0.8314696123025452f, -0.5555702330196022f});
+    rtw[4] = mul_k(rtw0, c2{0.7071067811865476f, -0.7071067811865476f});
+    rtw[5] = mul_k(rtw0, c2{0.5555702330196022f, -0.8314696123025452f});
+    rtw[6] = mul_k(rtw0, c2{0.3826834323650898f, -0.9238795325112867f});
+    rtw[7] = mul_k(rtw0, c2{0.19509032201612825f, -0.9807852804032304f});
+}
 
-template <int W, int MODE>
+// Raw samples of the frame at padded position p0, requested into registers (no arithmetic, so
+// that the loads stay in flight).  NCH = 1: pf[j] is packed point lane + 64 j; NCH = 2: pf[j] holds
+// the two (left, right) pairs of packed point lane + 64 j.  Returns false when the frame needs the
+// generic loader instead (tail of the signal, odd alignment, another channel count).
+template <int NCH> struct FetchT;
+template <> struct FetchT<1> { typedef c2 type; };
+template <> struct FetchT<2> { typedef float4 type; };
+
+template <int NCH>
+__device__ __forceinline__ bool fetch_frame(typename FetchT<NCH>::type (&pf)[16], const float *__restrict__ xs, int64_t n,
+                                            int n_ch, int64_t p0, int lane) {
+    typedef typename FetchT<NCH>::type V;
+    const bool ok = p0 + 2048 <= n && n_ch == NCH && (reinterpret_cast<uintptr_t>(xs + NCH * p0) & (sizeof(V) - 1)) == 0;
+    // No branch around the loads (a join between the loads and their first use would make the
+    // compiler wait for every younger memory operation as well): a frame that cannot be fetched this
+    // way reads the first 2048 frames of the signal instead, from the address rounded down to the
+    // load size, and the result is ignored.  Every signal holds at least one whole frame; rounding
+    // down stays inside the caller's buffer because only element offsets inside it can be odd.
+    // (pointer arithmetic only: an integer round trip would turn the loads into flat ones)
+    const float *src = ok ? xs + NCH * p0 : xs - ((reinterpret_cast<uintptr_t>(xs) & (sizeof(V) - 1)) >> 2);
+    const V *xv = reinterpret_cast<const V *>(src) + lane;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) pf[j] = xv[64 * j];
+    __builtin_amdgcn_sched_barrier(0);
+    return ok;
+}
+
+__device__ __forceinline__ c2 fold_point(const c2 &q) { return q; }
+__device__ __forceinline__ c2 fold_point(const float4 &q) { return c2{(q.x + q.y) / 2.0f, (q.z + q.w) / 2.0f}; }
+
+// Windowed packed frame r[j] = z[lane + 64 j] from the fetched samples; wv = first half of the window
+template <typename V>
+__device__ __forceinline__ void window_fetched(c2 (&r)[16], const V (&pf)[16], const c2 *wv, int lane) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const c2 w = wv[lane + 64 * j];
+        const c2 lo = fold_point(pf[j]), hi = fold_point(pf[j + 8]);
+        r[j] = lo * w;
+        r[j + 8] = hi - hi * w;                            // w[n + 1024] = 1 - w[n]
+    }
+}
+
+// Any frame (zero-padded tail, odd alignment, any channel count): staged through the wave's buffer.
+__device__ __noinline__ void stage_frame_half_window(c2 *buf, const float *__restrict__ xs, int64_t n, int n_ch,
+                                                     int64_t p0, const float *__restrict__ whalf, int lane) {
+#pragma unroll 1
+    for (int i = lane; i < NC; i += 64) {
+        const float u = fold_sample(xs, p0 + 2 * i, n, n_ch), v = fold_sample(xs, p0 + 2 * i + 1, n, n_ch);
+        const int wi = 2 * (i & 511);
+        const float w0 = whalf[wi], w1 = whalf[wi + 1];
+        buf[nat(i)] = i < 512 ? c2{u * w0, v * w1} : c2{u - u * w0, v - v * w1};
+    }
+}
+
+// NCH: the channel count whose frames are fetched straight into registers (other counts, and frames
+// at the zero-padded tail of a signal, take the staged loader)
+template <int W, int MODE, int NCH, bool PROF>
 __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_apply_wave(ApplyArgs<float> a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int H = 512;
@@ -928,13 +1037,18 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     c2 *bufs = reinterpret_cast<c2 *>(smem);                                          // [W][WBUF] exchange
     c2 *slots = bufs + (size_t)W * WBUF;                                              // [W][SLOT] parked spectrum / gain row
     c2 *twtab = slots + (size_t)W * SLOT;
-    c2 *rtab = twtab + TWTAB;                                                         // [512] real-FFT split factors
-    float *wtab = reinterpret_cast<float *>(rtab + 512);                              // [2048] window
-    float *ntab = wtab + 2048;                                                        // [512] scale / full-overlap norm
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
+    float *wtab = reinterpret_cast<float *>(twtab + TWTAB);                           // [1024] first half of the window
+    float *ntab = wtab + 1024;                                                        // [512] scale / full-overlap norm
+    float *nrow = ntab + 512;                                                         // [GROW] SUBTRACT: the signal's noise row
+    const int wave = threadIdx.x >> 6, lane0 = threadIdx.x & 63, tid = threadIdx.x;
+    // SUBTRACT: the waves of a workgroup work on one signal (segs_per_sig is a multiple of W)
+    const int64_t gid = (int64_t)blockIdx.x * W + wave;
+    const int64_t sig = gid / a.segs_per_sig;
+    const int run = (int)(gid % a.segs_per_sig);
+    const bool have_sig = sig < a.n_sig;
+    const float *row = a.row + (have_sig ? sig : 0) * a.row_stride;
     fill_tw_table(twtab, tb.fast_tw, tid, W * 64);
-    for (int i = tid; i < 512; i += W * 64) rtab[i] = as_c2(tb.rtw)[i];
-    for (int i = tid; i < 2048; i += W * 64) wtab[i] = tb.window[i];
+    for (int i = tid; i < 1024; i += W * 64) wtab[i] = tb.window[i];
     const float fscale = (float)(1.0 / tb.wsum);
     const float iscale = (float)(tb.wsum / 1024.0);
     for (int i = tid; i < 512; i += W * 64) {
@@ -946,12 +1060,11 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
         ntab[i] = iscale / (sq > 1e-10f ? sq : 1.0f);
     }
+    if (MODE == APPLY_SUBTRACT)
+        for (int i = tid; i <= 1024; i += W * 64) nrow[i] = row[i];
     __syncthreads();                                       // the only workgroup barrier: every wave reaches it
 
-    const int64_t gid = (int64_t)blockIdx.x * W + wave;
-    const int64_t sig = gid / a.segs_per_sig;
-    const int run = (int)(gid % a.segs_per_sig);
-    if (sig >= a.n_sig) return;
+    if (!have_sig) return;
     const int64_t n = a.sg.len[sig];
     const int Tn = (int)stft_frames(n, 2048, H, 1);        // frame / hop indices of one signal fit 32 bits
     // output hops are the padded hops j = 2 .. Tn (istft drops n_fft/2 at both ends); hop j is
@@ -964,34 +1077,34 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const float *xs = a.x + a.sg.off[sig];
     float *ys = a.y + a.y_off[sig];
     int16_t *ps = a.pcm ? a.pcm + a.y_off[sig] : nullptr;
-    const float *row = a.row + sig * a.row_stride;
     c2 *buf = bufs + wave * WBUF;
     float *bufr = reinterpret_cast<float *>(buf);
     c2 *park = slots + wave * SLOT;
     float *grow_lds = reinterpret_cast<float *>(park);
-    const LaneTw tw = lane_tw(twtab, lane);
     const c2 *wv = reinterpret_cast<const c2 *>(wtab);
     const c2 *nv = reinterpret_cast<const c2 *>(ntab);
-    const int mlane = (lane & 15) + 64 * (lane >> 4);      // packed point of r[4 cc + d] is mlane + 16 cc + 256 d
+    const c2 rtw0 = as_c2(tb.rtw)[lane0];
     const bool y_vec = (reinterpret_cast<uintptr_t>(ys) & 7) == 0;
     const bool p_vec = (reinterpret_cast<uintptr_t>(ps) & 3) == 0;
     const bool gain_in_lds = MODE == APPLY_GAIN && a.row_t_stride == 0;
     if (gain_in_lds) {
-        for (int k = lane; k <= 1024; k += 64) grow_lds[k] = row[k];
+        for (int k = lane0; k <= 1024; k += 64) grow_lds[k] = row[k];
         wave_sync();
     }
+    auto wfull = [&](int idx) { return idx < 1024 ? wtab[idx] : 1.0f - wtab[idx - 1024]; };
 
     // one finished hop: normalise, clip, optional PCM16, store
-    auto emit = [&](int j, const c2 (&v)[4]) {
+    auto emit = [&](int j, const c2 (&v)[4], int mlane) {
         const bool full = j >= 3 && j <= Tn - 1;
-        const int64_t base = (int64_t)(j - 2) * H;
+        const int64_t base = (int64_t)(j - 2) * H + 2 * mlane;               // the lane's first sample of the hop
+        float *yp0 = ys + base;
+        int16_t *pp0 = ps + base;
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
             const int i = 2 * (mlane + 16 * cc);           // sample of the hop (and i + 1)
             c2 o;
             if (full) {
-                const c2 q = nv[mlane + 16 * cc];
-                o = c2{v[cc].x * q.x, v[cc].y * q.y};
+                o = v[cc] * nv[mlane + 16 * cc];
             } else {
                 float nx_ = 0.0f, ny_ = 0.0f;
                 int t_lo = j - 3;
@@ -999,7 +1112,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 const int t_hi = j < Tn - 1 ? j : Tn - 1;
 #pragma unroll 1
                 for (int tt = t_lo; tt <= t_hi; ++tt) {
-                    const float w0 = wtab[(j - tt) * H + i], w1 = wtab[(j - tt) * H + i + 1];
+                    const float w0 = wfull((j - tt) * H + i), w1 = wfull((j - tt) * H + i + 1);
                     nx_ += w0 * w0;
                     ny_ += w1 * w1;
                 }
@@ -1011,7 +1124,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
             if (ps) {
                 const int k0 = pcm_int32(o.x) >> 16, k1 = pcm_int32(o.y) >> 16;
-                int16_t *pp = ps + base + i;
+                int16_t *pp = pp0 + 32 * cc;
                 if (p_vec) {
                     *reinterpret_cast<unsigned *>(pp) = (unsigned)(k0 & 0xFFFF) | ((unsigned)k1 << 16);
                 } else {
@@ -1020,7 +1133,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 }
                 o = c2{(float)k0 * (1.0f / 32768.0f), (float)k1 * (1.0f / 32768.0f)};
             }
-            float *yp = ys + base + i;
+            float *yp = yp0 + 32 * cc;
             if (y_vec) {
                 *reinterpret_cast<c2 *>(yp) = o;
             } else {
@@ -1040,22 +1153,86 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     float m1_lo[8], m1_hi[8], m1_mid = 0.0f;               // row of the previous frame
     float s2_lo[8], s2_hi[8], s2_mid = 0.0f;               // sum of the rows of the two previous frames
     const int s_end = MODE == APPLY_SUBTRACT ? tb_ + 1 : tb_;
+    // diagnostics (PROF): shader-clock totals of the phases of this wave's frames
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tk = PROF ? clock64() : 0;
+    auto tick = [&](int i) {
+        if (PROF) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long now = clock64();
+            ph[i] += now - tk;
+            tk = now;
+        }
+    };
+    c2 pend[4];                                            // finished hop waiting to be stored
+    int pend_j = -1;
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) pend[cc] = c2{0.0f, 0.0f};
 
 #pragma unroll 1
     for (int s = u0; s <= s_end; ++s) {
+        // Everything derived from the lane index (LDS and memory addresses of a dozen access patterns)
+        // is re-derived in every step from an opaque copy: kept across the steps as loop invariants,
+        // those values alone would take some 150 registers from the transforms.
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        const int mlane = (lane & 15) + 64 * (lane >> 4);  // packed point of r[4 cc + d] is mlane + 16 cc + 256 d
+        const LaneTw tw = lane_tw(twtab, lane);
         Spec sp;
         const bool analyse = s <= u1;
+        // the frame's samples are requested first, THEN the hop finished by the previous step is stored
+        typename FetchT<NCH>::type pf[16];
+        bool pf_mode = false;
+        // (a step without analysis fetches, and ignores, the run's last frame again)
+        pf_mode = fetch_frame<NCH>(pf, xs, n, a.sg.n_ch, (int64_t)(analyse ? s : u1) * H, lane) && analyse;
+        // The common case of the pending hop (full overlap, aligned output, no PCM copy) is stored by
+        // straight-line code: four unconditional stores, no branch.  The wait for the frame
+        // then allows exactly those four stores to be outstanding; any branch between the loads and
+        // their first use makes the compiler's wait conservative (it would wait for the stores too).
+        const bool pend_fast = pend_j >= 3 && pend_j <= Tn - 1 && y_vec && ps == nullptr;
+        {
+            const float lim = a.no_clip ? __builtin_inff() : 1.0f;
+            // a hop that is not stored here goes to a scratch line instead (unconditional stores)
+            float *yp0 = pend_fast ? ys + ((int64_t)(pend_j - 2) * H + 2 * mlane) : a.dummy + 2 * mlane;
+            c2 o[4];
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                o[cc] = pend[cc] * nv[mlane + 16 * cc];
+                o[cc].x = o[cc].x < -lim ? -lim : (o[cc].x > lim ? lim : o[cc].x);
+                o[cc].y = o[cc].y < -lim ? -lim : (o[cc].y > lim ? lim : o[cc].y);
+            }
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) *reinterpret_cast<c2 *>(yp0 + 32 * cc) = o[cc];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        c2 r[16];                                          // the frame being transformed (either direction)
         if (analyse) {
-            // ---- frame s: load, window, forward transform, real-signal spectrum
-            c2 r[16];
-            load_frame(r, buf, xs, n, a.sg.n_ch, (int64_t)s * H, wtab, lane);
+            // ---- frame s: window the fetched samples, forward transform, real-signal spectrum
+            if (pf_mode) {
+                window_fetched(r, pf, wv, lane);
+            } else {
+                stage_frame_half_window(buf, xs, n, a.sg.n_ch, (int64_t)s * H, wtab, lane);
+                wave_sync();
+                const c2 *nb = buf + lane;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) r[j] = nb[64 * j + 8 * (j >> 2)];        // nat(lane + 64 j)
+                wave_sync();
+            }
+            tick(0);
+        }
+        // the other cases of the pending hop (first / last hops of a signal, PCM copy, odd alignment)
+        if (pend_j >= 0 && !pend_fast) emit(pend_j, pend, mlane);
+        pend_j = -1;
+        if (analyse) {
             wave_fft1024<false>(r, buf, tw, lane);
+            tick(1);
             store_natural(r, buf, lane);
             wave_sync();
             c2 rtw[8];
-            load_rtw(rtw, rtab, lane);
+            derive_rtw(rtw, rtw0);
             split_spectrum(sp, buf, rtw, fscale, lane);
             wave_sync();
+            tick(2);
         }
         __builtin_amdgcn_sched_barrier(0);
         int t = s;                                          // frame synthesised in this step
@@ -1066,19 +1243,21 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 // bins at both ends for the box filter's edge replication)
                 float *rawm = bufr + RAWPAD;
                 {
-                    const float *nlo = row + lane, *nhi = row + 1024 - lane;      // one address each, constant offsets
-                    float *wlo = rawm + lane, *whi = rawm + 1024 - lane;
+                    // mirrored bins 1024 - lane - 64 j are addressed upwards from the lowest one (j = 7):
+                    // LDS instructions take unsigned offsets only
+                    const float *nlo = nrow + lane, *nhi = nrow + 576 - lane;
+                    float *wlo = rawm + lane, *whi = rawm + 576 - lane;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float m0 = __builtin_amdgcn_sqrtf(norm2(sp.lo[j]));
                         const float m1 = __builtin_amdgcn_sqrtf(norm2(sp.hi[j]));
                         wlo[64 * j] = fmaxf(m0 - a.alpha * nlo[64 * j], a.beta * m0);
-                        whi[-64 * j] = fmaxf(m1 - a.alpha * nhi[-64 * j], a.beta * m1);
+                        whi[64 * (7 - j)] = fmaxf(m1 - a.alpha * nhi[64 * (7 - j)], a.beta * m1);
                     }
                 }
                 if (lane == 0) {
                     const float mm = __builtin_amdgcn_sqrtf(norm2(sp.mid));
-                    rawm[512] = fmaxf(mm - a.alpha * row[512], a.beta * mm);
+                    rawm[512] = fmaxf(mm - a.alpha * nrow[512], a.beta * mm);
                 }
                 // park the new spectrum, take the previous frame's
 #pragma unroll
@@ -1102,11 +1281,11 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 // box mean over five bins (the only frequency smoothing this kernel is launched for);
                 // same summation order as the shape-generic kernel
                 const float inv_sf = 1.0f / 5.0f;
-                const float *blo = rawm + lane, *bhi = rawm + 1024 - lane;
+                const float *blo = rawm + lane - 2, *bhi = rawm + 576 - lane - 2;     // first bin of each window
                 auto box = [&](const float *p) {
                     float rv[5];
 #pragma unroll
-                    for (int d = 0; d < 5; ++d) rv[d] = p[d - 2];
+                    for (int d = 0; d < 5; ++d) rv[d] = p[d];
                     float fs = 0.0f;
 #pragma unroll
                     for (int d = 0; d < 5; ++d) fs += rv[d];
@@ -1115,10 +1294,10 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     mc_lo[j] = box(blo + 64 * j);
-                    mc_hi[j] = box(bhi - 64 * j);
+                    mc_hi[j] = box(bhi + 64 * (7 - j));
                     if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);     // at most 40 row values in flight
                 }
-                mc_mid = box(rawm + 512);
+                mc_mid = box(rawm + 510);
                 wave_sync();                                // the row has been read: the buffer is free again
             } else {
                 // s == Tn: the row beyond the last frame is the last frame's (edge replication); its
@@ -1172,66 +1351,73 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             m1_mid = mc_mid;
         } else {
             if (gain_in_lds) {
-                const float *glo = grow_lds + lane, *ghi = grow_lds + 1024 - lane;
+                const float *glo = grow_lds + lane, *ghi = grow_lds + 576 - lane;     // upwards from bin 1024 - lane - 448
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float g0v = glo[64 * j], g1v = ghi[-64 * j];
-                    sp.lo[j] = c2{sp.lo[j].x * g0v, sp.lo[j].y * g0v};
-                    sp.hi[j] = c2{sp.hi[j].x * g1v, sp.hi[j].y * g1v};
+                    sp.lo[j] = sp.lo[j] * glo[64 * j];
+                    sp.hi[j] = sp.hi[j] * ghi[64 * (7 - j)];
                 }
-                const float gmv = grow_lds[512];
-                sp.mid = c2{sp.mid.x * gmv, sp.mid.y * gmv};
+                sp.mid = sp.mid * grow_lds[512];
             } else {
                 const float *grow = row + (int64_t)t * a.row_t_stride;     // per-frame gain rows (masks)
                 const float *glo = grow + lane, *ghi = grow + 1024 - lane;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float g0v = glo[64 * j], g1v = ghi[-64 * j];
-                    sp.lo[j] = c2{sp.lo[j].x * g0v, sp.lo[j].y * g0v};
-                    sp.hi[j] = c2{sp.hi[j].x * g1v, sp.hi[j].y * g1v};
+                    sp.lo[j] = sp.lo[j] * glo[64 * j];
+                    sp.hi[j] = sp.hi[j] * ghi[-64 * j];
                 }
-                const float gmv = grow[512];
-                sp.mid = c2{sp.mid.x * gmv, sp.mid.y * gmv};
+                sp.mid = sp.mid * grow[512];
             }
         }
-        if (t < ta) continue;
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- frame t: back to the packed spectrum, inverse transform, synthesis window, overlap-add
-        {
-            c2 rtw[8];
-            load_rtw(rtw, rtab, lane);
-            merge_spectrum(sp, buf, rtw, lane);
-        }
-        wave_sync();
-        c2 r[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) r[j] = buf[nat(lane + 64 * j)];
-        wave_sync();
-        wave_fft1024<true>(r, buf, tw, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        c2 out[4];
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            c2 q[4];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const c2 w = wv[mlane + 16 * cc + 256 * d];
-                q[d] = c2{r[4 * cc + d].x * w.x, r[4 * cc + d].y * w.y};
+        tick(3);
+        const bool synth = t >= ta;
+        if (synth) {
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- frame t: back to the packed spectrum, inverse transform
+            {
+                c2 rtw[8];
+                derive_rtw(rtw, rtw0);
+                merge_spectrum(sp, buf, rtw, lane);
             }
-            out[cc] = acc0[cc] + q[0];                     // oldest frame first, like a sequential overlap-add
-            acc0[cc] = acc1[cc] + q[1];
-            acc1[cc] = acc2[cc] + q[2];
-            acc2[cc] = q[3];
+            wave_sync();
+            {
+                const c2 *nb = buf + lane;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) r[j] = nb[64 * j + 8 * (j >> 2)];        // nat(lane + 64 j)
+            }
+            wave_sync();
+            tick(4);
+            wave_fft1024<true>(r, buf, tw, lane);
+            tick(5);
         }
-        if (t >= ja) emit(t, out);
+        __builtin_amdgcn_sched_barrier(0);
+        if (synth) {
+            // ---- synthesis window (first half stored: w[n + 1024] = 1 - w[n]), overlap-add
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const c2 w0 = wv[mlane + 16 * cc], w1 = wv[mlane + 16 * cc + 256];
+                const c2 q0 = r[4 * cc] * w0, q1 = r[4 * cc + 1] * w1;
+                const c2 q2 = r[4 * cc + 2] - r[4 * cc + 2] * w0, q3 = r[4 * cc + 3] - r[4 * cc + 3] * w1;
+                pend[cc] = acc0[cc] + q0;                  // oldest frame first, like a sequential overlap-add
+                acc0[cc] = acc1[cc] + q1;
+                acc1[cc] = acc2[cc] + q2;
+                acc2[cc] = q3;
+            }
+            if (t >= ja) pend_j = t;                       // stored by the next step, after its loads are out
+        }
+        tick(6);
     }
+    const int mlane0 = (lane0 & 15) + 64 * (lane0 >> 4);
+    if (pend_j >= 0) emit(pend_j, pend, mlane0);
     // the hop after the last frame is complete without a frame of its own
-    if (jb == Tn + 1) emit(Tn, acc0);
+    if (jb == Tn + 1) emit(Tn, acc0, mlane0);
+    if (PROF && lane0 == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&a.dbg[i], ph[i]);
 }
 
 static size_t apply_wave_lds(int W, int mode) {
     return (size_t)W * WBUF * sizeof(c2) + (size_t)W * (mode == APPLY_SUBTRACT ? PARK : GROW / 2) * sizeof(c2) +
-           (size_t)(TWTAB + 512) * sizeof(c2) + (2048 + 512) * sizeof(float);
+           (size_t)TWTAB * sizeof(c2) + (1024 + 512 + (mode == APPLY_SUBTRACT ? GROW : 0)) * sizeof(float);
 }
 
 static size_t apply_lds(int W, int mode, int hop) {
@@ -1256,21 +1442,45 @@ static int apply_wave(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
     run = run < 16 ? 16 : (run > 1024 ? 1024 : run);
     a.seg_hops = (int)run;
     a.segs_per_sig = ceil_div(out_hops, run);
+    // SUBTRACT: the waves of a workgroup share one signal's noise row (runs beyond the signal's end exit at once)
+    if (MODE == APPLY_SUBTRACT) a.segs_per_sig = ceil_div(a.segs_per_sig, (int64_t)W) * W;
     a.n_sig = n_sig;
+    // one 2 KB line that takes the stores of hops which are not stored by the kernel's fast path
+    if (c->ws_used + APPLY_WS_BYTES > c->ws_bytes) {
+        set_error("internal: the caller of the fused STFT kernel did not reserve its scratch line");
+        return ADN_ERR_NOMEM;
+    }
+    a.dummy = ws_take<float>(c, APPLY_WS_BYTES / sizeof(float));
     const size_t lds = fast::apply_wave_lds(W, MODE);
-    auto kern = fast::k_apply_wave<W, MODE>;
+    a.dbg = nullptr;
+    if (c->ablate & 16) {       // diagnostics: per-phase cycle totals, printed after the launch
+        ADN_HIP(hipMalloc(&a.dbg, 8 * sizeof(unsigned long long)));
+        ADN_HIP(hipMemset(a.dbg, 0, 8 * sizeof(unsigned long long)));
+    }
+    auto kern = a.sg.n_ch == 2 ? (a.dbg ? fast::k_apply_wave<W, MODE, 2, true> : fast::k_apply_wave<W, MODE, 2, false>)
+                               : (a.dbg ? fast::k_apply_wave<W, MODE, 1, true> : fast::k_apply_wave<W, MODE, 1, false>);
     ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t wgs = ceil_div(n_sig * a.segs_per_sig, (int64_t)W);
     ADN_REQUIRE(wgs < (int64_t)0x7FFFFFFF, "batch too large for one launch");
     ADN_LAUNCH_NAMED((MODE == APPLY_SUBTRACT ? "k_apply_wave<SUBTRACT>" : "k_apply_wave<GAIN>"), kern, dim3((unsigned)wgs),
                      dim3(W * 64), lds, c->stream, a);
     ADN_HIP(hipGetLastError());
+    if (a.dbg) {
+        unsigned long long hp[8];
+        ADN_HIP(hipStreamSynchronize(c->stream));
+        ADN_HIP(hipMemcpy(hp, a.dbg, sizeof(hp), hipMemcpyDeviceToHost));
+        ADN_HIP(hipFree(a.dbg));
+        const double fr = (double)n_sig * (double)out_hops;
+        fprintf(stderr, "k_apply_wave<%d> shader clocks per frame and wave: load+window %.0f fft %.0f natural+split %.0f modify %.0f "
+                "merge+reload %.0f ifft %.0f window+ola+emit %.0f (run %d hops)\n", MODE, hp[0] / fr, hp[1] / fr, hp[2] / fr,
+                hp[3] / fr, hp[4] / fr, hp[5] / fr, hp[6] / fr, a.seg_hops);
+    }
     return ADN_OK;
 }
 
 template <int MODE>
 int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
-    if (a.sg.hop == 512 && c->ablate == 0 && (MODE == APPLY_GAIN || (a.sf == 5 && a.st == fast::FAST_ST)))
+    if (a.sg.hop == 512 && (c->ablate & ~16) == 0 && (MODE == APPLY_GAIN || (a.sf == 5 && a.st == fast::FAST_ST)))
         return apply_wave<MODE>(c, a, n_sig, Tmax);
     // 8 waves per workgroup.  4-wave workgroups, two per CU, measured the same in GAIN mode (the
     // overlap-add path handles W = 4 too) and do not fit LDS twice in SUBTRACT mode.

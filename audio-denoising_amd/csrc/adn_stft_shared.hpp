@@ -96,9 +96,14 @@ struct ApplyArgs {
     int64_t n_sig;       // signals of the batch (kernels whose grid is not a multiple of it)
     int seg_hops;        // output hops per workgroup (or per wave)
     int ablate;          // diagnostics: bit 0 skips the analysis, 1 the synthesis, 2 the overlap-add
+    T *dummy;            // 512 writable elements nobody reads (target of stores a kernel issues unconditionally)
     unsigned long long *dbg;   // diagnostics (ablate bit 4): per-phase shader-clock totals of wave 0
 };
 
+
+// Workspace the fused apply kernels take beyond what their callers carve out themselves; callers
+// add it to their ws_reserve request.
+static constexpr size_t APPLY_WS_BYTES = 4096;
 
 // register-resident path (binary32, n_fft = 2048)
 bool apply_fast_ok(int n_fft, int hop, int st, int sf);
