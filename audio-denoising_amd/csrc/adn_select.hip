@@ -1397,6 +1397,237 @@ static int launch_select_big(Ctx *c, const T *d_vals, const SelectArgs &a) {
     return ADN_OK;
 }
 
+// ----------------------------------------------------------------------------
+// Rows of up to a few thousand binary32 values: one wave per segment, the keys held in
+// registers (KPL per lane).  The wanted order statistic is found bit by bit on the
+// range-normalised keys: for each bit, from the top, the number of keys below the trial
+// value is one vector compare per held key (the compare's lane mask goes to the scalar
+// unit, which counts and adds while the vector unit runs the next compare).  No LDS, no
+// barrier, no atomics; rows of one workgroup are independent of each other.
+static constexpr int SEL_CK = 8;                        // candidate keys per lane after compaction
+
+// Number of keys of the wave (N per lane) below `trial`.  Groups of eight keys: eight vector compares whose lane
+// masks go to eight scalar register pairs, THEN the eight scalar counts and additions.  A scalar instruction that
+// reads a register the vector unit has just written waits for that instruction to leave the vector pipeline; with
+// the compares grouped the wait is paid once per group, and the running sum keeps the scalar register demand at the
+// eight masks.  (The CU's one scalar unit, two instructions per key, is what bounds this loop.)
+template <int N>
+__device__ __forceinline__ uint32_t count_below(const uint32_t (&key)[N], uint32_t trial) {
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int g = 0; g < N; g += 8) {
+        unsigned long long m[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m[i] = g + i < N ? __ballot(key[g + i] < trial) : 0ull;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (g + i < N) cnt += (uint32_t)__builtin_popcountll(m[i]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    return cnt;
+}
+
+template <int XF, bool MASKED, int KPL>
+__global__ __launch_bounds__(256) void k_select_wave(const float *__restrict__ vals, const int64_t *__restrict__ seg_off,
+                                                     int64_t seg_stride, const int64_t *__restrict__ seg_len,
+                                                     int64_t len_div, int64_t uniform_len, int64_t n_seg, int mode,
+                                                     double q, const double *__restrict__ center,
+                                                     double *__restrict__ out, MaskedMean mm, int max_bits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t seg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (seg >= n_seg) return;
+    const int n = (int)(seg_len ? seg_len[seg / len_div] : uniform_len);
+    if (n <= 0) {
+        if (lane == 0) {
+            out[seg] = __longlong_as_double(0x7FF8000000000000ll);
+            if (MASKED) mm.out[seg] = 0.0;
+        }
+        return;
+    }
+    int64_t r0l, r1l;
+    double frac;
+    big_ranks(n, mode, q, &r0l, &r1l, &frac);
+    const uint32_t r0 = (uint32_t)r0l, r1 = (uint32_t)r1l;
+    const float c = XF == XF_ABSDEV ? (float)center[seg] : 0.0f;
+    const float *vrow = vals + (seg_off ? seg_off[seg] : seg * seg_stride);
+    const unsigned char *mrow = MASKED ? mm.mask + (seg / mm.mask_div) * mm.mask_stride : nullptr;
+
+    // ---- load: all loads of the row are issued back to back, with no branch between them.  Whole quads:
+    // element 4 (lane + 64 i) + e is key[4 i + e] (a quad index beyond the row re-reads the row's last whole quad and
+    // is ignored); the up to three elements after the last whole quad go to the extra slot key[KPL] of lanes 0..2.
+    // Positions that hold no element of the row keep the largest key.
+    uint32_t key[KPL + 1];
+    float msum = 0.0f;
+    int mcnt = 0;
+    bool saw_nan = false;
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
+    auto take = [&](int slot, float x, unsigned m, bool valid) {
+        if (MASKED && valid && m) {
+            msum += x;
+            ++mcnt;
+        }
+        if (XF == XF_ABSDEV) x = fabsf(x - c);
+        const bool is_nan = x != x;
+        const uint32_t k = (!valid || is_nan) ? 0xFFFFFFFFu : key_of(x);
+        saw_nan |= valid && is_nan;
+        key[slot] = k;
+        if (valid) {
+            kmin = k < kmin ? k : kmin;
+            kmax = k > kmax ? k : kmax;
+        }
+    };
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(vrow) & 15) == 0 && (!MASKED || (reinterpret_cast<uintptr_t>(mrow) & 3) == 0);
+    if (vec_ok && n >= 4) {
+        const int nq = n >> 2;                              // whole quads
+        const float4 *vv = reinterpret_cast<const float4 *>(vrow);
+        const uint32_t *mv = reinterpret_cast<const uint32_t *>(mrow);
+        float4 xq[KPL / 4];
+        uint32_t mq[KPL / 4];
+#pragma unroll
+        for (int i = 0; i < KPL / 4; ++i) {
+            const int j = lane + 64 * i;
+            const int js = j < nq ? j : nq - 1;
+            xq[i] = vv[js];
+            mq[i] = MASKED ? mv[js] : 0u;
+        }
+        const int jt = 4 * nq + lane;                       // tail element of lanes 0..2
+        const bool tail = lane < 3 && jt < n;
+        const float xt = vrow[tail ? jt : 0];
+        const unsigned mt = MASKED ? mrow[tail ? jt : 0] : 0u;
+#pragma unroll
+        for (int i = 0; i < KPL / 4; ++i) {
+            const bool valid = lane + 64 * i < nq;
+            take(4 * i + 0, xq[i].x, mq[i] & 0xFF, valid);
+            take(4 * i + 1, xq[i].y, (mq[i] >> 8) & 0xFF, valid);
+            take(4 * i + 2, xq[i].z, (mq[i] >> 16) & 0xFF, valid);
+            take(4 * i + 3, xq[i].w, mq[i] >> 24, valid);
+        }
+        take(KPL, xt, mt, tail);
+    } else {
+        float xs[KPL];
+        unsigned ms[KPL];
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) {
+            const int j = lane + 64 * i;
+            const int js = j < n ? j : n - 1;
+            xs[i] = vrow[js];
+            ms[i] = MASKED ? mrow[js] : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < KPL; ++i) take(i, xs[i], ms[i], lane + 64 * i < n);
+        key[KPL] = 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t a = __shfl_xor(kmin, d), b = __shfl_xor(kmax, d);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+        if (MASKED) {
+            msum += __shfl_xor(msum, d);
+            mcnt += __shfl_xor(mcnt, d);
+        }
+    }
+    const bool any_nan = __ballot(saw_nan) != 0;
+    if (MASKED && lane == 0) mm.out[seg] = (double)(msum / (float)(mcnt > 1 ? mcnt : 1));
+    if (any_nan) {
+        if (lane == 0) out[seg] = __longlong_as_double(0x7FF8000000000000ll);
+        return;
+    }
+    // ---- selection on key - kmin (the padding keys stay above every trial value that can be accepted)
+    int bits = 32 - __clz(kmax - kmin);                    // 0 when all keys are equal
+    bits = bits < max_bits ? bits : max_bits;              // diagnostics (ADN_OPT_ABLATE): results become wrong
+#pragma unroll
+    for (int i = 0; i <= KPL; ++i) key[i] -= kmin;
+    // lo_cnt = keys below res, hi_cnt = keys below res + 2^(undecided bits): their difference is the number of
+    // keys that still share the decided prefix.  Once those candidates fit SEL_CK registers per lane they are
+    // compacted (through the wave's LDS slot) and the remaining bits are decided on them alone: a row of some
+    // thousand spread-out keys needs a handful of full sweeps, not one per bit.
+    uint32_t res = 0, lo_cnt = 0, hi_cnt = (uint32_t)n;
+    uint32_t ck[SEL_CK];
+    bool compact = false;
+    int b = bits - 1;
+    for (; b >= 0; --b) {
+        const uint32_t trial = res | (1u << b);
+        const uint32_t cnt = count_below<KPL + 1>(key, trial);
+        if (cnt <= r0) {                                    // the r0-th key (0-based) is >= trial
+            res = trial;
+            lo_cnt = cnt;
+        } else {
+            hi_cnt = cnt;
+        }
+        if (KPL > SEL_CK && b >= 3 && hi_cnt - lo_cnt <= SEL_CK * 64) {
+            compact = true;
+            break;
+        }
+    }
+    if (compact) {
+        __shared__ uint32_t cbuf_all[4][SEL_CK * 64];
+        uint32_t *cbuf = cbuf_all[threadIdx.x >> 6];
+        const uint32_t span = 1u << b;                      // candidates: res <= key < res + span
+        uint32_t base = 0;
+#pragma unroll
+        for (int i = 0; i <= KPL; ++i) {
+            const bool in = key[i] - res < span;
+            const unsigned long long m = __ballot(in);
+            const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (in) cbuf[pos] = key[i];
+            base += (uint32_t)__builtin_popcountll(m);
+            if ((i & 7) == 7) asm volatile("" : "+s"(base));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int i = 0; i < SEL_CK; ++i) ck[i] = lane + 64 * i < (int)base ? cbuf[lane + 64 * i] : 0xFFFFFFFFu;
+        for (--b; b >= 0; --b) {
+            const uint32_t trial = res | (1u << b);
+            const uint32_t cnt = lo_cnt + count_below<SEL_CK>(ck, trial);
+            if (cnt <= r0) res = trial;
+        }
+    }
+    uint32_t k0 = res, k1 = res;
+    if (r1 != r0) {
+        // the next order statistic: the same value if it occurs often enough, else the smallest key above it
+        uint32_t cnt_le = 0, above = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i <= KPL; ++i) {
+            cnt_le += (uint32_t)__builtin_popcountll(__ballot(key[i] <= res));
+            if ((i & 7) == 7) asm volatile("" : "+s"(cnt_le));
+            above = (key[i] > res && key[i] < above) ? key[i] : above;
+        }
+        if (cnt_le <= r1) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const uint32_t o = __shfl_xor(above, d);
+                above = o < above ? o : above;
+            }
+            k1 = above;
+        }
+    }
+    if (lane == 0) out[seg] = select_result<float>(val_of(k0 + kmin), val_of(k1 + kmin), r0 == r1, frac, mode);
+}
+
+static constexpr int64_t SEL_WAVE_MAX = 128 * 64;       // longest row the register-resident kernel takes
+
+template <int XF, bool MASKED>
+static int launch_select_wave(Ctx *c, const float *d_vals, const SelectArgs &a) {
+    MaskedMean mm{a.d_mask, a.mask_div, a.mask_stride, a.d_masked_mean};
+    dim3 grid((unsigned)ceil_div(a.n_seg, 4)), block(256);
+#define ADN_SEL_WAVE(KPLV)                                                                                          \
+    ADN_LAUNCH_NAMED("k_select_wave<" #KPLV ">", (k_select_wave<XF, MASKED, KPLV>), grid, block, 0, c->stream, d_vals,  \
+                     a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len, a.n_seg, a.mode, a.q, a.d_center, \
+                     a.d_out, mm, (c->ablate & 32) ? 0 : 32)
+    if (a.max_len <= 8 * 64) ADN_SEL_WAVE(8);
+    else if (a.max_len <= 24 * 64) ADN_SEL_WAVE(24);
+    else if (a.max_len <= 48 * 64) ADN_SEL_WAVE(48);
+    else if (a.max_len <= 96 * 64) ADN_SEL_WAVE(96);
+    else ADN_SEL_WAVE(128);
+#undef ADN_SEL_WAVE
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
+
 template <typename T>
 int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {
     if (a.n_seg <= 0) return ADN_OK;
@@ -1408,6 +1639,15 @@ int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {
         }
         return a.xform == XF_ABSDEV ? launch_select_big<T, XF_ABSDEV>(c, d_vals, a)
                                     : launch_select_big<T, XF_NONE>(c, d_vals, a);
+    }
+    // binary32 rows of up to a few thousand values: one wave per row, keys in registers
+    if constexpr (std::is_same<T, float>::value) {
+        if (!c->force_generic && a.max_len > 0 && a.max_len <= SEL_WAVE_MAX && a.mode != SEL_PERCENTILE_DB20) {
+            const bool masked = a.d_masked_mean != nullptr;
+            if (a.xform == XF_ABSDEV) return masked ? launch_select_wave<XF_ABSDEV, true>(c, d_vals, a)
+                                                    : launch_select_wave<XF_ABSDEV, false>(c, d_vals, a);
+            return masked ? launch_select_wave<XF_NONE, true>(c, d_vals, a) : launch_select_wave<XF_NONE, false>(c, d_vals, a);
+        }
     }
     // segments whose keys fit LDS take the lean kernel (LDS = the keys, several workgroups per CU)
     if (a.max_len > 0 && (size_t)a.max_len * sizeof(K) <= SEL_LDS_MAX_BYTES) {
