@@ -30,6 +30,7 @@ _PLAIN = {
     "adn_set_option": (_i, [_vp, _i, _i]),
     "adn_workspace_bytes": (_i64, [_vp]),
     "adn_kernel_times": (_i64, [_vp, C.c_char_p, _i64]),
+    "adn_select_resolve": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "adn_wavelet_denoise_noalloc_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i,
                                              _vp, _vp, _vp]),
     "adn_wavelet_out_frames": (_i64, [_i64]),
@@ -51,6 +52,15 @@ _TYPED = {
     "adn_spectral_subtract": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _vp, _i64, _i, _i, _d, _d, _i, _i, _vp, _vp, _vp],
     "adn_wiener": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _d, _i, _i, _vp, _vp, _vp, _vp],
     "adn_window_rms": [_vp, _vp, _i64, _i, _i64, _vp],
+    "adn_wavelet_shrink": [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _vp, _vp],
+    "adn_select_hist": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _vp, _vp, _i, _vp],
+    "adn_select_value": [_vp, _vp, _i64, _vp],
+    "adn_select_combine": [_vp, _vp, _vp, _i64, _i64, _d, _vp],
+    "adn_stft_rows": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _i, _i, _vp, _i64],
+    "adn_vad_frames": [_vp, _vp, _i64, _i, _i64, _i64, _i, _d, _i, _i64, _i64, _vp],
+    "adn_rows_masked_sum": [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp],
+    "adn_wiener_gain": [_vp, _vp, _vp, _i64, _i, _i, _vp],
+    "adn_stft_apply_gain": [_vp, _vp, _i64, _vp, _vp, _i64, _i, _i, _i, _vp, _i64, _vp, _vp, _vp],
     "adn_pcm_encode": [_vp, _vp, _i64, _i, _vp, _vp],
     "adn_synth_noisy_speech": [_vp, _vp, _i64, _i64, _i, _u64, _u64, _d, _d],
 }

@@ -358,6 +358,98 @@ class Engine:
                    int(lens.max()), _ptr(None), _ptr(out))
         return out if len(lens) > 1 else out[0]
 
+    # ------------------------------------------ pieces for recordings split into time chunks
+    def wavelet_shrink(self, x, in_off, frames, out, out_off, thresh, wavelet="db4", level=2, thr_mode="soft",
+                       mode="per", max_frames=None, want_zeroed=False):
+        """Mono blocks shrunk with the thresholds in `thresh` (float64 device tensor, one per block)."""
+        nb = int(frames.numel())
+        if max_frames is None:
+            max_frames = int(frames.max().item()) if nb else 1
+        zeroed = torch.empty(nb, dtype=torch.int64, device=self.torch_device) if want_zeroed else None
+        self._call("adn_wavelet_shrink", x.dtype, _ptr(x), _ptr(out), nb, _ptr(in_off), _ptr(frames), _ptr(out_off),
+                   int(max_frames), WAVELET[wavelet], int(level), EXT[mode], THR[thr_mode], _ptr(thresh), _ptr(zeroed))
+        return zeroed
+
+    def select_hist(self, vals, offs, lens, prefix, done_bits, hist, absdev=False, centers=None, max_len=None):
+        """One round of the distributed order statistic: `hist` (int32 [n_seg, 256]) receives the counts of the next
+        key digit of this holder's values under `prefix` (uint64 keys as int64 tensor)."""
+        n_seg = int(lens.numel())
+        if max_len is None:
+            max_len = int(lens.max().item()) if n_seg else 0
+        self._call("adn_select_hist", vals.dtype, _ptr(vals), n_seg, _ptr(offs), _ptr(lens), int(max_len),
+                   int(bool(absdev)), _ptr(centers), _ptr(prefix), int(done_bits), _ptr(hist))
+
+    def select_resolve(self, hist, key_bits, done_bits, rank, prefix):
+        self.use_current_stream()
+        self._check(self.lib.adn_select_resolve(self._h, _ptr(hist), int(rank.numel()), int(key_bits), int(done_bits),
+                                                _ptr(rank), _ptr(prefix)))
+
+    def select_value(self, prefix, dtype):
+        out = torch.empty(prefix.numel(), dtype=torch.float64, device=self.torch_device)
+        self._call("adn_select_value", dtype, _ptr(prefix), int(prefix.numel()), _ptr(out))
+        return out
+
+    def select_combine(self, lo, hi, n_values, q, dtype):
+        """Median (q=None) or percentile q of segments of n_values values from the two bracketing order statistics."""
+        out = torch.empty_like(lo)
+        self._call("adn_select_combine", dtype, _ptr(lo), _ptr(hi), int(lo.numel()), int(n_values),
+                   -1.0 if q is None else float(q), _ptr(out))
+        return out
+
+    def stft_rows(self, x, lens, n_ch=1, n_fft=2048, hop=512, padded=True, power=True, offsets=None):
+        """|Z|^2 (or |Z|) rows of a batch: returns (S[n_sig, F, Ts], frame counts)."""
+        starts, lens = self._signals(lens, n_ch, n_fft)
+        if offsets is not None:
+            starts = np.asarray(offsets, dtype=np.int64)
+        frames = np.array([self.stft_num_frames(n, n_fft, hop, padded) for n in lens], dtype=np.int64)
+        ts = (int(frames.max()) + 31) // 32 * 32
+        S = torch.zeros((len(lens), n_fft // 2 + 1, ts), dtype=x.dtype, device=x.device)
+        d_off, d_len = self._i64(starts), self._i64(lens)
+        self._call("adn_stft_rows", x.dtype, _ptr(x), len(lens), _ptr(d_off), _ptr(d_len), int(lens.max()), int(n_ch),
+                   int(n_fft), int(hop), int(bool(padded)), int(bool(power)), _ptr(S), ts)
+        return S, frames
+
+    def vad_frames(self, buf, base_sample, n_total, sample_rate, t0, n_frames, update_ms=20, hop=512, n_ch=1):
+        """Energy-VAD flags of STFT frames t0 .. t0 + n_frames - 1 of a signal of n_total samples; `buf` holds the
+        signal's samples from `base_sample` on."""
+        vad = torch.empty(int(n_frames), dtype=torch.uint8, device=buf.device)
+        n_buf = int(buf.shape[0]) if buf.dim() > 1 else int(buf.numel()) // n_ch
+        self._call("adn_vad_frames", buf.dtype, _ptr(buf), n_buf, int(n_ch), int(base_sample), int(n_total),
+                   int(sample_rate), float(update_ms), int(hop), int(t0), int(n_frames), _ptr(vad))
+        return vad
+
+    def rows_masked_sum(self, S, row_len, mask):
+        """(sums[n_rows] float64, count) over the masked frames of the rows of S[n_rows, stride]."""
+        n_rows, stride = int(S.shape[0]), int(S.shape[1])
+        sums = torch.empty(n_rows, dtype=torch.float64, device=S.device)
+        count = torch.zeros(1, dtype=torch.int64, device=S.device)
+        self._call("adn_rows_masked_sum", S.dtype, _ptr(S), n_rows, int(row_len), stride, _ptr(mask), _ptr(sums),
+                   _ptr(count))
+        return sums, count
+
+    def wiener_gain(self, noise_psd, speech_psd, dtype, kernel_bins=5):
+        """Per-bin gain rows from float64 [n_sig, F] statistics."""
+        n_sig, F = int(noise_psd.shape[0]), int(noise_psd.shape[1])
+        gain = torch.empty((n_sig, F), dtype=dtype, device=noise_psd.device)
+        self._call("adn_wiener_gain", dtype, _ptr(noise_psd.contiguous()), _ptr(speech_psd.contiguous()), n_sig, F,
+                   int(kernel_bins), _ptr(gain))
+        return gain
+
+    def stft_apply_gain(self, x, lens, gain, n_ch=1, n_fft=2048, hop=512, offsets=None):
+        """STFT -> Z * gain -> ISTFT -> clip.  gain: (F,) shared or (n_sig, F).  Returns (y, out_lens)."""
+        starts, lens = self._signals(lens, n_ch, n_fft)
+        if offsets is not None:
+            starts = np.asarray(offsets, dtype=np.int64)
+        out_lens = np.array([self.istft_out_samples(n, n_fft, hop) for n in lens], dtype=np.int64)
+        out_offsets = np.concatenate([[0], np.cumsum(out_lens)[:-1]]).astype(np.int64)
+        out = self._out_buffer(int(out_lens.sum()), x)
+        gain = gain.to(dtype=x.dtype, device=x.device).contiguous()
+        stride = 0 if gain.dim() == 1 else gain.shape[1]
+        d_off, d_len, d_yoff = self._i64(starts), self._i64(lens), self._i64(out_offsets)
+        self._call("adn_stft_apply_gain", x.dtype, _ptr(x), len(lens), _ptr(d_off), _ptr(d_len), int(lens.max()),
+                   int(n_ch), int(n_fft), int(hop), _ptr(gain), int(stride), _ptr(out), _ptr(d_yoff), _ptr(None))
+        return out, out_lens
+
     # ------------------------------------------------------------------ misc
     def window_rms(self, x, win):
         n_rows = int(x.shape[0])

@@ -212,6 +212,12 @@ int adn_synchronize(adn_ctx *c) {
 
 int64_t adn_workspace_bytes(adn_ctx *c) { return c ? (int64_t)c->ws_bytes : 0; }
 
+int adn_select_resolve(adn_ctx *c, const uint32_t *d_hist, int64_t n_seg, int key_bits, int done_bits, int64_t *d_rank,
+                       uint64_t *d_prefix) {
+    return adn::select_resolve(c, d_hist, n_seg, key_bits, done_bits, reinterpret_cast<long long *>(d_rank),
+                               reinterpret_cast<unsigned long long *>(d_prefix));
+}
+
 int64_t adn_wavelet_out_frames(int64_t frames) { return 2 * ((frames + 1) / 2); }
 
 int64_t adn_denoise_block_frames(int64_t rate, int64_t frames) {
@@ -300,6 +306,62 @@ int64_t adn_istft_out_samples(int64_t n, int n_fft, int hop) {
                          T *d_y, const int64_t *d_y_off, T *d_gain, int16_t *d_pcm16) {             \
         return adn::wiener<T>(c, d_x, n_sig, d_off, d_len, max_len, n_ch, sample_rate, n_fft, hop,  \
                               update_ms, kernel_bins, vad_guided, d_y, d_y_off, d_gain, d_pcm16);   \
+    }                                                                                               \
+    int adn_wavelet_shrink_##SUF(adn_ctx *c, const T *d_in, T *d_out, int64_t n_blocks,             \
+                                 const int64_t *d_in_off, const int64_t *d_frames,                  \
+                                 const int64_t *d_out_off, int64_t max_frames, int wavelet,         \
+                                 int level, int ext_mode, int thr_mode, const double *d_thresh,     \
+                                 int64_t *d_zeroed) {                                               \
+        return adn::wavelet_shrink<T>(c, d_in, d_out, n_blocks, d_in_off, d_frames, d_out_off,      \
+                                      max_frames, wavelet, level, ext_mode, thr_mode, d_thresh,     \
+                                      d_zeroed);                                                    \
+    }                                                                                               \
+    int adn_select_hist_##SUF(adn_ctx *c, const T *d_vals, int64_t n_seg, const int64_t *d_off,     \
+                              const int64_t *d_len, int64_t max_len, int absdev,                    \
+                              const double *d_center, const uint64_t *d_prefix, int done_bits,      \
+                              uint32_t *d_hist) {                                                   \
+        return adn::select_hist<T>(c, d_vals, n_seg, d_off, d_len, max_len, absdev, d_center,       \
+                                   reinterpret_cast<const unsigned long long *>(d_prefix),          \
+                                   done_bits, d_hist);                                              \
+    }                                                                                               \
+    int adn_select_value_##SUF(adn_ctx *c, const uint64_t *d_prefix, int64_t n_seg, double *d_out) { \
+        return adn::select_value<T>(c, reinterpret_cast<const unsigned long long *>(d_prefix),      \
+                                    n_seg, d_out);                                                  \
+    }                                                                                               \
+    int adn_select_combine_##SUF(adn_ctx *c, const double *d_lo, const double *d_hi, int64_t n_seg, \
+                                 int64_t n_values, double q, double *d_out) {                       \
+        return adn::select_combine<T>(c, d_lo, d_hi, n_seg, n_values, q, d_out);                    \
+    }                                                                                               \
+    int adn_stft_rows_##SUF(adn_ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off,          \
+                            const int64_t *d_len, int64_t max_len, int n_ch, int n_fft, int hop,    \
+                            int padded, int power, T *d_S, int64_t row_stride) {                    \
+        return adn::stft_rows<T>(c, d_x, n_sig, d_off, d_len, max_len, n_ch, n_fft, hop, padded,    \
+                                 power, d_S, row_stride);                                           \
+    }                                                                                               \
+    int adn_vad_frames_##SUF(adn_ctx *c, const T *d_x, int64_t n_buf, int n_ch,                     \
+                             int64_t base_sample, int64_t n_total, int sample_rate,                 \
+                             double update_ms, int hop, int64_t t0, int64_t n_frames,               \
+                             uint8_t *d_vad) {                                                      \
+        return adn::vad_frames<T>(c, d_x, n_buf, n_ch, base_sample, n_total, sample_rate,           \
+                                  update_ms, hop, t0, n_frames, d_vad);                             \
+    }                                                                                               \
+    int adn_rows_masked_sum_##SUF(adn_ctx *c, const T *d_S, int64_t n_rows, int64_t row_len,        \
+                                  int64_t row_stride, const uint8_t *d_mask, double *d_sum,         \
+                                  int64_t *d_count) {                                               \
+        return adn::rows_masked_sum<T>(c, d_S, n_rows, row_len, row_stride, d_mask, d_sum,          \
+                                       reinterpret_cast<long long *>(d_count));                     \
+    }                                                                                               \
+    int adn_wiener_gain_##SUF(adn_ctx *c, const double *d_noise_psd, const double *d_speech_psd,    \
+                              int64_t n_sig, int n_bins, int kernel_bins, T *d_gain) {              \
+        return adn::wiener_gain<T>(c, d_noise_psd, d_speech_psd, n_sig, n_bins, kernel_bins,        \
+                                   d_gain);                                                         \
+    }                                                                                               \
+    int adn_stft_apply_gain_##SUF(adn_ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off,    \
+                                  const int64_t *d_len, int64_t max_len, int n_ch, int n_fft,       \
+                                  int hop, const T *d_gain, int64_t gain_stride, T *d_y,            \
+                                  const int64_t *d_y_off, int16_t *d_pcm16) {                       \
+        return adn::stft_apply_gain<T>(c, d_x, n_sig, d_off, d_len, max_len, n_ch, n_fft, hop,      \
+                                       d_gain, gain_stride, d_y, d_y_off, d_pcm16);                 \
     }                                                                                               \
     int adn_window_rms_##SUF(adn_ctx *c, const T *d_x, int64_t n_rows, int n_ch, int64_t win,       \
                              double *d_rms) {                                                       \

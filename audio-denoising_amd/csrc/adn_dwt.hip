@@ -120,8 +120,8 @@ __global__ __launch_bounds__(256) void k_fwd_level(const T *__restrict__ x, T *_
         int i = (int)((2 * k + F / 2) % Mi);
         for (int j = 0; j < F; ++j) {
             const T v = in[i < Ni ? i : Ni - 1];
-            sa += tp.h[j] * v;
-            sd += tp.g[j] * v;
+            sa = fma(tp.h[j], v, sa);
+            sd = fma(tp.g[j], v, sd);
             i = i == 0 ? Mi - 1 : i - 1;
         }
     } else {
@@ -130,8 +130,8 @@ __global__ __launch_bounds__(256) void k_fwd_level(const T *__restrict__ x, T *_
             if (i < 0) i += 2 * N;
             if (i >= N) i = 2 * N - 1 - i;
             const T v = in[i];
-            sa += tp.h[j] * v;
-            sd += tp.g[j] * v;
+            sa = fma(tp.h[j], v, sa);
+            sd = fma(tp.g[j], v, sd);
         }
     }
     cA[k] = sa;
@@ -180,7 +180,8 @@ __global__ __launch_bounds__(256) void k_inv_level(T *__restrict__ y, T *__restr
             for (int j = par; j < F; j += 2) {
                 T dv = d[k];
                 if (do_thr) dv = shrink(dv, t, thr_mode);
-                s += tp.rl[j] * a[k] + tp.rh[j] * dv;
+                s = fma(tp.rl[j], a[k], s);
+                s = fma(tp.rh[j], dv, s);
                 k = k == 0 ? Ki - 1 : k - 1;
             }
         } else {
@@ -190,7 +191,8 @@ __global__ __launch_bounds__(256) void k_inv_level(T *__restrict__ y, T *__restr
                 if (u < 0 || (u & 1) || (u >> 1) >= K) continue;
                 T dv = d[u >> 1];
                 if (do_thr) dv = shrink(dv, t, thr_mode);
-                s += tp.rl[j] * a[u >> 1] + tp.rh[j] * dv;
+                s = fma(tp.rl[j], a[u >> 1], s);
+                s = fma(tp.rh[j], dv, s);
             }
         }
         out[n] = s;
@@ -559,7 +561,7 @@ static int channel_denoise(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t
 template <typename T>
 static int general_denoise(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_frames,
                            int wavelet, int level, int ext, int thr_mode, double *d_sigma,
-                           double *d_thresh, int64_t *d_zeroed) {
+                           double *d_thresh, int64_t *d_zeroed, const double *d_thresh_given) {
     const Taps<T> tp = make_taps<T>(wavelet);
     const int F = tp.F;
     // symmetric synthesis of level l writes 2 K - F + 2 values, one more than the band above
@@ -577,8 +579,8 @@ static int general_denoise(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t
         ADN_LAUNCH((k_fwd_level<T>), dim3((unsigned)(tiles * g.n_blocks)), dim3(256), 0,
                            c->stream, d_in, A0, A1, D, g, l, ext, tp, tiles);
     }
-    double *thresh = nullptr;
-    ADN_TRY(mad_threshold<T>(c, D, g, F, ext, 0, max_seg, d_sigma, d_thresh, &thresh));
+    double *thresh = const_cast<double *>(d_thresh_given);
+    if (!d_thresh_given) ADN_TRY(mad_threshold<T>(c, D, g, F, ext, 0, max_seg, d_sigma, d_thresh, &thresh));
     for (int l = level; l >= 1; --l) {
         const int64_t tiles = ceil_div(2 * band_len(max_frames, l, F, ext), 256);
         ADN_LAUNCH((k_inv_level<T>), dim3((unsigned)(tiles * g.n_blocks)), dim3(256), 0,
@@ -593,15 +595,15 @@ static int general_denoise(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t
 template <typename T>
 static int mono_denoise(Ctx *c, const T *d_in, T *d_out, const BlockGeom &g, int64_t max_frames,
                         int wavelet, int level, int ext, int thr_mode, double *d_sigma,
-                        double *d_thresh, int64_t *d_zeroed) {
+                        double *d_thresh, int64_t *d_zeroed, const double *d_thresh_given = nullptr) {
     if (ext == ADN_EXT_PERIODIZATION) {
         bool handled = false;
         ADN_TRY(wavelet_denoise_fused<T>(c, d_in, d_out, g, max_frames, wavelet, level, thr_mode,
-                                         d_sigma, d_thresh, d_zeroed, &handled));
+                                         d_sigma, d_thresh, d_zeroed, d_thresh_given, &handled));
         if (handled) return ADN_OK;
     }
     return general_denoise<T>(c, d_in, d_out, g, max_frames, wavelet, level, ext, thr_mode, d_sigma,
-                              d_thresh, d_zeroed);
+                              d_thresh, d_zeroed, d_thresh_given);
 }
 
 // ADN_AXIS_TIME on interleaved multi-channel blocks: channel ch of block b becomes the mono block
@@ -698,6 +700,28 @@ int wavelet_denoise(Ctx *c, const T *d_in, T *d_out, int64_t n_blocks, const int
         case 6: return channel_denoise<T, 6>(c, d_in, d_out, g, max_frames, m, thr_mode, d_sigma, d_thresh, d_zeroed);
         default: return channel_denoise<T, 8>(c, d_in, d_out, g, max_frames, m, thr_mode, d_sigma, d_thresh, d_zeroed);
     }
+}
+
+// Mono blocks shrunk with thresholds the caller hands in (one per block): the statistics of a block
+// that is shared between devices are reduced outside, every device then shrinks its part of the block.
+template <typename T>
+int wavelet_shrink(Ctx *c, const T *d_in, T *d_out, int64_t n_blocks, const int64_t *d_in_off,
+                   const int64_t *d_frames, const int64_t *d_out_off, int64_t max_frames, int wavelet, int level,
+                   int ext_mode, int thr_mode, const double *d_thresh, int64_t *d_zeroed) {
+    ADN_REQUIRE(c && d_in && d_out && d_in_off && d_frames && d_out_off && d_thresh, "null pointer argument");
+    ADN_REQUIRE(n_blocks >= 0 && max_frames >= 1, "n_blocks must be >= 0 and max_frames >= 1");
+    ADN_REQUIRE(wavelet == ADN_WAVELET_DB4 || wavelet == ADN_WAVELET_DB8, "unknown wavelet id %d", wavelet);
+    ADN_REQUIRE(level >= 1 && level <= 16, "level must be in [1, 16], got %d", level);
+    ADN_REQUIRE(thr_mode == ADN_THR_SOFT || thr_mode == ADN_THR_HARD, "unknown threshold mode %d", thr_mode);
+    ADN_REQUIRE(ext_mode == ADN_EXT_PERIODIZATION || ext_mode == ADN_EXT_SYMMETRIC, "unknown extension mode %d", ext_mode);
+    if (n_blocks == 0) return ADN_OK;
+    ADN_REQUIRE(n_blocks * ceil_div(max_frames, 256) < (int64_t)0x7FFFFFFF, "batch too large for one launch");
+    DeviceGuard dg(c->device);
+    ws_reset(c);
+    if (d_zeroed) ADN_HIP(hipMemsetAsync(d_zeroed, 0, sizeof(int64_t) * n_blocks, c->stream));
+    BlockGeom g{d_in_off, d_frames, d_out_off, n_blocks, 0, 0};
+    return mono_denoise<T>(c, d_in, d_out, g, max_frames, wavelet, level, ext_mode, thr_mode, nullptr, nullptr, d_zeroed,
+                           d_thresh);
 }
 
 // ------------------------------------------- single-signal wavedec / waverec
@@ -807,6 +831,8 @@ int waverec(Ctx *c, const T *d_coeffs, const int64_t *h_band_len, int wavelet, i
     template int wavelet_denoise<T>(Ctx *, const T *, T *, int64_t, const int64_t *,              \
                                     const int64_t *, const int64_t *, int64_t, int, int, int, int, \
                                     int, int, double *, double *, int64_t *);                     \
+    template int wavelet_shrink<T>(Ctx *, const T *, T *, int64_t, const int64_t *, const int64_t *,  \
+                                   const int64_t *, int64_t, int, int, int, int, const double *, int64_t *); \
     template int wavedec<T>(Ctx *, const T *, int64_t, int, int, int, T *, int64_t, int64_t *);   \
     template int waverec<T>(Ctx *, const T *, const int64_t *, int, int, int, T *, int64_t, int64_t *);
 ADN_INST(float)

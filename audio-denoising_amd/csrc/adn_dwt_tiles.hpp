@@ -294,8 +294,8 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
                 for (int j = 0; j < F; ++j) {
                     const int q = idx < Ns ? idx : Ns - 1;
                     const T v = src[rg_local(sr, q)];
-                    sa += tp.h[j] * v;
-                    sd += tp.g[j] * v;
+                    sa = fma(tp.h[j], v, sa);           // the interior path's operation order, so that a
+                    sd = fma(tp.g[j], v, sd);           // sample's result does not depend on its tile
                     idx = idx == 0 ? Ms - 1 : idx - 1;
                 }
                 dA[i] = sa;
@@ -397,7 +397,8 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
                     const int li = rg_local(ir, k);
                     const T cl = par ? tp.rl[2 * q + 1] : tp.rl[2 * q];
                     const T ch = par ? tp.rh[2 * q + 1] : tp.rh[2 * q];
-                    s += cl * ra[li] + ch * rd[li];
+                    s = fma(cl, ra[li], s);
+                    s = fma(ch, rd[li], s);
                     k = k == 0 ? K - 1 : k - 1;
                 }
                 out[i] = s;
@@ -449,8 +450,8 @@ __global__ __launch_bounds__(512) void k_deep(T *__restrict__ top, int64_t top_s
 #pragma unroll
             for (int j = 0; j < F; ++j) {
                 const T v = src[idx < Ns ? idx : Ns - 1];
-                sa += tp.h[j] * v;
-                sd += tp.g[j] * v;
+                sa = fma(tp.h[j], v, sa);
+                sd = fma(tp.g[j], v, sd);
                 idx = idx == 0 ? Ms - 1 : idx - 1;
             }
             dA[k] = sa;
@@ -486,7 +487,8 @@ __global__ __launch_bounds__(512) void k_deep(T *__restrict__ top, int64_t top_s
             for (int q = 0; q < F / 2; ++q) {
                 const T cl = par ? tp.rl[2 * q + 1] : tp.rl[2 * q];
                 const T ch = par ? tp.rh[2 * q + 1] : tp.rh[2 * q];
-                s += cl * ra[k] + ch * rd[k];
+                s = fma(cl, ra[k], s);
+                s = fma(ch, rd[k], s);
                 k = k == 0 ? K - 1 : k - 1;
             }
             out[nn] = s;
@@ -540,7 +542,7 @@ static size_t deep_lds_bytes(int64_t max_frames, int TL, int L) {
 template <typename T, int F>
 static int denoise_f(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_frames, int wavelet,
                      int level, int thr_mode, double *d_sigma, double *d_thresh, int64_t *d_zeroed,
-                     bool *handled) {
+                     const double *d_thresh_given, bool *handled) {
     const int TL = level < TL_MAX ? level : TL_MAX;
     const bool deep = level > TL;
     size_t deep_lds = 0;
@@ -558,15 +560,18 @@ static int denoise_f(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_f
                               mad_ws_bytes(g.n_blocks, (max_frames + 1) / 2)));
     T *D1 = ws_take<T>(c, nD);
     T *top = deep ? ws_take<T>(c, nT) : nullptr;
+    // thresholds handed in by the caller (a block shared between devices): no statistics; the first
+    // pass still runs when the deep levels need the level-TL approximation it writes
     if (deep)
         launch_tile_tl<T, F, MODE_STATS>(c, TL, d_in, (T *)nullptr, g, max_frames, wavelet, nullptr, thr_mode,
                                          nullptr, D1, d1_stride, top, top_stride, 0);
-    else
+    else if (!d_thresh_given)
         launch_tile_tl<T, F, MODE_STATS>(c, 1, d_in, (T *)nullptr, g, max_frames, wavelet, nullptr, thr_mode,
                                          nullptr, D1, d1_stride, (T *)nullptr, 0, 0);
-    double *thresh = nullptr;
-    ADN_TRY(mad_threshold<T>(c, D1, g, F, ADN_EXT_PERIODIZATION, 0, (max_frames + 1) / 2, d_sigma, d_thresh,
-                             &thresh));
+    double *thresh = const_cast<double *>(d_thresh_given);
+    if (!d_thresh_given)
+        ADN_TRY(mad_threshold<T>(c, D1, g, F, ADN_EXT_PERIODIZATION, 0, (max_frames + 1) / 2, d_sigma, d_thresh,
+                                 &thresh));
     if (deep) {
         const TapsF<T, F> tp = make_taps_f<T, F>(wavelet);
         if (deep_lds > 48 * 1024)
@@ -590,14 +595,14 @@ static int denoise_f(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_f
 template <typename T>
 static int wavelet_denoise_fused(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_frames,
                                  int wavelet, int level, int thr_mode, double *d_sigma,
-                                 double *d_thresh, int64_t *d_zeroed, bool *handled) {
+                                 double *d_thresh, int64_t *d_zeroed, const double *d_thresh_given, bool *handled) {
     *handled = false;
     if (c->force_generic || max_frames >= (int64_t(1) << 30)) return ADN_OK;
     const int64_t tiles = ceil_div(max_frames + 1, tiles::TileS<T>::S);
     if (tiles * g.n_blocks >= (int64_t)0x7FFFFFFF) return ADN_OK;
     if (filter_bank(wavelet).F == 8)
         return tiles::denoise_f<T, 8>(c, d_in, d_out, g, max_frames, wavelet, level, thr_mode, d_sigma,
-                                      d_thresh, d_zeroed, handled);
+                                      d_thresh, d_zeroed, d_thresh_given, handled);
     return tiles::denoise_f<T, 16>(c, d_in, d_out, g, max_frames, wavelet, level, thr_mode, d_sigma,
-                                   d_thresh, d_zeroed, handled);
+                                   d_thresh, d_zeroed, d_thresh_given, handled);
 }

@@ -98,6 +98,39 @@ int hpss_separate(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, con
                   int preserve_transients, double threshold, double blend, T *d_yh, T *d_yp,
                   const int64_t *d_y_off, double *d_stats);
 
+// ------------------------------------------- one recording split over devices
+template <typename T>
+int wavelet_shrink(Ctx *c, const T *d_in, T *d_out, int64_t n_blocks, const int64_t *d_in_off,
+                   const int64_t *d_frames, const int64_t *d_out_off, int64_t max_frames, int wavelet, int level,
+                   int ext_mode, int thr_mode, const double *d_thresh, int64_t *d_zeroed);
+template <typename T>
+int select_hist(Ctx *c, const T *d_vals, int64_t n_seg, const int64_t *d_off, const int64_t *d_len, int64_t max_len,
+                int absdev, const double *d_center, const unsigned long long *d_prefix, int done_bits,
+                unsigned int *d_hist);
+int select_resolve(Ctx *c, const unsigned int *d_hist, int64_t n_seg, int key_bits, int done_bits, long long *d_rank,
+                   unsigned long long *d_prefix);
+template <typename T>
+int select_value(Ctx *c, const unsigned long long *d_prefix, int64_t n_seg, double *d_out);
+template <typename T>
+int select_combine(Ctx *c, const double *d_lo, const double *d_hi, int64_t n_seg, int64_t n_values, double q,
+                   double *d_out);
+template <typename T>
+int stft_rows(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int64_t *d_len, int64_t max_len, int n_ch,
+              int n_fft, int hop, int padded, int power, T *d_S, int64_t row_stride);
+template <typename T>
+int vad_frames(Ctx *c, const T *d_x, int64_t n_buf, int n_ch, int64_t base_sample, int64_t n_total, int sample_rate,
+               double update_ms, int hop, int64_t t0, int64_t n_frames, unsigned char *d_vad);
+template <typename T>
+int rows_masked_sum(Ctx *c, const T *d_S, int64_t n_rows, int64_t row_len, int64_t row_stride, const unsigned char *d_mask,
+                    double *d_sum, long long *d_count);
+template <typename T>
+int wiener_gain(Ctx *c, const double *d_noise_psd, const double *d_speech_psd, int64_t n_sig, int n_bins, int kernel_bins,
+                T *d_gain);
+template <typename T>
+int stft_apply_gain(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int64_t *d_len, int64_t max_len,
+                    int n_ch, int n_fft, int hop, const T *d_gain, int64_t gain_stride, T *d_y, const int64_t *d_y_off,
+                    int16_t *d_pcm16);
+
 // ------------------------------------------------------------------ misc
 template <typename T>
 int window_rms(Ctx *c, const T *d_x, int64_t n_rows, int n_ch, int64_t win, double *d_rms);

@@ -43,8 +43,28 @@ __device__ __forceinline__ void hist_add_matched(uint32_t *hist, uint32_t digit,
 // count is the mean of the middle pair; percentiles interpolate linearly with numpy's t >= 0.5
 // branch, in the array's dtype).  SEL_PERCENTILE_DB20 interpolates 20*log10(v + 1e-12) of the two
 // order statistics instead (the percentile of a dB-converted array, in binary64: the map is monotone).
+// The two ranks that bracket the statistic of n values and the interpolation weight between them:
+// numpy.median (ranks (n-1)/2 and n/2) or numpy.percentile's 'linear' method (virtual index (n-1) q/100,
+// rounded before its fraction is taken, as numpy does).
+__host__ __device__ inline void stat_ranks(int64_t n, int mode, double q, int64_t *r0, int64_t *r1, double *frac) {
+#pragma clang fp contract(off)
+    if (mode == SEL_MEDIAN) {
+        *r0 = (n - 1) / 2;
+        *r1 = n / 2;
+        *frac = 0.5;
+        return;
+    }
+    const double pos = (double)(n - 1) * (q / 100.0);
+    int64_t lo = (int64_t)floor(pos);
+    if (lo > n - 1) lo = n - 1;
+    *r0 = lo;
+    *frac = pos - (double)lo;
+    *r1 = lo + 1 < n ? lo + 1 : n - 1;
+}
+
 template <typename T>
 __device__ __forceinline__ double select_result(T a, T b, bool same, double frac, int mode) {
+#pragma clang fp contract(off)   // numpy rounds the product and the sum separately
     if (mode == SEL_MEDIAN) return same ? (double)a : (double)(T)((a + b) / (T)2);
     double da = (double)a, db = (double)b;
     if (mode == SEL_PERCENTILE_DB20) {
@@ -135,17 +155,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select(const T *__restrict__ va
     {
         // ranks come from the length of the ORIGINAL segment
         const int64_t nr = sub.below ? (sub.orig_len ? sub.orig_len[seg / sub.orig_div] : sub.orig_uniform) : n;
-        if (mode == SEL_MEDIAN) {
-            r0 = (nr - 1) / 2;
-            r1 = nr / 2;
-            frac = 0.5;
-        } else {
-            const double pos = (double)(nr - 1) * (q / 100.0);
-            r0 = (int64_t)floor(pos);
-            if (r0 > nr - 1) r0 = nr - 1;
-            frac = pos - (double)r0;
-            r1 = r0 + 1 < nr ? r0 + 1 : nr - 1;
-        }
+        stat_ranks(nr, mode, q, &r0, &r1, &frac);
         if (sub.below) {
             r0 -= (int64_t)sub.below[seg];
             r1 -= (int64_t)sub.below[seg];
@@ -442,17 +452,7 @@ __global__ __launch_bounds__(NT) void k_select_lds(const T *__restrict__ vals,
     double frac;
     {
         const int64_t nr = sub.below ? (sub.orig_len ? sub.orig_len[seg / sub.orig_div] : sub.orig_uniform) : n;
-        if (mode == SEL_MEDIAN) {
-            r0l = (nr - 1) / 2;
-            r1l = nr / 2;
-            frac = 0.5;
-        } else {
-            const double pos = (double)(nr - 1) * (q / 100.0);
-            r0l = (int64_t)floor(pos);
-            if (r0l > nr - 1) r0l = nr - 1;
-            frac = pos - (double)r0l;
-            r1l = r0l + 1 < nr ? r0l + 1 : nr - 1;
-        }
+        stat_ranks(nr, mode, q, &r0l, &r1l, &frac);
         if (sub.below) {
             r0l -= (int64_t)sub.below[seg];
             r1l -= (int64_t)sub.below[seg];
@@ -710,18 +710,7 @@ struct BigState {            // per segment
 };
 
 __device__ __forceinline__ void big_ranks(int64_t n, int mode, double q, int64_t *r0, int64_t *r1, double *frac) {
-    if (mode == SEL_MEDIAN) {
-        *r0 = (n - 1) / 2;
-        *r1 = n / 2;
-        *frac = 0.5;
-    } else {
-        const double pos = (double)(n - 1) * (q / 100.0);
-        int64_t lo = (int64_t)floor(pos);
-        if (lo > n - 1) lo = n - 1;
-        *r0 = lo;
-        *frac = pos - (double)lo;
-        *r1 = lo + 1 < n ? lo + 1 : n - 1;
-    }
+    stat_ranks(n, mode, q, r0, r1, frac);
 }
 
 __global__ void k_big_init(BigState *st, const int64_t *seg_len, int64_t len_div, int64_t uniform_len,
@@ -1396,6 +1385,150 @@ static int launch_select_big(Ctx *c, const T *d_vals, const SelectArgs &a) {
     ADN_HIP(hipGetLastError());
     return ADN_OK;
 }
+
+// ----------------------------------------------------------------------------
+// Order statistics of a segment that is SPLIT over several devices (or over several calls): the
+// selection is an 8-bit MSD radix descent whose only shared state is, per segment, the key prefix
+// decided so far and the rank that remains below it.  Every holder of a part histograms the next
+// digit of its keys under the prefix (select_hist); the histograms are summed outside (an
+// all-reduce of n_seg x 256 counters); every holder then takes the same decision from the sum
+// (select_resolve).  After key-bits / 8 rounds the prefix is the key of the wanted order statistic.
+template <typename T, int XF>
+__global__ __launch_bounds__(256) void k_part_hist(const T *__restrict__ vals, const int64_t *__restrict__ seg_off,
+                                                   const int64_t *__restrict__ seg_len, const double *__restrict__ center,
+                                                   const unsigned long long *__restrict__ prefix, int done_bits,
+                                                   unsigned int *__restrict__ hist, int64_t tiles_per_seg) {
+    using K = typename KeyT<T>::type;
+    constexpr int BITS = KeyT<T>::bits;
+    __shared__ unsigned int lh[256];
+    const int64_t seg = blockIdx.x / tiles_per_seg, tile = blockIdx.x % tiles_per_seg;
+    const int64_t n = seg_len[seg];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    const T c = XF == XF_ABSDEV ? (T)center[seg] : (T)0;
+    const T *v = vals + seg_off[seg];
+    const K pre = (K)prefix[seg];
+    const int shift = BITS - done_bits - 8;                 // position of the digit to histogram
+    const int64_t i0 = tile * 4096, i1 = i0 + 4096 < n ? i0 + 4096 : n;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        T x = v[i];
+        if (XF == XF_ABSDEV) x = fabs(x - c);
+        const K k = x != x ? ~(K)0 : key_of(x);
+        const bool match = done_bits == 0 || (k >> (BITS - done_bits)) == (pre >> (BITS - done_bits));
+        if (match) atomicAdd(&lh[(unsigned)(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    const unsigned int h = lh[threadIdx.x];
+    if (h) atomicAdd(&hist[seg * 256 + threadIdx.x], h);
+}
+
+__global__ void k_part_resolve(const unsigned int *__restrict__ hist, int64_t n_seg, int key_bits, int done_bits,
+                               long long *__restrict__ rank, unsigned long long *__restrict__ prefix) {
+    const int64_t seg = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (seg >= n_seg) return;
+    long long r = rank[seg];
+    const unsigned int *h = hist + seg * 256;
+    int d = 0;
+    long long below = 0;
+    for (; d < 255; ++d) {
+        if (r < below + (long long)h[d]) break;
+        below += h[d];
+    }
+    rank[seg] = r - below;
+    prefix[seg] |= (unsigned long long)d << (key_bits - done_bits - 8);
+}
+
+template <typename T>
+__global__ void k_part_value(const unsigned long long *__restrict__ prefix, int64_t n_seg, double *__restrict__ out) {
+    using K = typename KeyT<T>::type;
+    const int64_t seg = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (seg >= n_seg) return;
+    const K k = (K)prefix[seg];
+    out[seg] = k == ~(K)0 ? __longlong_as_double(0x7FF8000000000000ll) : (double)val_of(k);
+}
+
+template <typename T>
+int select_hist(Ctx *c, const T *d_vals, int64_t n_seg, const int64_t *d_off, const int64_t *d_len, int64_t max_len,
+                int absdev, const double *d_center, const unsigned long long *d_prefix, int done_bits,
+                unsigned int *d_hist) {
+    ADN_REQUIRE(c && d_vals && d_off && d_len && d_prefix && d_hist, "null pointer argument");
+    ADN_REQUIRE(!absdev || d_center, "the absolute-deviation transform needs the centres");
+    ADN_REQUIRE(done_bits >= 0 && done_bits % 8 == 0 && done_bits < KeyT<T>::bits, "done_bits must be a multiple of 8 below %d",
+                KeyT<T>::bits);
+    ADN_REQUIRE(n_seg >= 0 && max_len >= 0, "negative size");
+    if (n_seg == 0) return ADN_OK;
+    DeviceGuard dg(c->device);
+    ADN_HIP(hipMemsetAsync(d_hist, 0, sizeof(unsigned int) * 256 * n_seg, c->stream));
+    const int64_t tiles = ceil_div(max_len > 0 ? max_len : 1, (int64_t)4096);
+    ADN_REQUIRE(n_seg * tiles < (int64_t)0x7FFFFFFF, "batch too large for one launch");
+    if (absdev)
+        ADN_LAUNCH((k_part_hist<T, XF_ABSDEV>), dim3((unsigned)(n_seg * tiles)), dim3(256), 0, c->stream, d_vals, d_off, d_len,
+                   d_center, d_prefix, done_bits, d_hist, tiles);
+    else
+        ADN_LAUNCH((k_part_hist<T, XF_NONE>), dim3((unsigned)(n_seg * tiles)), dim3(256), 0, c->stream, d_vals, d_off, d_len,
+                   d_center, d_prefix, done_bits, d_hist, tiles);
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
+
+int select_resolve(Ctx *c, const unsigned int *d_hist, int64_t n_seg, int key_bits, int done_bits, long long *d_rank,
+                   unsigned long long *d_prefix) {
+    ADN_REQUIRE(c && d_hist && d_rank && d_prefix, "null pointer argument");
+    ADN_REQUIRE((key_bits == 32 || key_bits == 64) && done_bits >= 0 && done_bits % 8 == 0 && done_bits < key_bits,
+                "key_bits must be 32 or 64 and done_bits a multiple of 8 below it");
+    if (n_seg <= 0) return ADN_OK;
+    DeviceGuard dg(c->device);
+    ADN_LAUNCH(k_part_resolve, dim3((unsigned)ceil_div(n_seg, 256)), dim3(256), 0, c->stream, d_hist, n_seg, key_bits,
+               done_bits, d_rank, d_prefix);
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
+
+template <typename T>
+int select_value(Ctx *c, const unsigned long long *d_prefix, int64_t n_seg, double *d_out) {
+    ADN_REQUIRE(c && d_prefix && d_out, "null pointer argument");
+    if (n_seg <= 0) return ADN_OK;
+    DeviceGuard dg(c->device);
+    ADN_LAUNCH((k_part_value<T>), dim3((unsigned)ceil_div(n_seg, 256)), dim3(256), 0, c->stream, d_prefix, n_seg, d_out);
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
+
+// The statistic from its two neighbouring order statistics, with the very arithmetic of the one-call kernels:
+// the median of an even count (q < 0) or numpy's linear interpolation at percentile q of n values.
+template <typename T>
+__global__ void k_part_combine(const double *__restrict__ a, const double *__restrict__ b, int64_t n_seg, bool same,
+                               double frac, int mode, double *__restrict__ out) {
+    const int64_t seg = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (seg >= n_seg) return;
+    out[seg] = select_result<T>((T)a[seg], (T)b[seg], same, frac, mode);
+}
+
+template <typename T>
+int select_combine(Ctx *c, const double *d_lo, const double *d_hi, int64_t n_seg, int64_t n_values, double q,
+                   double *d_out) {
+    ADN_REQUIRE(c && d_lo && d_hi && d_out, "null pointer argument");
+    ADN_REQUIRE(n_values >= 1 && q <= 100.0, "a statistic of %lld values at percentile %g", (long long)n_values, q);
+    if (n_seg <= 0) return ADN_OK;
+    const int mode = q < 0.0 ? SEL_MEDIAN : SEL_PERCENTILE;
+    int64_t r0, r1;
+    double frac;
+    stat_ranks(n_values, mode, q, &r0, &r1, &frac);
+    DeviceGuard dg(c->device);
+    ADN_LAUNCH((k_part_combine<T>), dim3((unsigned)ceil_div(n_seg, 256)), dim3(256), 0, c->stream, d_lo, d_hi, n_seg,
+               r0 == r1, frac, mode, d_out);
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
+template int select_combine<float>(Ctx *, const double *, const double *, int64_t, int64_t, double, double *);
+template int select_combine<double>(Ctx *, const double *, const double *, int64_t, int64_t, double, double *);
+
+template int select_hist<float>(Ctx *, const float *, int64_t, const int64_t *, const int64_t *, int64_t, int, const double *,
+                                const unsigned long long *, int, unsigned int *);
+template int select_hist<double>(Ctx *, const double *, int64_t, const int64_t *, const int64_t *, int64_t, int,
+                                 const double *, const unsigned long long *, int, unsigned int *);
+template int select_value<float>(Ctx *, const unsigned long long *, int64_t, double *);
+template int select_value<double>(Ctx *, const unsigned long long *, int64_t, double *);
 
 // ----------------------------------------------------------------------------
 // Rows of up to a few thousand binary32 values: one wave per segment, the keys held in

@@ -1150,6 +1150,191 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     return apply_dispatch<T, APPLY_GAIN>(c, a, n_sig, Tmax);
 }
 
+// ------------------------------------------------ the Wiener stage in parts
+// One recording split into time chunks over several devices (or calls): every holder computes the
+// statistics of its own frames with these pieces, the per-bin order statistic is a distributed
+// selection over the power rows (select_hist / select_resolve), the masked sums are added up
+// outside, and every holder applies the same gain to its chunk.
+
+// |Z| (power = 0) or |Z|^2 (power = 1) of every frame of every signal, transposed: d_S[(s * F + k) * row_stride + t].
+template <typename T>
+int stft_rows(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int64_t *d_len, int64_t max_len, int n_ch,
+              int n_fft, int hop, int padded, int power, T *d_S, int64_t row_stride) {
+    ADN_REQUIRE(c && d_x && d_off && d_len && d_S, "null pointer argument");
+    ADN_TRY(check_stft_args(n_fft, hop, n_ch));
+    if (n_sig <= 0) return ADN_OK;
+    if (max_len < n_fft) {
+        set_error("window is longer than input signal (n_fft=%d, longest signal=%lld)", n_fft, (long long)max_len);
+        return ADN_ERR_SHORT;
+    }
+    const int64_t Tmax = stft_frames(max_len, n_fft, hop, padded);
+    ADN_REQUIRE(row_stride >= Tmax && row_stride % 32 == 0, "row_stride must be a multiple of 32 and at least %lld frames",
+                (long long)Tmax);
+    DeviceGuard dg(c->device);
+    ws_reset(c);
+    Tables<T> tb;
+    ADN_TRY(get_tables<T>(c, n_fft, &tb));
+    Signals sg{d_off, d_len, n_ch, n_fft, hop, padded};
+    return rows_dispatch<T>(c, d_x, sg, tb, n_sig, row_stride, power, d_S, nullptr);
+}
+
+// Energy VAD flags of STFT frames t0 .. t0 + n_frames - 1 of ONE signal of n_total samples
+// (src/wiener_filter.py:12-33, 92-98) from a buffer that holds its samples from `base_sample` on:
+// the buffer must reach back to VAD frame min(t0 * hop / frame_len, last) - 5 (hangover) and forward to
+// the end of the VAD frame of the last STFT frame (or the end of the signal).
+template <typename T>
+__global__ __launch_bounds__(256) void k_vad_part_energy(const T *__restrict__ xv, int n_ch, int64_t n_total, int64_t frame_len,
+                                                         int64_t i0, int64_t n_vad, unsigned char *__restrict__ speech) {
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (w >= n_vad) return;
+    const int64_t i = i0 + w;
+    const int64_t s = i * frame_len, e = (s + frame_len < n_total) ? s + frame_len : n_total;
+    double acc = 0.0;
+    for (int64_t p = s + lane; p < e; p += 64) {
+        const double v = (double)fold_sample(xv, p, n_total, n_ch);
+        acc += v * v;
+    }
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane == 0) {
+        unsigned char f = 0;
+        if (e > s) {
+            const double rms = sqrt(acc / (double)(e - s) + 1e-12);
+            f = 20.0 * log10(rms + 1e-12) > -40.0;
+        }
+        speech[w] = f;
+    }
+}
+
+__global__ void k_vad_part_map(int64_t n_total, int64_t frame_len, int hop, int64_t t0, int64_t n_frames, int64_t i0,
+                               const unsigned char *__restrict__ speech, unsigned char *__restrict__ vad) {
+    const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (q >= n_frames) return;
+    int64_t nv = (n_total + frame_len - 1) / frame_len;
+    nv = nv < 1 ? 1 : nv;
+    int64_t idx = ((t0 + q) * hop) / frame_len;
+    idx = idx > nv - 1 ? nv - 1 : idx;
+    unsigned char v = 0;
+    for (int64_t j = idx > 5 ? idx - 5 : 0; j <= idx; ++j) v |= speech[j - i0];
+    vad[q] = v;
+}
+
+template <typename T>
+int vad_frames(Ctx *c, const T *d_x, int64_t n_buf, int n_ch, int64_t base_sample, int64_t n_total, int sample_rate,
+               double update_ms, int hop, int64_t t0, int64_t n_frames, unsigned char *d_vad) {
+    ADN_REQUIRE(c && d_x && d_vad, "null pointer argument");
+    ADN_REQUIRE(n_ch >= 1 && hop >= 1 && t0 >= 0 && n_frames >= 0 && base_sample >= 0 && n_total >= 1, "bad size");
+    const int64_t frame_len = (int64_t)((double)sample_rate * update_ms / 1000.0);
+    ADN_REQUIRE(frame_len >= 1, "VAD frame of %lld samples (sample_rate*update_ms/1000)", (long long)frame_len);
+    if (n_frames == 0) return ADN_OK;
+    int64_t nv = ceil_div(n_total, frame_len);
+    nv = nv < 1 ? 1 : nv;
+    int64_t first = (t0 * hop) / frame_len, last = ((t0 + n_frames - 1) * hop) / frame_len;
+    first = first > nv - 1 ? nv - 1 : first;
+    last = last > nv - 1 ? nv - 1 : last;
+    const int64_t i0 = first > 5 ? first - 5 : 0, n_vad = last - i0 + 1;
+    const int64_t need_lo = i0 * frame_len, need_hi = ((last + 1) * frame_len < n_total) ? (last + 1) * frame_len : n_total;
+    ADN_REQUIRE(base_sample <= need_lo && base_sample + n_buf >= need_hi,
+                "the buffer holds samples [%lld, %lld) but the flags need [%lld, %lld)", (long long)base_sample,
+                (long long)(base_sample + n_buf), (long long)need_lo, (long long)need_hi);
+    DeviceGuard dg(c->device);
+    ws_reset(c);
+    ADN_TRY(ws_reserve(c, ws_need(n_vad, 1)));
+    unsigned char *speech = ws_take<unsigned char>(c, n_vad);
+    const T *xv = d_x - base_sample * n_ch;                // sample p of the signal is xv[p * n_ch + channel]
+    ADN_LAUNCH((k_vad_part_energy<T>), dim3((unsigned)ceil_div(n_vad, 4)), dim3(256), 0, c->stream, xv, n_ch, n_total,
+               frame_len, i0, n_vad, speech);
+    ADN_LAUNCH(k_vad_part_map, dim3((unsigned)ceil_div(n_frames, 256)), dim3(256), 0, c->stream, n_total, frame_len, hop, t0,
+               n_frames, i0, speech, d_vad);
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
+
+// d_sum[row] = sum of d_S[row * row_stride + t] over the t < row_len with d_mask[t] != 0 (binary64 sums);
+// *d_count = number of such t.
+template <typename T>
+__global__ __launch_bounds__(256) void k_rows_masked_sum(const T *__restrict__ S, int64_t n_rows, int64_t row_len,
+                                                         int64_t row_stride, const unsigned char *__restrict__ mask,
+                                                         double *__restrict__ sum, long long *__restrict__ count) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n_rows) return;
+    const T *r = S + row * row_stride;
+    double acc = 0.0;
+    long long cn = 0;
+    for (int64_t t = lane; t < row_len; t += 64) {
+        const bool on = mask[t] != 0;
+        acc += on ? (double)r[t] : 0.0;
+        cn += on;
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        acc += __shfl_xor(acc, d);
+        cn += __shfl_xor(cn, d);
+    }
+    if (lane == 0) {
+        sum[row] = acc;
+        if (row == 0) *count = cn;
+    }
+}
+
+template <typename T>
+int rows_masked_sum(Ctx *c, const T *d_S, int64_t n_rows, int64_t row_len, int64_t row_stride, const unsigned char *d_mask,
+                    double *d_sum, long long *d_count) {
+    ADN_REQUIRE(c && d_S && d_mask && d_sum && d_count, "null pointer argument");
+    ADN_REQUIRE(n_rows >= 1 && row_len >= 0 && row_stride >= row_len, "bad size");
+    DeviceGuard dg(c->device);
+    ADN_LAUNCH((k_rows_masked_sum<T>), dim3((unsigned)ceil_div(n_rows, 4)), dim3(256), 0, c->stream, d_S, n_rows, row_len,
+               row_stride, d_mask, d_sum, d_count);
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
+
+// The per-bin gain from the two per-bin statistics (src/wiener_filter.py:84-86, 108-115, 35-39).
+template <typename T>
+int wiener_gain(Ctx *c, const double *d_noise_psd, const double *d_speech_psd, int64_t n_sig, int n_bins, int kernel_bins,
+                T *d_gain) {
+    ADN_REQUIRE(c && d_noise_psd && d_speech_psd && d_gain, "null pointer argument");
+    ADN_REQUIRE(kernel_bins >= 1 && kernel_bins <= 31 && (kernel_bins & 1), "median kernel must be odd and <= 31");
+    ADN_REQUIRE(n_bins >= 1 && n_bins <= 9 * 256, "bin count out of range");
+    if (n_sig <= 0) return ADN_OK;
+    DeviceGuard dg(c->device);
+    ADN_LAUNCH((k_wiener_gain<T>), dim3((unsigned)n_sig), dim3(256), 3 * n_bins * sizeof(double), c->stream, d_noise_psd,
+               d_speech_psd, n_bins, kernel_bins, d_gain);
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
+
+// STFT -> Z * gain -> ISTFT -> clip with gain rows handed in (the apply half of the Wiener stage).
+template <typename T>
+int stft_apply_gain(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int64_t *d_len, int64_t max_len,
+                    int n_ch, int n_fft, int hop, const T *d_gain, int64_t gain_stride, T *d_y, const int64_t *d_y_off,
+                    int16_t *d_pcm16) {
+    ADN_REQUIRE(c && d_x && d_off && d_len && d_gain && d_y && d_y_off, "null pointer argument");
+    ADN_TRY(check_stft_args(n_fft, hop, n_ch));
+    if (n_sig <= 0) return ADN_OK;
+    if (max_len < n_fft) {
+        set_error("window is longer than input signal (n_fft=%d, longest signal=%lld)", n_fft, (long long)max_len);
+        return ADN_ERR_SHORT;
+    }
+    DeviceGuard dg(c->device);
+    ws_reset(c);
+    ADN_TRY(ws_reserve(c, APPLY_WS_BYTES));
+    Tables<T> tb;
+    ADN_TRY(get_tables<T>(c, n_fft, &tb));
+    ApplyArgs<T> a{};
+    a.x = d_x;
+    a.y = d_y;
+    a.y_off = d_y_off;
+    a.sg = Signals{d_off, d_len, n_ch, n_fft, hop, 1};
+    a.tb = tb;
+    a.pcm = d_pcm16;
+    a.row = d_gain;
+    a.row_stride = gain_stride;
+    a.st = 1;
+    a.sf = 1;
+    return apply_dispatch<T, APPLY_GAIN>(c, a, n_sig, stft_frames(max_len, n_fft, hop, 1));
+}
+
 // ------------------------------------------------ phase-1 analysis summaries
 // (src/analyze_audio.py:50-62 summarize_band_energy, :161 noise_profile_time_mean_mag)
 struct BandDesc {
@@ -1322,7 +1507,16 @@ int band_summary(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, cons
                                   const double *, int, double, double, T *, T *, const int64_t *, double *); \
     template int band_summary<T>(Ctx *, const T *, int64_t, const int64_t *, const int64_t *, int64_t, \
                                  int, int, int, int, int, int, const double *, const double *, int,   \
-                                 const double *, double *, double *, T *, T *);
+                                 const double *, double *, double *, T *, T *);                        \
+    template int stft_rows<T>(Ctx *, const T *, int64_t, const int64_t *, const int64_t *, int64_t, int, int, int, \
+                              int, int, T *, int64_t);                                                 \
+    template int vad_frames<T>(Ctx *, const T *, int64_t, int, int64_t, int64_t, int, double, int, int64_t, int64_t, \
+                               unsigned char *);                                                       \
+    template int rows_masked_sum<T>(Ctx *, const T *, int64_t, int64_t, int64_t, const unsigned char *, double *, \
+                                    long long *);                                                      \
+    template int wiener_gain<T>(Ctx *, const double *, const double *, int64_t, int, int, T *);        \
+    template int stft_apply_gain<T>(Ctx *, const T *, int64_t, const int64_t *, const int64_t *, int64_t, int, int, \
+                                    int, const T *, int64_t, T *, const int64_t *, int16_t *);
 ADN_INST(float)
 ADN_INST(double)
 

@@ -290,6 +290,99 @@ int adn_wiener_f64(adn_ctx *ctx, const double *d_x, int64_t n_sig, const int64_t
                    int hop, double update_ms, int kernel_bins, int vad_guided, double *d_y,
                    const int64_t *d_y_off, double *d_gain, int16_t *d_pcm16);
 
+/* ------------------------------------- one recording split over several devices
+ * The reference loads a whole file into one spectrogram (src/spectral_subtract.py:75,82,
+ * src/wiener_filter.py:66,72) and denoises it in blocks of 10 % of the file (denoise.py:76); a
+ * recording too long for one device is cut into time chunks instead.  Everything that is local in
+ * time runs on a chunk plus a halo of its neighbours' samples through the ordinary entry points
+ * (the caller drops the halo's output); the entry points below are the pieces whose statistics
+ * span the whole block / file: they expose the partial results that the holders of the chunks add
+ * up (an all-reduce, or a loop over chunks on one device) before every holder finishes alone.
+ *
+ * Distributed order statistic of segments whose values are scattered over the holders (per-block
+ * MAD of denoise.py:16-23,80; per-bin percentile of src/wiener_filter.py:84): an 8-bit radix descent
+ * on the order-preserving integer keys.  Shared state per segment: d_prefix (the key bits decided so
+ * far, zero at the start) and d_rank (0-based rank still to be found below the prefix, initially the
+ * wanted rank among ALL values of the segment).  Round r (done_bits = 8 r): every holder calls
+ * adn_select_hist_* on its part (d_hist: n_seg x 256 counters, cleared by the call), the histograms
+ * are summed over the holders, every holder calls adn_select_resolve on the sum.  After 4 rounds
+ * (binary32) / 8 rounds (binary64) adn_select_value_* turns the prefix into the value.  absdev != 0:
+ * the values are |x - d_center[seg]| (second median of the MAD).  A NaN sorts above every number. */
+int adn_select_hist_f32(adn_ctx *ctx, const float *d_vals, int64_t n_seg, const int64_t *d_off,
+                        const int64_t *d_len, int64_t max_len, int absdev, const double *d_center,
+                        const uint64_t *d_prefix, int done_bits, uint32_t *d_hist);
+int adn_select_hist_f64(adn_ctx *ctx, const double *d_vals, int64_t n_seg, const int64_t *d_off,
+                        const int64_t *d_len, int64_t max_len, int absdev, const double *d_center,
+                        const uint64_t *d_prefix, int done_bits, uint32_t *d_hist);
+int adn_select_resolve(adn_ctx *ctx, const uint32_t *d_hist, int64_t n_seg, int key_bits, int done_bits,
+                       int64_t *d_rank, uint64_t *d_prefix);
+int adn_select_value_f32(adn_ctx *ctx, const uint64_t *d_prefix, int64_t n_seg, double *d_out);
+int adn_select_value_f64(adn_ctx *ctx, const uint64_t *d_prefix, int64_t n_seg, double *d_out);
+/* The statistic from the two order statistics that bracket it, rounded as the one-call entry points
+ * round it (numpy computes in the array's dtype).  n_values = size of a whole segment.  q < 0: the
+ * median (ranks (n-1)/2 and n/2: numpy.median, denoise.py:21-22); 0 <= q <= 100: numpy.percentile's
+ * linear interpolation between ranks floor((n-1) q/100) and that + 1 (src/wiener_filter.py:84). */
+int adn_select_combine_f32(adn_ctx *ctx, const double *d_lo, const double *d_hi, int64_t n_seg,
+                           int64_t n_values, double q, double *d_out);
+int adn_select_combine_f64(adn_ctx *ctx, const double *d_lo, const double *d_hi, int64_t n_seg,
+                           int64_t n_values, double q, double *d_out);
+
+/* adn_wavelet_denoise_* for mono blocks with the thresholds handed in (d_thresh: one per block)
+ * instead of computed from the block: pywt.wavedec -> pywt.threshold(value = d_thresh[b]) ->
+ * pywt.waverec (denoise.py:77,86,89).  A holder of a chunk of a block runs it on the chunk plus a
+ * halo (a multiple of 2^level samples on both sides, at least 2 (taps - 1)(2^level - 1) of them; the
+ * halo beyond a block's end is the block's other end: periodization) and keeps the chunk's samples. */
+int adn_wavelet_shrink_f32(adn_ctx *ctx, const float *d_in, float *d_out, int64_t n_blocks,
+                           const int64_t *d_in_off, const int64_t *d_frames, const int64_t *d_out_off,
+                           int64_t max_frames, int wavelet, int level, int ext_mode, int thr_mode,
+                           const double *d_thresh, int64_t *d_zeroed);
+int adn_wavelet_shrink_f64(adn_ctx *ctx, const double *d_in, double *d_out, int64_t n_blocks,
+                           const int64_t *d_in_off, const int64_t *d_frames, const int64_t *d_out_off,
+                           int64_t max_frames, int wavelet, int level, int ext_mode, int thr_mode,
+                           const double *d_thresh, int64_t *d_zeroed);
+
+/* |Z| (power = 0) or |Z|^2 (power = 1) of every STFT frame (scipy.signal.stft, boundary=None:
+ * src/noise_profile.py:11-14, src/wiener_filter.py:72-75), transposed for row statistics:
+ * d_S[(s * (n_fft/2+1) + k) * row_stride + t]; row_stride a multiple of 32, >= the frame count. */
+int adn_stft_rows_f32(adn_ctx *ctx, const float *d_x, int64_t n_sig, const int64_t *d_off,
+                      const int64_t *d_len, int64_t max_len, int n_ch, int n_fft, int hop, int padded,
+                      int power, float *d_S, int64_t row_stride);
+int adn_stft_rows_f64(adn_ctx *ctx, const double *d_x, int64_t n_sig, const int64_t *d_off,
+                      const int64_t *d_len, int64_t max_len, int n_ch, int n_fft, int hop, int padded,
+                      int power, double *d_S, int64_t row_stride);
+/* Energy-VAD flags (src/wiener_filter.py:12-33, 92-98) of STFT frames t0 .. t0 + n_frames - 1 of ONE
+ * signal of n_total samples, from a buffer of n_buf samples that starts at sample base_sample of the
+ * signal.  The buffer must reach back five VAD frames (hangover) before the VAD frame of STFT frame
+ * t0 and forward to the end of the VAD frame of the last STFT frame (or the signal's end). */
+int adn_vad_frames_f32(adn_ctx *ctx, const float *d_x, int64_t n_buf, int n_ch, int64_t base_sample,
+                       int64_t n_total, int sample_rate, double update_ms, int hop, int64_t t0,
+                       int64_t n_frames, uint8_t *d_vad);
+int adn_vad_frames_f64(adn_ctx *ctx, const double *d_x, int64_t n_buf, int n_ch, int64_t base_sample,
+                       int64_t n_total, int sample_rate, double update_ms, int hop, int64_t t0,
+                       int64_t n_frames, uint8_t *d_vad);
+/* d_sum[row] = sum over t < row_len with d_mask[t] != 0 of d_S[row * row_stride + t] (binary64);
+ * *d_count = number of such t.  (Numerator and denominator of src/wiener_filter.py:99-102.) */
+int adn_rows_masked_sum_f32(adn_ctx *ctx, const float *d_S, int64_t n_rows, int64_t row_len,
+                            int64_t row_stride, const uint8_t *d_mask, double *d_sum, int64_t *d_count);
+int adn_rows_masked_sum_f64(adn_ctx *ctx, const double *d_S, int64_t n_rows, int64_t row_len,
+                            int64_t row_stride, const uint8_t *d_mask, double *d_sum, int64_t *d_count);
+/* Per-bin gain from the noise PSD (10th percentile) and the speech PSD (masked mean or median), both
+ * before their running medians: src/wiener_filter.py:85-86, 108-115, 35-39.  n_sig rows of n_bins. */
+int adn_wiener_gain_f32(adn_ctx *ctx, const double *d_noise_psd, const double *d_speech_psd, int64_t n_sig,
+                        int n_bins, int kernel_bins, float *d_gain);
+int adn_wiener_gain_f64(adn_ctx *ctx, const double *d_noise_psd, const double *d_speech_psd, int64_t n_sig,
+                        int n_bins, int kernel_bins, double *d_gain);
+/* STFT -> Z * gain -> ISTFT -> clip (src/wiener_filter.py:127-129) with the gain rows handed in:
+ * d_gain[s * gain_stride + k] (gain_stride = 0 shares one row).  Other arguments as adn_wiener_*. */
+int adn_stft_apply_gain_f32(adn_ctx *ctx, const float *d_x, int64_t n_sig, const int64_t *d_off,
+                            const int64_t *d_len, int64_t max_len, int n_ch, int n_fft, int hop,
+                            const float *d_gain, int64_t gain_stride, float *d_y, const int64_t *d_y_off,
+                            int16_t *d_pcm16);
+int adn_stft_apply_gain_f64(adn_ctx *ctx, const double *d_x, int64_t n_sig, const int64_t *d_off,
+                            const int64_t *d_len, int64_t max_len, int n_ch, int n_fft, int hop,
+                            const double *d_gain, int64_t gain_stride, double *d_y, const int64_t *d_y_off,
+                            int16_t *d_pcm16);
+
 /* ------------------------------------------------- RMS-window profiler
  * Per-window sum of squares over all channels divided by the window's row
  * count, then sqrt (lib/windowBundle.py:67-74 as used by

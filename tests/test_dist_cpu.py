@@ -82,3 +82,115 @@ def test_bench_single_rank_line_and_world_mismatch():
     bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "4", "--rehearse-host"],
                          env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr
+
+
+# ---------------------------------------------------------------- one recording split over ranks
+class _HostSelectDouble:
+    """Test double for the three device calls of the distributed order statistic (numpy on CPU tensors),
+    so that the exchange protocol itself -- lock-step rounds, summed histograms, shared decisions -- runs
+    under gloo without a GPU.  The device kernels are checked against numpy's sort in the GPU tests."""
+    torch_device = torch.device("cpu")
+
+    @staticmethod
+    def _keys(v):
+        if v.dtype == np.float32:
+            u = v.view(np.uint32).astype(np.uint64)
+            k = np.where(u >> 31, ~u & 0xFFFFFFFF, u | 0x80000000)
+            return k.astype(np.uint64), 32
+        u = v.view(np.uint64)
+        return np.where(u >> np.uint64(63), ~u, u | np.uint64(1 << 63)), 64
+
+    def select_hist(self, vals, offs, lens, prefix, done_bits, hist, absdev=False, centers=None, max_len=None):
+        v, hist_np = vals.numpy(), np.zeros(tuple(hist.shape), dtype=np.int32)
+        for s, (o, n) in enumerate(zip(offs.tolist(), lens.tolist())):
+            x = v[o:o + n]
+            if absdev:
+                x = np.abs(x - x.dtype.type(centers[s].item()))
+            k, bits = self._keys(np.ascontiguousarray(x))
+            pre = np.uint64(prefix[s].item() & 0xFFFFFFFFFFFFFFFF)
+            if done_bits:
+                k = k[(k >> np.uint64(bits - done_bits)) == (pre >> np.uint64(bits - done_bits))]
+            d = (k >> np.uint64(bits - done_bits - 8)) & np.uint64(255)
+            hist_np[s] = np.bincount(d.astype(np.int64), minlength=256)
+        hist.copy_(torch.from_numpy(hist_np))
+
+    def select_resolve(self, hist, key_bits, done_bits, rank, prefix):
+        for s in range(rank.numel()):
+            c = np.cumsum(hist[s].numpy().astype(np.int64))
+            d = min(int(np.searchsorted(c, rank[s].item(), side="right")), 255)
+            rank[s] -= int(c[d - 1]) if d else 0
+            p = (prefix[s].item() & 0xFFFFFFFFFFFFFFFF) | (d << (key_bits - done_bits - 8))
+            prefix[s] = p - (1 << 64) if p >= (1 << 63) else p
+
+    def select_value(self, prefix, dtype):
+        out = []
+        for p in prefix.tolist():
+            p &= 0xFFFFFFFFFFFFFFFF
+            if dtype == torch.float32:
+                u = np.uint32(p ^ 0x80000000 if p >> 31 else ~p & 0xFFFFFFFF)
+                out.append(float(u.view(np.float32)))
+            else:
+                u = np.uint64(p ^ (1 << 63) if p >> 63 else ~p & 0xFFFFFFFFFFFFFFFF)
+                out.append(float(u.view(np.float64)))
+        return torch.tensor(out, dtype=torch.float64)
+
+    @staticmethod
+    def _i64(a):
+        return torch.as_tensor(np.asarray(a, dtype=np.int64))
+
+
+def _chunk_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(REPO, "audio-denoising_amd"))
+    from adn_hip import chunked as ck
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        e, red = _HostSelectDouble(), ck.DistReducer()
+        rng = np.random.default_rng(11)                              # same stream on both ranks
+        res = {}
+        for name, npdt, dt in (("f32", np.float32, torch.float32), ("f64", np.float64, torch.float64)):
+            segs = [rng.standard_normal(m).astype(npdt) for m in (5, 301, 2000)]
+            cut = [len(v) * 2 // 5 for v in segs]                    # rank 0 holds 2/5 of every segment
+            mine = [v[:c] if rank == 0 else v[c:] for v, c in zip(segs, cut)]
+            lens = np.array([m.size for m in mine], dtype=np.int64)
+            offs = np.concatenate([[0], np.cumsum(lens)[:-1]])
+            part = (torch.from_numpy(np.concatenate(mine)), e._i64(offs), e._i64(lens))
+            ranks = [(len(v) - 1) // 2 for v in segs]
+            res[name] = ck.order_statistics(e, [part], [ranks], dt, red)[0].numpy()
+            res[name + "_want"] = np.array([np.sort(v)[r] for v, r in zip(segs, ranks)], dtype=np.float64)
+        # masked sums / frame counts / maxima go through the same reducer
+        res["sum"] = red.sum([torch.full((3,), 1.0 + rank, dtype=torch.float64), torch.ones(3, dtype=torch.float64)]).numpy()
+        res["cnt"] = red.sum([torch.tensor([7 + rank], dtype=torch.int64)]).numpy()
+        res["max"] = red.max([torch.tensor([0.25 * (rank + 1)], dtype=torch.float64)]).numpy()
+        np.savez(os.path.join(out_dir, "c%d.npz" % rank), **res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_chunk_statistics_exchange(tmp_path):
+    """Histogram / sum / max exchange of a recording split over two ranks: both ranks end with the same,
+    exact order statistics although neither holds a whole segment."""
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    mp.spawn(_chunk_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r = [np.load(str(tmp_path / ("c%d.npz" % k))) for k in range(world)]
+    for x in r:
+        assert np.array_equal(x["f32"], x["f32_want"]) and np.array_equal(x["f64"], x["f64_want"])
+        assert np.array_equal(x["sum"], np.full(3, 5.0)) and int(x["cnt"][0]) == 15 and float(x["max"][0]) == 0.5
+
+
+def test_chunk_plans():
+    sys.path.insert(0, os.path.join(REPO, "audio-denoising_amd"))
+    from adn_hip import chunked as ck
+    owned, halo = ck.plan_wavelet_chunks(160000, 4, 8, 16)
+    assert halo == 7680 and owned[0][0] == 0 and owned[-1][1] == 160000
+    assert all(a % 256 == 0 and b % 256 == 0 for a, b in owned) and all(a[1] == b[0] for a, b in zip(owned, owned[1:]))
+    with pytest.raises(ValueError):
+        ck.plan_wavelet_chunks(160001, 2, 2, 8)
+    hops, frames = ck.plan_stft_chunks(320333, 5)
+    assert frames == 1 + -(-(320333 - 2048) // 512) and hops[0][0] == 0 and hops[-1][1] == frames - 1
+    s0, s1, keep = ck.stft_chunk_window(0, 100, frames, 320333)
+    assert (s0, keep) == (0, 0) and s1 == 102 * 512 + 2048
+    s0, s1, keep = ck.stft_chunk_window(500, frames - 1, frames, 320333)
+    assert s0 == 498 * 512 and s1 == 320333 and keep == 1024
+    assert ck.stft_chunk_window(500, 510, frames, 320333, reach=0) == (499 * 512, 511 * 512 + 2048, 512)
