@@ -979,6 +979,13 @@ template <int NCH> struct FetchT;
 template <> struct FetchT<1> { typedef c2 type; };
 template <> struct FetchT<2> { typedef float4 type; };
 
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ c2 load_streaming(const c2 *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ float4 load_streaming(const float4 *p) {
+    const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));
+    return float4{v.x, v.y, v.z, v.w};
+}
+
 template <int NCH>
 __device__ __forceinline__ bool fetch_frame(typename FetchT<NCH>::type (&pf)[16], const float *__restrict__ xs, int64_t n,
                                             int n_ch, int64_t p0, int lane) {
@@ -993,8 +1000,12 @@ __device__ __forceinline__ bool fetch_frame(typename FetchT<NCH>::type (&pf)[16]
     const float *src = ok ? xs + NCH * p0 : xs - ((reinterpret_cast<uintptr_t>(xs) & (sizeof(V) - 1)) >> 2);
     const V *xv = reinterpret_cast<const V *>(src) + lane;
     __builtin_amdgcn_sched_barrier(0);
+    // the first quarter of a frame is the hop that no later frame of the run reads again: it is loaded
+    // with the streaming hint, so that the cache keeps the three hops the next steps come back for
 #pragma unroll
-    for (int j = 0; j < 16; ++j) pf[j] = xv[64 * j];
+    for (int j = 0; j < 4; ++j) pf[j] = load_streaming(xv + 64 * j);
+#pragma unroll
+    for (int j = 4; j < 16; ++j) pf[j] = xv[64 * j];
     __builtin_amdgcn_sched_barrier(0);
     return ok;
 }
@@ -1202,7 +1213,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 o[cc].y = o[cc].y < -lim ? -lim : (o[cc].y > lim ? lim : o[cc].y);
             }
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) *reinterpret_cast<c2 *>(yp0 + 32 * cc) = o[cc];
+            for (int cc = 0; cc < 4; ++cc) __builtin_nontemporal_store(o[cc], reinterpret_cast<c2 *>(yp0 + 32 * cc));
         }
         __builtin_amdgcn_sched_barrier(0);
         c2 r[16];                                          // the frame being transformed (either direction)
