@@ -1539,36 +1539,53 @@ template int select_value<double>(Ctx *, const unsigned long long *, int64_t, do
 // barrier, no atomics; rows of one workgroup are independent of each other.
 static constexpr int SEL_CK = 8;                        // candidate keys per lane after compaction
 
-// Number of keys of the wave (N per lane) below `trial`.  Groups of eight keys: eight vector compares whose lane
-// masks go to eight scalar register pairs, THEN the eight scalar counts and additions.  A scalar instruction that
-// reads a register the vector unit has just written waits for that instruction to leave the vector pipeline; with
-// the compares grouped the wait is paid once per group, and the running sum keeps the scalar register demand at the
-// eight masks.  (The CU's one scalar unit, two instructions per key, is what bounds this loop.)
+// Number of keys of the wave (N per lane) below `trial`.  Two ways of counting share the work, because each is
+// bound by another unit: (a) vector compare -> lane mask in scalar registers -> scalar bit count and addition (one
+// vector, two scalar instructions per key; a SIMD gets one scalar issue slot in four cycles); (b) vector compare ->
+// add-with-carry into a per-lane counter (two vector instructions per key), summed over the lanes once per call
+// from the ballots of the counter's bits.  Per twelve keys: eight by (a), four by (b), which loads both units
+// alike.  (a) runs in groups of eight compares followed by their eight counts: a scalar instruction that reads
+// a register the vector unit has just written waits for that instruction to leave the vector pipeline, and with
+// the compares grouped the wait is paid once per group.
 template <int N>
 __device__ __forceinline__ uint32_t count_below(const uint32_t (&key)[N], uint32_t trial) {
-    uint32_t cnt = 0;
+    uint32_t cnt = 0, vc = 0;
 #pragma unroll
-    for (int g = 0; g < N; g += 8) {
+    for (int g = 0; g < N; g += 12) {
         unsigned long long m[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) m[i] = g + i < N ? __ballot(key[g + i] < trial) : 0ull;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
+        for (int i = 8; i < 12; ++i)
+            if (g + i < N)
+                asm volatile("v_cmp_gt_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc"
+                             : "+v"(vc)
+                             : "v"(key[g + i]), "s"(trial)
+                             : "vcc");
+#pragma unroll
         for (int i = 0; i < 8; ++i)
             if (g + i < N) cnt += (uint32_t)__builtin_popcountll(m[i]);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if (N > 8) {
+        constexpr int VB = N >= 12 * 16 ? 7 : (N >= 12 * 8 ? 6 : (N >= 12 * 4 ? 5 : 4));      // bits of a lane's counter
+#pragma unroll
+        for (int k = 0; k < VB; ++k) cnt += (uint32_t)__builtin_popcountll(__ballot((vc >> k) & 1u)) << k;
     }
     return cnt;
 }
 
 template <int XF, bool MASKED, int KPL>
-__global__ __launch_bounds__(256) void k_select_wave(const float *__restrict__ vals, const int64_t *__restrict__ seg_off,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KPL <= 96 ? 3 : 2))) void k_select_wave(const float *__restrict__ vals, const int64_t *__restrict__ seg_off,
                                                      int64_t seg_stride, const int64_t *__restrict__ seg_len,
                                                      int64_t len_div, int64_t uniform_len, int64_t n_seg, int mode,
                                                      double q, const double *__restrict__ center,
                                                      double *__restrict__ out, MaskedMean mm, int max_bits) {
     const int lane = threadIdx.x & 63;
-    const int64_t seg = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // the wave index as a scalar: the row's addresses then live in scalar registers and every load of the row
+    // takes one 32-bit lane offset instead of a 64-bit address pair
+    const int64_t seg = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (seg >= n_seg) return;
     const int n = (int)(seg_len ? seg_len[seg / len_div] : uniform_len);
     if (n <= 0) {
@@ -1611,44 +1628,59 @@ __global__ __launch_bounds__(256) void k_select_wave(const float *__restrict__ v
         }
     };
     const bool vec_ok = (reinterpret_cast<uintptr_t>(vrow) & 15) == 0 && (!MASKED || (reinterpret_cast<uintptr_t>(mrow) & 3) == 0);
+    // The loads go out in batches (all loads of a batch back to back, no branch between them) and a batch is
+    // turned into keys before the next one is requested: the staging registers of ONE batch beside the keys keep
+    // the kernel at three waves per SIMD, and it is the other waves that cover a wave's memory round trips.
+    constexpr int SB = KPL < 16 ? KPL : 16;                 // single elements per batch (rows that are not 16-byte aligned)
+    constexpr int QB = KPL / 4 <= 24 ? KPL / 4 : 24;          // quads per batch
     if (vec_ok && n >= 4) {
         const int nq = n >> 2;                              // whole quads
         const float4 *vv = reinterpret_cast<const float4 *>(vrow);
         const uint32_t *mv = reinterpret_cast<const uint32_t *>(mrow);
-        float4 xq[KPL / 4];
-        uint32_t mq[KPL / 4];
-#pragma unroll
-        for (int i = 0; i < KPL / 4; ++i) {
-            const int j = lane + 64 * i;
-            const int js = j < nq ? j : nq - 1;
-            xq[i] = vv[js];
-            mq[i] = MASKED ? mv[js] : 0u;
-        }
         const int jt = 4 * nq + lane;                       // tail element of lanes 0..2
         const bool tail = lane < 3 && jt < n;
         const float xt = vrow[tail ? jt : 0];
         const unsigned mt = MASKED ? mrow[tail ? jt : 0] : 0u;
 #pragma unroll
-        for (int i = 0; i < KPL / 4; ++i) {
-            const bool valid = lane + 64 * i < nq;
-            take(4 * i + 0, xq[i].x, mq[i] & 0xFF, valid);
-            take(4 * i + 1, xq[i].y, (mq[i] >> 8) & 0xFF, valid);
-            take(4 * i + 2, xq[i].z, (mq[i] >> 16) & 0xFF, valid);
-            take(4 * i + 3, xq[i].w, mq[i] >> 24, valid);
+        for (int b0 = 0; b0 < KPL / 4; b0 += QB) {
+            float4 xq[QB];
+            uint32_t mq[QB];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < QB; ++i) {
+                const uint32_t j = (uint32_t)lane + 64u * (uint32_t)(b0 + i);
+                const uint32_t js = j < (uint32_t)nq ? j : (uint32_t)nq - 1u;
+                xq[i] = vv[js];
+                mq[i] = MASKED ? mv[js] : 0u;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < QB; ++i) {
+                const bool valid = lane + 64 * (b0 + i) < nq;
+                take(4 * (b0 + i) + 0, xq[i].x, mq[i] & 0xFF, valid);
+                take(4 * (b0 + i) + 1, xq[i].y, (mq[i] >> 8) & 0xFF, valid);
+                take(4 * (b0 + i) + 2, xq[i].z, (mq[i] >> 16) & 0xFF, valid);
+                take(4 * (b0 + i) + 3, xq[i].w, mq[i] >> 24, valid);
+            }
         }
         take(KPL, xt, mt, tail);
     } else {
-        float xs[KPL];
-        unsigned ms[KPL];
 #pragma unroll
-        for (int i = 0; i < KPL; ++i) {
-            const int j = lane + 64 * i;
-            const int js = j < n ? j : n - 1;
-            xs[i] = vrow[js];
-            ms[i] = MASKED ? mrow[js] : 0u;
+        for (int b0 = 0; b0 < KPL; b0 += SB) {
+            float xs[SB];
+            unsigned ms[SB];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const uint32_t j = (uint32_t)lane + 64u * (uint32_t)(b0 + i);
+                const uint32_t js = j < (uint32_t)n ? j : (uint32_t)n - 1u;
+                xs[i] = vrow[js];
+                ms[i] = MASKED ? mrow[js] : 0u;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < SB; ++i) take(b0 + i, xs[i], ms[i], lane + 64 * (b0 + i) < n);
         }
-#pragma unroll
-        for (int i = 0; i < KPL; ++i) take(i, xs[i], ms[i], lane + 64 * i < n);
         key[KPL] = 0xFFFFFFFFu;
     }
 #pragma unroll
