@@ -1040,19 +1040,21 @@ __device__ __noinline__ void stage_frame_half_window(c2 *buf, const float *__res
 // NCH: the channel count whose frames are fetched straight into registers (other counts, and frames
 // at the zero-padded tail of a signal, take the staged loader)
 template <int W, int MODE, int NCH, bool PROF>
-__global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_apply_wave(ApplyArgs<float> a) {
+__global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(MODE == APPLY_SUBTRACT ? 2 : 3, MODE == APPLY_SUBTRACT ? 2 : 3)))
+void k_apply_wave(ApplyArgs<float> a) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int H = 512;
-    constexpr int SLOT = MODE == APPLY_SUBTRACT ? PARK : GROW / 2;                   // float2 per wave beside the exchange buffer
+    constexpr int SLOT = MODE == APPLY_SUBTRACT ? PARK : 0;                          // float2 per wave beside the exchange buffer
     const Tables<float> &tb = a.tb;
     c2 *bufs = reinterpret_cast<c2 *>(smem);                                          // [W][WBUF] exchange
     c2 *slots = bufs + (size_t)W * WBUF;                                              // [W][SLOT] parked spectrum / gain row
     c2 *twtab = slots + (size_t)W * SLOT;
     float *wtab = reinterpret_cast<float *>(twtab + TWTAB);                           // [1024] first half of the window
     float *ntab = wtab + 1024;                                                        // [512] scale / full-overlap norm
-    float *nrow = ntab + 512;                                                         // [GROW] SUBTRACT: the signal's noise row
-    const int wave = threadIdx.x >> 6, lane0 = threadIdx.x & 63, tid = threadIdx.x;
-    // SUBTRACT: the waves of a workgroup work on one signal (segs_per_sig is a multiple of W)
+    float *nrow = ntab + 512;                                                         // [GROW] the signal's noise row (SUBTRACT) / gain row (GAIN)
+    // the wave index as a scalar: the run's bounds, pointers and counters then live in scalar registers
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane0 = threadIdx.x & 63, tid = threadIdx.x;
+    // the waves of a workgroup work on one signal (segs_per_sig is a multiple of W) and share its noise / gain row
     const int64_t gid = (int64_t)blockIdx.x * W + wave;
     const int64_t sig = gid / a.segs_per_sig;
     const int run = (int)(gid % a.segs_per_sig);
@@ -1071,7 +1073,7 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
         ntab[i] = iscale / (sq > 1e-10f ? sq : 1.0f);
     }
-    if (MODE == APPLY_SUBTRACT)
+    if (MODE == APPLY_SUBTRACT || a.row_t_stride == 0)
         for (int i = tid; i <= 1024; i += W * 64) nrow[i] = row[i];
     __syncthreads();                                       // the only workgroup barrier: every wave reaches it
 
@@ -1091,17 +1093,13 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     c2 *buf = bufs + wave * WBUF;
     float *bufr = reinterpret_cast<float *>(buf);
     c2 *park = slots + wave * SLOT;
-    float *grow_lds = reinterpret_cast<float *>(park);
+    float *grow_lds = nrow;
     const c2 *wv = reinterpret_cast<const c2 *>(wtab);
     const c2 *nv = reinterpret_cast<const c2 *>(ntab);
     const c2 rtw0 = as_c2(tb.rtw)[lane0];
     const bool y_vec = (reinterpret_cast<uintptr_t>(ys) & 7) == 0;
     const bool p_vec = (reinterpret_cast<uintptr_t>(ps) & 3) == 0;
     const bool gain_in_lds = MODE == APPLY_GAIN && a.row_t_stride == 0;
-    if (gain_in_lds) {
-        for (int k = lane0; k <= 1024; k += 64) grow_lds[k] = row[k];
-        wave_sync();
-    }
     auto wfull = [&](int idx) { return idx < 1024 ? wtab[idx] : 1.0f - wtab[idx - 1024]; };
 
     // one finished hop: normalise, clip, optional PCM16, store
@@ -1427,8 +1425,8 @@ __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 }
 
 static size_t apply_wave_lds(int W, int mode) {
-    return (size_t)W * WBUF * sizeof(c2) + (size_t)W * (mode == APPLY_SUBTRACT ? PARK : GROW / 2) * sizeof(c2) +
-           (size_t)TWTAB * sizeof(c2) + (1024 + 512 + (mode == APPLY_SUBTRACT ? GROW : 0)) * sizeof(float);
+    return (size_t)W * WBUF * sizeof(c2) + (size_t)W * (mode == APPLY_SUBTRACT ? PARK : 0) * sizeof(c2) +
+           (size_t)TWTAB * sizeof(c2) + (1024 + 512 + GROW) * sizeof(float);
 }
 
 static size_t apply_lds(int W, int mode, int hop) {
@@ -1453,8 +1451,8 @@ static int apply_wave(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
     run = run < 16 ? 16 : (run > 1024 ? 1024 : run);
     a.seg_hops = (int)run;
     a.segs_per_sig = ceil_div(out_hops, run);
-    // SUBTRACT: the waves of a workgroup share one signal's noise row (runs beyond the signal's end exit at once)
-    if (MODE == APPLY_SUBTRACT) a.segs_per_sig = ceil_div(a.segs_per_sig, (int64_t)W) * W;
+    // the waves of a workgroup share one signal's noise / gain row (runs beyond the signal's end exit at once)
+    a.segs_per_sig = ceil_div(a.segs_per_sig, (int64_t)W) * W;
     a.n_sig = n_sig;
     // one 2 KB line that takes the stores of hops which are not stored by the kernel's fast path
     if (c->ws_used + APPLY_WS_BYTES > c->ws_bytes) {
