@@ -25,7 +25,13 @@ struct SelectArgs {
     const unsigned char *d_mask = nullptr;   // mask[(seg / mask_div) * mask_stride + i]
     int64_t mask_div = 1, mask_stride = 0;
     double *d_masked_mean = nullptr;
+    // binary32 rows held in groups of four values (the layout rows_wave writes): value i of segment seg is
+    // d_vals[(seg / blk_rows) * blk_sig_stride + (i / 4) * 4 * quad_stride + (seg % blk_rows) * 4 + i % 4];
+    // quad_stride == 1: plain contiguous segments (the fields above)
+    int64_t quad_stride = 1, blk_rows = 1, blk_sig_stride = 0;
 };
+// longest row of the grouped layout launch_select takes
+int64_t select_grouped_limit();
 // longest segment launch_select handles inside one workgroup (longer ones take the
 // multi-workgroup path, which has no fused masked mean)
 int64_t select_short_limit();

@@ -1581,11 +1581,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KPL <= 96 ?
                                                      int64_t seg_stride, const int64_t *__restrict__ seg_len,
                                                      int64_t len_div, int64_t uniform_len, int64_t n_seg, int mode,
                                                      double q, const double *__restrict__ center,
-                                                     double *__restrict__ out, MaskedMean mm, int max_bits) {
+                                                     double *__restrict__ out, MaskedMean mm, int max_bits,
+                                                     int64_t quad_stride, int64_t blk_rows, int64_t blk_sig_stride) {
     const int lane = threadIdx.x & 63;
     // the wave index as a scalar: the row's addresses then live in scalar registers and every load of the row
     // takes one 32-bit lane offset instead of a 64-bit address pair
-    const int64_t seg = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // Rows in groups of four values: the two workgroups that share the 128-byte lines of eight neighbouring rows
+    // must meet in one L2, and consecutive workgroups go to different XCDs: workgroup b (XCD b mod 8) takes the
+    // rows of logical workgroup ((b / 16) * 8 + b mod 8) * 2 + (b / 8) mod 2.
+    int64_t wg = blockIdx.x;
+    if (quad_stride != 1 && (int64_t)gridDim.x % 16 == 0) wg = ((wg >> 4) * 8 + (wg & 7)) * 2 + ((wg >> 3) & 1);
+    const int64_t seg = wg * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (seg >= n_seg) return;
     const int n = (int)(seg_len ? seg_len[seg / len_div] : uniform_len);
     if (n <= 0) {
@@ -1600,7 +1606,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KPL <= 96 ?
     big_ranks(n, mode, q, &r0l, &r1l, &frac);
     const uint32_t r0 = (uint32_t)r0l, r1 = (uint32_t)r1l;
     const float c = XF == XF_ABSDEV ? (float)center[seg] : 0.0f;
-    const float *vrow = vals + (seg_off ? seg_off[seg] : seg * seg_stride);
+    const float *vrow = quad_stride != 1 ? vals + (seg / blk_rows) * blk_sig_stride + (seg % blk_rows) * 4
+                                         : vals + (seg_off ? seg_off[seg] : seg * seg_stride);
+    const uint32_t qs = (uint32_t)quad_stride;
     const unsigned char *mrow = MASKED ? mm.mask + (seg / mm.mask_div) * mm.mask_stride : nullptr;
 
     // ---- load: all loads of the row are issued back to back, with no branch between them.  Whole quads:
@@ -1627,7 +1635,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KPL <= 96 ?
             kmax = k > kmax ? k : kmax;
         }
     };
-    const bool vec_ok = (reinterpret_cast<uintptr_t>(vrow) & 15) == 0 && (!MASKED || (reinterpret_cast<uintptr_t>(mrow) & 3) == 0);
+    const bool vec_ok = quad_stride != 1 ||
+                        ((reinterpret_cast<uintptr_t>(vrow) & 15) == 0 && (!MASKED || (reinterpret_cast<uintptr_t>(mrow) & 3) == 0));
     // The loads go out in batches (all loads of a batch back to back, no branch between them) and a batch is
     // turned into keys before the next one is requested: the staging registers of ONE batch beside the keys keep
     // the kernel at three waves per SIMD, and it is the other waves that cover a wave's memory round trips.
@@ -1639,7 +1648,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KPL <= 96 ?
         const uint32_t *mv = reinterpret_cast<const uint32_t *>(mrow);
         const int jt = 4 * nq + lane;                       // tail element of lanes 0..2
         const bool tail = lane < 3 && jt < n;
-        const float xt = vrow[tail ? jt : 0];
+        const float xt = vrow[tail ? (size_t)nq * 4 * qs + lane : 0];
         const unsigned mt = MASKED ? mrow[tail ? jt : 0] : 0u;
 #pragma unroll
         for (int b0 = 0; b0 < KPL / 4; b0 += QB) {
@@ -1650,7 +1659,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KPL <= 96 ?
             for (int i = 0; i < QB; ++i) {
                 const uint32_t j = (uint32_t)lane + 64u * (uint32_t)(b0 + i);
                 const uint32_t js = j < (uint32_t)nq ? j : (uint32_t)nq - 1u;
-                xq[i] = vv[js];
+                xq[i] = vv[js * qs];
                 mq[i] = MASKED ? mv[js] : 0u;
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1778,11 +1787,13 @@ static constexpr int64_t SEL_WAVE_MAX = 128 * 64;       // longest row the regis
 template <int XF, bool MASKED>
 static int launch_select_wave(Ctx *c, const float *d_vals, const SelectArgs &a) {
     MaskedMean mm{a.d_mask, a.mask_div, a.mask_stride, a.d_masked_mean};
-    dim3 grid((unsigned)ceil_div(a.n_seg, 4)), block(256);
+    // (grouped rows: a multiple of 16 workgroups, so that the kernel's workgroup permutation is one)
+    const int64_t wgs = a.quad_stride != 1 ? ceil_div(ceil_div(a.n_seg, (int64_t)4), (int64_t)16) * 16 : ceil_div(a.n_seg, (int64_t)4);
+    dim3 grid((unsigned)wgs), block(256);
 #define ADN_SEL_WAVE(KPLV)                                                                                          \
     ADN_LAUNCH_NAMED("k_select_wave<" #KPLV ">", (k_select_wave<XF, MASKED, KPLV>), grid, block, 0, c->stream, d_vals,  \
                      a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len, a.n_seg, a.mode, a.q, a.d_center, \
-                     a.d_out, mm, (c->ablate & 32) ? 0 : 32)
+                     a.d_out, mm, (c->ablate & 32) ? 0 : 32, a.quad_stride, a.blk_rows, a.blk_sig_stride)
     if (a.max_len <= 8 * 64) ADN_SEL_WAVE(8);
     else if (a.max_len <= 24 * 64) ADN_SEL_WAVE(24);
     else if (a.max_len <= 48 * 64) ADN_SEL_WAVE(48);
@@ -1793,10 +1804,18 @@ static int launch_select_wave(Ctx *c, const float *d_vals, const SelectArgs &a) 
     return ADN_OK;
 }
 
+int64_t select_grouped_limit() { return 96 * 64; }
+
 template <typename T>
 int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {
     if (a.n_seg <= 0) return ADN_OK;
     using K = typename KeyT<T>::type;
+    if (a.quad_stride != 1) {
+        ADN_REQUIRE((std::is_same<T, float>::value) && a.max_len > 0 && a.max_len <= select_grouped_limit() &&
+                        a.mode != SEL_PERCENTILE_DB20 && (reinterpret_cast<uintptr_t>(d_vals) & 15) == 0 &&
+                        a.blk_sig_stride % 4 == 0 && (a.quad_stride * (a.max_len / 4 + 1)) < (int64_t(1) << 28),
+                    "internal: grouped rows are binary32 rows of at most %lld values", (long long)select_grouped_limit());
+    }
     if (a.max_len > BIG_THRESHOLD) {
         if (a.d_masked_mean) {
             set_error("internal: the fused masked mean is only available for LDS-resident segments");
@@ -1807,7 +1826,8 @@ int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {
     }
     // binary32 rows of up to a few thousand values: one wave per row, keys in registers
     if constexpr (std::is_same<T, float>::value) {
-        if (!c->force_generic && a.max_len > 0 && a.max_len <= SEL_WAVE_MAX && a.mode != SEL_PERCENTILE_DB20) {
+        if ((!c->force_generic || a.quad_stride != 1) && a.max_len > 0 && a.max_len <= SEL_WAVE_MAX &&
+            a.mode != SEL_PERCENTILE_DB20) {
             const bool masked = a.d_masked_mean != nullptr;
             if (a.xform == XF_ABSDEV) return masked ? launch_select_wave<XF_ABSDEV, true>(c, d_vals, a)
                                                     : launch_select_wave<XF_ABSDEV, false>(c, d_vals, a);

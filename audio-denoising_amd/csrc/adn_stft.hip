@@ -1089,7 +1089,7 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     const size_t nS = (size_t)n_sig * F * Ts, nR = (size_t)n_sig * F;
     ADN_TRY(ws_reserve(c, ws_need(nS, sizeof(T)) + ws_need(n_sig, 8) + 2 * ws_need(nR, 8) + ws_need(nR, sizeof(T)) +
                               ws_need((size_t)n_sig * nv_max, 1) + ws_need((size_t)n_sig * Ts, 1) + ws_need(n_sig, 4) +
-                              2 * select_ws_bytes(n_sig * F, Tmax) + APPLY_WS_BYTES));
+                              2 * select_ws_bytes(n_sig * F, Tmax) + 2 * APPLY_WS_BYTES));
     T *S = ws_take<T>(c, nS);
     int64_t *Tn = ws_take<int64_t>(c, n_sig);
     double *p10 = ws_take<double>(c, nR), *sraw = ws_take<double>(c, nR);
@@ -1104,8 +1104,20 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
         ADN_LAUNCH(k_vad_map, dim3((unsigned)ceil_div(n_sig * Ts, 256)), dim3(256), 0, c->stream, sg, n_sig,
                            frame_len, nv_max, Ts, speech, vad);
     }
-    ADN_TRY(rows_dispatch<T>(c, d_x, sg, tb, n_sig, Ts, 1, S, nullptr));
     SelectArgs sa;
+    // binary32 rows of up to a few thousand frames: power rows in groups of four frames, written by waves that
+    // work alone and read by the register-resident row select
+    bool grouped = false;
+    if constexpr (std::is_same<T, float>::value)
+        grouped = !c->force_generic && (c->ablate & 64) == 0 && rows_wave_ok(sg, n_fft) && Tmax <= select_grouped_limit();
+    if (grouped) {
+        if constexpr (std::is_same<T, float>::value) ADN_TRY(rows_wave(c, d_x, sg, tb, n_sig, Tmax, 1, S, (int64_t)F * Ts));
+        sa.quad_stride = F;
+        sa.blk_rows = F;
+        sa.blk_sig_stride = (int64_t)F * Ts;
+    } else {
+        ADN_TRY(rows_dispatch<T>(c, d_x, sg, tb, n_sig, Ts, 1, S, nullptr));
+    }
     sa.n_seg = n_sig * F;
     sa.seg_stride = Ts;
     sa.d_seg_len = Tn;
@@ -1115,7 +1127,7 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     sa.q = 10.0;
     sa.d_out = p10;
     // rows that fit one workgroup get the VAD-masked mean from the same pass over the row
-    const bool fuse_mean = vad_guided && Tmax <= select_short_limit();
+    const bool fuse_mean = vad_guided && (grouped || Tmax <= select_short_limit());
     if (fuse_mean) {
         sa.d_mask = vad;
         sa.mask_div = F;

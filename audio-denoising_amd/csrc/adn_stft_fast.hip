@@ -93,7 +93,9 @@ __device__ __forceinline__ c2 conj_sub_rot(c2 a, c2 b) {
     asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-__device__ __forceinline__ float norm2(c2 z) { return z.x * z.x + z.y * z.y; }
+// (explicit fused multiply-adds where a kernel's result must not depend on how the compiler contracts the
+// expression in that kernel: the rows kernels and the fused kernels have to agree bit for bit)
+__device__ __forceinline__ float norm2(c2 z) { return __builtin_fmaf(z.x, z.x, z.y * z.y); }
 
 // v * W16^M (forward) or its conjugate (inverse)
 template <int M, bool INV>
@@ -392,9 +394,122 @@ __device__ __forceinline__ void merge_spectrum(const Spec &s, c2 *buf, const c2 
     if (lane == 0) buf[nat(512)] = c2{s.mid.x, -s.mid.y};
 }
 
+// The same for a wave that transforms the result itself: the lower half of the packed spectrum, Z'[lane + 64 j]
+// for j < 8, is what the inverse transform wants in r[j] of this very lane, so it stays in registers; only the
+// mirrored bins (the upper half, owned by other lanes) go through buf.
+template <int J>
+__device__ __forceinline__ void merge_bin_keep(const Spec &s, c2 (&r)[16], const NatAddr &na, const c2 (&rtw)[8], int lane) {
+    const c2 xk = s.lo[J], xm = s.hi[J];
+    c2 *mir = const_cast<c2 *>((J & 3) == 0 ? na.mir4 : na.mir);
+    const c2 e = add_conj(xk, xm) * 0.5f;                  // ((xk.x + xm.x) / 2, (xk.y - xm.y) / 2)
+    c2 d;                                                  // (xk.x - xm.x, xk.y + xm.y)
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(d) : "v"(xk), "v"(xm));
+    const c2 o = mulc(d * 0.5f, rtw[J]);
+    r[J] = add_rot<true>(e, o);                            // e + i o = (e.x - o.y, e.y + o.x)
+    const c2 m = conj_sub_rot(e, o);                       // conj(e - i o) = (e.x + o.y, o.x - e.y)
+    if (J == 0) {
+        // lane 0: bins 0 and 1024 are real and pack into Z'[0]; its mirror slot is not a bin
+        if (lane == 0) r[0] = c2{(xk.x + xm.x) * 0.5f, (xk.x - xm.x) * 0.5f};
+        else mir[nat_mir_off<J>()] = m;
+    } else {
+        mir[nat_mir_off<J>()] = m;
+    }
+}
+
+__device__ __forceinline__ void merge_spectrum_keep(const Spec &s, c2 (&r)[16], c2 *buf, const c2 (&rtw)[8], int lane) {
+    const NatAddr na = nat_addr(buf, lane);
+    merge_bin_keep<0>(s, r, na, rtw, lane);
+    merge_bin_keep<1>(s, r, na, rtw, lane);
+    merge_bin_keep<2>(s, r, na, rtw, lane);
+    merge_bin_keep<3>(s, r, na, rtw, lane);
+    merge_bin_keep<4>(s, r, na, rtw, lane);
+    merge_bin_keep<5>(s, r, na, rtw, lane);
+    merge_bin_keep<6>(s, r, na, rtw, lane);
+    merge_bin_keep<7>(s, r, na, rtw, lane);
+    if (lane == 0) buf[nat(512)] = c2{s.mid.x, -s.mid.y};
+}
+
 __device__ __forceinline__ void load_rtw(c2 (&rtw)[8], const c2 *tab, int lane) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) rtw[j] = tab[lane + 64 * j];
+}
+
+// exp(-2 pi i (lane + 64 j) / 2048) = rtw0 * exp(-i pi j / 16)
+__device__ __forceinline__ void derive_rtw(c2 (&rtw)[8], c2 rtw0) {
+    rtw[0] = rtw0;
+    rtw[1] = mul_k(rtw0, c2{0.9807852804032304f, -0.19509032201612825f});
+    rtw[2] = mul_k(rtw0, c2{0.9238795325112867f, -0.3826834323650898f});
+    rtw[3] = mul_k(rtw0, c2{0.8314696123025452f, -0.5555702330196022f});
+    rtw[4] = mul_k(rtw0, c2{0.7071067811865476f, -0.7071067811865476f});
+    rtw[5] = mul_k(rtw0, c2{0.5555702330196022f, -0.8314696123025452f});
+    rtw[6] = mul_k(rtw0, c2{0.3826834323650898f, -0.9238795325112867f});
+    rtw[7] = mul_k(rtw0, c2{0.19509032201612825f, -0.9807852804032304f});
+}
+
+// Raw samples of the frame at padded position p0, requested into registers (no arithmetic, so
+// that the loads stay in flight).  NCH = 1: pf[j] is packed point lane + 64 j; NCH = 2: pf[j] holds
+// the two (left, right) pairs of packed point lane + 64 j.  Returns false when the frame needs the
+// generic loader instead (tail of the signal, odd alignment, another channel count).
+template <int NCH> struct FetchT;
+template <> struct FetchT<1> { typedef c2 type; };
+template <> struct FetchT<2> { typedef float4 type; };
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ c2 load_streaming(const c2 *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ float4 load_streaming(const float4 *p) {
+    const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));
+    return float4{v.x, v.y, v.z, v.w};
+}
+
+template <int NCH>
+__device__ __forceinline__ bool fetch_frame(typename FetchT<NCH>::type (&pf)[16], const float *__restrict__ xs, int64_t n,
+                                            int n_ch, int64_t p0, int lane) {
+    typedef typename FetchT<NCH>::type V;
+    const bool ok = p0 + 2048 <= n && n_ch == NCH && (reinterpret_cast<uintptr_t>(xs + NCH * p0) & (sizeof(V) - 1)) == 0;
+    // No branch around the loads (a join between the loads and their first use would make the
+    // compiler wait for every younger memory operation as well): a frame that cannot be fetched this
+    // way reads the first 2048 frames of the signal instead, from the address rounded down to the
+    // load size, and the result is ignored.  Every signal holds at least one whole frame; rounding
+    // down stays inside the caller's buffer because only element offsets inside it can be odd.
+    // (pointer arithmetic only: an integer round trip would turn the loads into flat ones)
+    const float *src = ok ? xs + NCH * p0 : xs - ((reinterpret_cast<uintptr_t>(xs) & (sizeof(V) - 1)) >> 2);
+    const V *xv = reinterpret_cast<const V *>(src) + lane;
+    __builtin_amdgcn_sched_barrier(0);
+    // the first quarter of a frame is the hop that no later frame of the run reads again: it is loaded
+    // with the streaming hint, so that the cache keeps the three hops the next steps come back for
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pf[j] = load_streaming(xv + 64 * j);
+#pragma unroll
+    for (int j = 4; j < 16; ++j) pf[j] = xv[64 * j];
+    __builtin_amdgcn_sched_barrier(0);
+    return ok;
+}
+
+__device__ __forceinline__ c2 fold_point(const c2 &q) { return q; }
+__device__ __forceinline__ c2 fold_point(const float4 &q) { return c2{(q.x + q.y) / 2.0f, (q.z + q.w) / 2.0f}; }
+
+// Windowed packed frame r[j] = z[lane + 64 j] from the fetched samples; wv = first half of the window
+template <typename V>
+__device__ __forceinline__ void window_fetched(c2 (&r)[16], const V (&pf)[16], const c2 *wv, int lane) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const c2 w = wv[lane + 64 * j];
+        const c2 lo = fold_point(pf[j]), hi = fold_point(pf[j + 8]);
+        r[j] = lo * w;
+        r[j + 8] = __builtin_elementwise_fma(-hi, w, hi);  // w[n + 1024] = 1 - w[n]
+    }
+}
+
+// Any frame (zero-padded tail, odd alignment, any channel count): staged through the wave's buffer.
+__device__ __noinline__ void stage_frame_half_window(c2 *buf, const float *__restrict__ xs, int64_t n, int n_ch,
+                                                     int64_t p0, const float *__restrict__ whalf, int lane) {
+#pragma unroll 1
+    for (int i = lane; i < NC; i += 64) {
+        const float u = fold_sample(xs, p0 + 2 * i, n, n_ch), v = fold_sample(xs, p0 + 2 * i + 1, n, n_ch);
+        const int wi = 2 * (i & 511);
+        const float w0 = whalf[wi], w1 = whalf[wi + 1];
+        buf[nat(i)] = i < 512 ? c2{u * w0, v * w1} : c2{__builtin_fmaf(-u, w0, u), __builtin_fmaf(-v, w1, v)};
+    }
 }
 
 // --------------------------------------------------- transposed power / magnitude rows
@@ -424,7 +539,7 @@ __global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ 
     __syncthreads();
     const LaneTw tw = lane_tw(twtab, lane);
     c2 rtw[8];
-    load_rtw(rtw, as_c2(tb.rtw), lane);
+    derive_rtw(rtw, as_c2(tb.rtw)[lane]);            // as the one-wave-per-run kernels derive them
     const float scale = (float)(1.0 / tb.wsum);
     const int ts = FT + 1;
     float vmax = 0.0f;
@@ -437,8 +552,28 @@ __global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ 
         const int ft = it * W + wave;
         const int64_t t = t0 + ft;
         if (t < Tn) {
+            // the loader and window arithmetic of the one-wave-per-run kernels (second half of the window applied as
+            // x - x w[n - 1024]), so that a frame gives the same bits whichever kernel transforms it
             c2 r[16];
-            load_frame(r, buf, xs, n, sg.n_ch, t * sg.hop, wtab, lane);
+            bool direct;
+            const c2 *wv = reinterpret_cast<const c2 *>(wtab);
+            if (sg.n_ch == 2) {
+                float4 pf[16];
+                direct = fetch_frame<2>(pf, xs, n, 2, t * sg.hop, lane);
+                if (direct) window_fetched(r, pf, wv, lane);
+            } else {
+                c2 pf[16];
+                direct = fetch_frame<1>(pf, xs, n, sg.n_ch, t * sg.hop, lane);
+                if (direct) window_fetched(r, pf, wv, lane);
+            }
+            if (!direct) {
+                stage_frame_half_window(buf, xs, n, sg.n_ch, t * sg.hop, wtab, lane);
+                wave_sync();
+                const c2 *nb = buf + lane;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) r[j] = nb[64 * j + 8 * (j >> 2)];        // nat(lane + 64 j)
+                wave_sync();
+            }
             wave_fft1024<false>(r, buf, tw, lane);
             store_natural(r, buf, lane);
             wave_sync();
@@ -448,8 +583,8 @@ __global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ 
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = lane + 64 * j;
-                float p0 = s.lo[j].x * s.lo[j].x + s.lo[j].y * s.lo[j].y;
-                float p1 = s.hi[j].x * s.hi[j].x + s.hi[j].y * s.hi[j].y;
+                float p0 = norm2(s.lo[j]);
+                float p1 = norm2(s.hi[j]);
                 if (!power) {
                     p0 = __builtin_amdgcn_sqrtf(p0);
                     p1 = __builtin_amdgcn_sqrtf(p1);
@@ -459,7 +594,7 @@ __global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ 
                 vmax = fmaxf(vmax, fmaxf(p0, p1));
             }
             if (lane == 0) {
-                float pm = s.mid.x * s.mid.x + s.mid.y * s.mid.y;
+                float pm = norm2(s.mid);
                 if (!power) pm = __builtin_amdgcn_sqrtf(pm);
                 tile[512 * ts + ft] = pm;
                 vmax = fmaxf(vmax, pm);
@@ -959,83 +1094,6 @@ __global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
 // factors of a lane are one value times compile-time constants.
 static constexpr int GROW = 1032;                 // floats of a gain / noise row slot (1025 used)
 
-// exp(-2 pi i (lane + 64 j) / 2048) = rtw0 * exp(-i pi j / 16)
-__device__ __forceinline__ void derive_rtw(c2 (&rtw)[8], c2 rtw0) {
-    rtw[0] = rtw0;
-    rtw[1] = mul_k(rtw0, c2{0.9807852804032304f, -0.19509032201612825f});
-    rtw[2] = mul_k(rtw0, c2{0.9238795325112867f, -0.3826834323650898f});
-    rtw[3] = mul_k(rtw0, c2{0.8314696123025452f, -0.5555702330196022f});
-    rtw[4] = mul_k(rtw0, c2{0.7071067811865476f, -0.7071067811865476f});
-    rtw[5] = mul_k(rtw0, c2{0.5555702330196022f, -0.8314696123025452f});
-    rtw[6] = mul_k(rtw0, c2{0.3826834323650898f, -0.9238795325112867f});
-    rtw[7] = mul_k(rtw0, c2{0.19509032201612825f, -0.9807852804032304f});
-}
-
-// Raw samples of the frame at padded position p0, requested into registers (no arithmetic, so
-// that the loads stay in flight).  NCH = 1: pf[j] is packed point lane + 64 j; NCH = 2: pf[j] holds
-// the two (left, right) pairs of packed point lane + 64 j.  Returns false when the frame needs the
-// generic loader instead (tail of the signal, odd alignment, another channel count).
-template <int NCH> struct FetchT;
-template <> struct FetchT<1> { typedef c2 type; };
-template <> struct FetchT<2> { typedef float4 type; };
-
-typedef float f4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ c2 load_streaming(const c2 *p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ float4 load_streaming(const float4 *p) {
-    const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));
-    return float4{v.x, v.y, v.z, v.w};
-}
-
-template <int NCH>
-__device__ __forceinline__ bool fetch_frame(typename FetchT<NCH>::type (&pf)[16], const float *__restrict__ xs, int64_t n,
-                                            int n_ch, int64_t p0, int lane) {
-    typedef typename FetchT<NCH>::type V;
-    const bool ok = p0 + 2048 <= n && n_ch == NCH && (reinterpret_cast<uintptr_t>(xs + NCH * p0) & (sizeof(V) - 1)) == 0;
-    // No branch around the loads (a join between the loads and their first use would make the
-    // compiler wait for every younger memory operation as well): a frame that cannot be fetched this
-    // way reads the first 2048 frames of the signal instead, from the address rounded down to the
-    // load size, and the result is ignored.  Every signal holds at least one whole frame; rounding
-    // down stays inside the caller's buffer because only element offsets inside it can be odd.
-    // (pointer arithmetic only: an integer round trip would turn the loads into flat ones)
-    const float *src = ok ? xs + NCH * p0 : xs - ((reinterpret_cast<uintptr_t>(xs) & (sizeof(V) - 1)) >> 2);
-    const V *xv = reinterpret_cast<const V *>(src) + lane;
-    __builtin_amdgcn_sched_barrier(0);
-    // the first quarter of a frame is the hop that no later frame of the run reads again: it is loaded
-    // with the streaming hint, so that the cache keeps the three hops the next steps come back for
-#pragma unroll
-    for (int j = 0; j < 4; ++j) pf[j] = load_streaming(xv + 64 * j);
-#pragma unroll
-    for (int j = 4; j < 16; ++j) pf[j] = xv[64 * j];
-    __builtin_amdgcn_sched_barrier(0);
-    return ok;
-}
-
-__device__ __forceinline__ c2 fold_point(const c2 &q) { return q; }
-__device__ __forceinline__ c2 fold_point(const float4 &q) { return c2{(q.x + q.y) / 2.0f, (q.z + q.w) / 2.0f}; }
-
-// Windowed packed frame r[j] = z[lane + 64 j] from the fetched samples; wv = first half of the window
-template <typename V>
-__device__ __forceinline__ void window_fetched(c2 (&r)[16], const V (&pf)[16], const c2 *wv, int lane) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const c2 w = wv[lane + 64 * j];
-        const c2 lo = fold_point(pf[j]), hi = fold_point(pf[j + 8]);
-        r[j] = lo * w;
-        r[j + 8] = hi - hi * w;                            // w[n + 1024] = 1 - w[n]
-    }
-}
-
-// Any frame (zero-padded tail, odd alignment, any channel count): staged through the wave's buffer.
-__device__ __noinline__ void stage_frame_half_window(c2 *buf, const float *__restrict__ xs, int64_t n, int n_ch,
-                                                     int64_t p0, const float *__restrict__ whalf, int lane) {
-#pragma unroll 1
-    for (int i = lane; i < NC; i += 64) {
-        const float u = fold_sample(xs, p0 + 2 * i, n, n_ch), v = fold_sample(xs, p0 + 2 * i + 1, n, n_ch);
-        const int wi = 2 * (i & 511);
-        const float w0 = whalf[wi], w1 = whalf[wi + 1];
-        buf[nat(i)] = i < 512 ? c2{u * w0, v * w1} : c2{u - u * w0, v - v * w1};
-    }
-}
 
 // NCH: the channel count whose frames are fetched straight into registers (other counts, and frames
 // at the zero-padded tail of a signal, take the staged loader)
@@ -1386,13 +1444,13 @@ void k_apply_wave(ApplyArgs<float> a) {
             {
                 c2 rtw[8];
                 derive_rtw(rtw, rtw0);
-                merge_spectrum(sp, buf, rtw, lane);
+                merge_spectrum_keep(sp, r, buf, rtw, lane);
             }
             wave_sync();
             {
                 const c2 *nb = buf + lane;
 #pragma unroll
-                for (int j = 0; j < 16; ++j) r[j] = nb[64 * j + 8 * (j >> 2)];        // nat(lane + 64 j)
+                for (int j = 8; j < 16; ++j) r[j] = nb[64 * j + 8 * (j >> 2)];        // nat(lane + 64 j)
             }
             wave_sync();
             tick(4);
@@ -1423,6 +1481,117 @@ void k_apply_wave(ApplyArgs<float> a) {
     if (PROF && lane0 == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&a.dbg[i], ph[i]);
 }
+
+// ------------------------------------ power / magnitude rows, one wave per run of frames
+// The statistics pass of the Wiener stage.  A wave walks consecutive frames alone (no workgroup barrier after
+// the tables are staged), keeps the 17 values of its bins for four frames in registers and writes them as one
+// 16-byte store per bin: S[signal][frame / 4][bin][frame % 4].  Every store instruction of a wave is 1 KB of
+// consecutive bytes, no transposition through LDS and nothing for the waves to wait for each other; the row
+// statistics read a bin's values as one 16-byte piece per group of four frames.
+template <int W, int NCH>
+__global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_rows_wave(const float *__restrict__ x, Signals sg, Tables<float> tb, int64_t n_sig, int64_t runs_per_sig,
+                 int groups_per_run, int64_t sig_stride, int power, float *__restrict__ S, float *__restrict__ dummy) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    constexpr int H = 512;
+    c2 *bufs = reinterpret_cast<c2 *>(smem);                                          // [W][WBUF] exchange
+    c2 *twtab = bufs + (size_t)W * WBUF;
+    float *wtab = reinterpret_cast<float *>(twtab + TWTAB);                           // [1024] first half of the window
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane0 = threadIdx.x & 63, tid = threadIdx.x;
+    fill_tw_table(twtab, tb.fast_tw, tid, W * 64);
+    for (int i = tid; i < 1024; i += W * 64) wtab[i] = tb.window[i];
+    __syncthreads();                                       // the only workgroup barrier: every wave reaches it
+    const int64_t gid = (int64_t)blockIdx.x * W + wave;
+    const int64_t sig = gid / runs_per_sig;
+    if (sig >= n_sig) return;
+    const int run = (int)(gid % runs_per_sig);
+    const int64_t n = sg.len[sig];
+    const int Tn = (int)stft_frames(n, 2048, H, sg.padded);
+    const int g0 = run * groups_per_run;
+    if (4 * g0 >= Tn) return;
+    const int g_all = (Tn + 3) >> 2;
+    const int g1 = g0 + groups_per_run < g_all ? g0 + groups_per_run : g_all;
+    const float *xs = x + sg.off[sig];
+    float4 *Sg = reinterpret_cast<float4 *>(S + sig * sig_stride);
+    c2 *buf = bufs + wave * WBUF;
+    const c2 *wv = reinterpret_cast<const c2 *>(wtab);
+    const c2 rtw0 = as_c2(tb.rtw)[lane0];
+    const float scale = (float)(1.0 / tb.wsum);
+    float m0[17], m1[17], m2[17], m3[17];                  // the lane's bins of the group's four frames
+#pragma unroll
+    for (int i = 0; i < 17; ++i) m0[i] = m1[i] = m2[i] = m3[i] = 0.0f;
+#pragma unroll 1
+    for (int t = 4 * g0; t < 4 * g1; ++t) {
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));                     // lane-derived addresses are re-derived per frame, not kept
+        float p[17];
+        if (t < Tn) {
+            const LaneTw tw = lane_tw(twtab, lane);
+            typename FetchT<NCH>::type pf[16];
+            const bool pf_mode = fetch_frame<NCH>(pf, xs, n, sg.n_ch, (int64_t)t * H, lane);
+            c2 r[16];
+            if (pf_mode) {
+                window_fetched(r, pf, wv, lane);
+            } else {
+                stage_frame_half_window(buf, xs, n, sg.n_ch, (int64_t)t * H, wtab, lane);
+                wave_sync();
+                const c2 *nb = buf + lane;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) r[j] = nb[64 * j + 8 * (j >> 2)];        // nat(lane + 64 j)
+                wave_sync();
+            }
+            wave_fft1024<false>(r, buf, tw, lane);
+            store_natural(r, buf, lane);
+            wave_sync();
+            Spec sp;
+            {
+                c2 rtw[8];
+                derive_rtw(rtw, rtw0);
+                split_spectrum(sp, buf, rtw, scale, lane);
+            }
+            wave_sync();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                p[j] = norm2(sp.lo[j]);
+                p[8 + j] = norm2(sp.hi[j]);
+            }
+            p[16] = norm2(sp.mid);
+            if (!power) {
+#pragma unroll
+                for (int i = 0; i < 17; ++i) p[i] = __builtin_amdgcn_sqrtf(p[i]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 17; ++i) p[i] = 0.0f;      // frames past the signal's end inside its last group
+        }
+        const int e = t & 3;
+        if (e == 0) {
+#pragma unroll
+            for (int i = 0; i < 17; ++i) m0[i] = p[i];
+        } else if (e == 1) {
+#pragma unroll
+            for (int i = 0; i < 17; ++i) m1[i] = p[i];
+        } else if (e == 2) {
+#pragma unroll
+            for (int i = 0; i < 17; ++i) m2[i] = p[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 17; ++i) m3[i] = p[i];
+            float4 *dst = Sg + (int64_t)(t >> 2) * 1025;
+            float4 *dlo = dst + lane, *dhi = dst + 1024 - lane;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                __builtin_nontemporal_store(f4v{m0[j], m1[j], m2[j], m3[j]}, reinterpret_cast<f4v *>(dlo + 64 * j));
+                __builtin_nontemporal_store(f4v{m0[8 + j], m1[8 + j], m2[8 + j], m3[8 + j]}, reinterpret_cast<f4v *>(dhi - 64 * j));
+            }
+            // bin 512 belongs to lane 0; the other lanes' (meaningless) values go to a scratch line
+            float4 *dm = lane == 0 ? dst + 512 : reinterpret_cast<float4 *>(dummy) + lane;
+            *dm = float4{m0[16], m1[16], m2[16], m3[16]};
+        }
+    }
+}
+
+static size_t rows_wave_lds(int W) { return (size_t)W * WBUF * sizeof(c2) + (size_t)TWTAB * sizeof(c2) + 1024 * sizeof(float); }
 
 static size_t apply_wave_lds(int W, int mode) {
     return (size_t)W * WBUF * sizeof(c2) + (size_t)W * (mode == APPLY_SUBTRACT ? PARK : 0) * sizeof(c2) +
@@ -1544,6 +1713,34 @@ int rows_fast(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &
     const int64_t wgs = ceil_div(groups, (int64_t)fast::ROWS_GPW);
     ADN_LAUNCH_NAMED("k_rows_fast", kern, dim3((unsigned)(wgs * n_sig)), dim3(W * 64), lds, c->stream, d_x, sg, tb,
                        groups, FT, Tmax, power, S, sig_max);
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
+
+bool rows_wave_ok(const Signals &sg, int n_fft) { return n_fft == 2048 && sg.hop == 512; }
+
+// Rows in groups of four frames: S[(s * sig_stride) + ((t / 4) * 1025 + k) * 4 + t % 4]; sig_stride >= 4100 * ceil(Tmax / 4).
+// The caller has reserved APPLY_WS_BYTES of workspace beyond what it took.
+int rows_wave(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &tb, int64_t n_sig, int64_t Tmax,
+              int power, float *S, int64_t sig_stride) {
+    constexpr int W = 4;
+    if (c->ws_used + APPLY_WS_BYTES > c->ws_bytes) {
+        set_error("internal: the caller of the rows kernel did not reserve its scratch line");
+        return ADN_ERR_NOMEM;
+    }
+    float *dummy = ws_take<float>(c, APPLY_WS_BYTES / sizeof(float));
+    const int64_t groups = ceil_div(Tmax, (int64_t)4);
+    // about two rounds of runs over the waves a full chip holds
+    int64_t gpr = ceil_div(n_sig * groups, (int64_t)c->num_cus * 12 * 2);
+    gpr = gpr < 4 ? 4 : (gpr > 64 ? 64 : gpr);
+    const int64_t runs_per_sig = ceil_div(groups, gpr);
+    const int64_t wgs = ceil_div(n_sig * runs_per_sig, (int64_t)W);
+    ADN_REQUIRE(wgs < (int64_t)0x7FFFFFFF, "batch too large for one launch");
+    const size_t lds = fast::rows_wave_lds(W);
+    auto kern = sg.n_ch == 2 ? fast::k_rows_wave<W, 2> : fast::k_rows_wave<W, 1>;
+    ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ADN_LAUNCH_NAMED("k_rows_wave", kern, dim3((unsigned)wgs), dim3(W * 64), lds, c->stream, d_x, sg, tb, n_sig, runs_per_sig,
+                     (int)gpr, sig_stride, power, S, dummy);
     ADN_HIP(hipGetLastError());
     return ADN_OK;
 }

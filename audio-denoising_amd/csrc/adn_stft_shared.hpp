@@ -107,6 +107,10 @@ static constexpr size_t APPLY_WS_BYTES = 4096;
 
 // register-resident path (binary32, n_fft = 2048)
 bool apply_fast_ok(int n_fft, int hop, int st, int sf);
+// binary32 rows in groups of four frames (see k_rows_wave); the caller reserves APPLY_WS_BYTES beyond what it took
+bool rows_wave_ok(const Signals &sg, int n_fft);
+int rows_wave(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &tb, int64_t n_sig, int64_t Tmax,
+              int power, float *S, int64_t sig_stride);
 template <int MODE>
 int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax);
 int rows_fast(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &tb, int64_t n_sig,
