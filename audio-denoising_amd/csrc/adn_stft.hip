@@ -513,6 +513,22 @@ __global__ __launch_bounds__(256) void k_vad_energy(const T *__restrict__ x, Sig
     }
 }
 
+// The same decision from energies that another kernel has added up (energy[sig * nv_max + i] = sum of squares).
+__global__ void k_vad_flags(Signals sg, int64_t n_sig, int64_t frame_len, int64_t nv_max, const double *__restrict__ energy,
+                            unsigned char *__restrict__ speech) {
+    const int64_t gid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (gid >= n_sig * nv_max) return;
+    const int64_t sig = gid / nv_max, i = gid % nv_max;
+    const int64_t n = sg.len[sig];
+    const int64_t s = i * frame_len, e = (s + frame_len < n) ? s + frame_len : n;
+    unsigned char f = 0;
+    if (e > s) {
+        const double rms = sqrt(energy[gid] / (double)(e - s) + 1e-12);
+        f = 20.0 * log10(rms + 1e-12) > -40.0;
+    }
+    speech[gid] = f;
+}
+
 // Hangover (a frame is speech if any of frames i-5..i fired) and the map from STFT
 // frames to VAD frames: idx = min(int(t*hop/frame_len), n_vad-1)  (src/wiener_filter.py:27-33, 92-98).
 __global__ void k_vad_map(Signals sg, int64_t n_sig, int64_t frame_len, int64_t nv_max, int64_t Tmax,
@@ -1089,8 +1105,9 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     const size_t nS = (size_t)n_sig * F * Ts, nR = (size_t)n_sig * F;
     ADN_TRY(ws_reserve(c, ws_need(nS, sizeof(T)) + ws_need(n_sig, 8) + 2 * ws_need(nR, 8) + ws_need(nR, sizeof(T)) +
                               ws_need((size_t)n_sig * nv_max, 1) + ws_need((size_t)n_sig * Ts, 1) + ws_need(n_sig, 4) +
-                              2 * select_ws_bytes(n_sig * F, Tmax) + 2 * APPLY_WS_BYTES));
+                              2 * select_ws_bytes(n_sig * F, Tmax) + 2 * APPLY_WS_BYTES + ws_need((size_t)n_sig * nv_max, 8)));
     T *S = ws_take<T>(c, nS);
+    double *vad_e = ws_take<double>(c, (size_t)n_sig * nv_max);
     int64_t *Tn = ws_take<int64_t>(c, n_sig);
     double *p10 = ws_take<double>(c, nR), *sraw = ws_take<double>(c, nR);
     T *gain = d_gain ? d_gain : ws_take<T>(c, nR);
@@ -1098,20 +1115,31 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     unsigned char *vad = ws_take<unsigned char>(c, (size_t)n_sig * Ts);   // rows padded like S
     Signals sg{d_off, d_len, n_ch, n_fft, hop, 1};
     ADN_LAUNCH(k_frame_counts, dim3((unsigned)ceil_div(n_sig, 256)), dim3(256), 0, c->stream, sg, n_sig, Tn);
-    if (vad_guided) {
+    SelectArgs sa;
+    // binary32 rows of up to a few thousand frames: power rows in groups of four frames, written by waves that
+    // work alone and read by the register-resident row select; the rows kernel adds up the voice-activity
+    // frames' energies on the way when those frames are at least a hop long
+    bool grouped = false;
+    if constexpr (std::is_same<T, float>::value)
+        grouped = !c->force_generic && (c->ablate & 64) == 0 && rows_wave_ok(sg, n_fft) && Tmax <= select_grouped_limit();
+    const bool vad_in_rows = grouped && vad_guided && (c->ablate & 128) == 0 && frame_len >= hop &&
+                             frame_len <= rows_wave_vad_max_frame();
+    if (vad_guided && !vad_in_rows) {
         ADN_LAUNCH((k_vad_energy<T>), dim3((unsigned)ceil_div(n_sig * nv_max, 4)), dim3(256), 0, c->stream,
                            d_x, sg, n_sig, frame_len, nv_max, speech);
         ADN_LAUNCH(k_vad_map, dim3((unsigned)ceil_div(n_sig * Ts, 256)), dim3(256), 0, c->stream, sg, n_sig,
                            frame_len, nv_max, Ts, speech, vad);
     }
-    SelectArgs sa;
-    // binary32 rows of up to a few thousand frames: power rows in groups of four frames, written by waves that
-    // work alone and read by the register-resident row select
-    bool grouped = false;
-    if constexpr (std::is_same<T, float>::value)
-        grouped = !c->force_generic && (c->ablate & 64) == 0 && rows_wave_ok(sg, n_fft) && Tmax <= select_grouped_limit();
     if (grouped) {
-        if constexpr (std::is_same<T, float>::value) ADN_TRY(rows_wave(c, d_x, sg, tb, n_sig, Tmax, 1, S, (int64_t)F * Ts));
+        if (vad_in_rows) ADN_HIP(hipMemsetAsync(vad_e, 0, (size_t)n_sig * nv_max * sizeof(double), c->stream));
+        if constexpr (std::is_same<T, float>::value)
+            ADN_TRY(rows_wave(c, d_x, sg, tb, n_sig, Tmax, 1, S, (int64_t)F * Ts, vad_in_rows ? vad_e : nullptr, frame_len, nv_max));
+        if (vad_in_rows) {
+            ADN_LAUNCH(k_vad_flags, dim3((unsigned)ceil_div(n_sig * nv_max, 256)), dim3(256), 0, c->stream, sg, n_sig,
+                       frame_len, nv_max, vad_e, speech);
+            ADN_LAUNCH(k_vad_map, dim3((unsigned)ceil_div(n_sig * Ts, 256)), dim3(256), 0, c->stream, sg, n_sig,
+                       frame_len, nv_max, Ts, speech, vad);
+        }
         sa.quad_stride = F;
         sa.blk_rows = F;
         sa.blk_sig_stride = (int64_t)F * Ts;

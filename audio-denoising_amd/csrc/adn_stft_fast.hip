@@ -1482,16 +1482,42 @@ void k_apply_wave(ApplyArgs<float> a) {
         for (int i = 0; i < 8; ++i) atomicAdd(&a.dbg[i], ph[i]);
 }
 
+// Sum of a binary64 value over the wave, delivered in lane 63: four shifts inside the rows of sixteen lanes, then
+// the two row broadcasts (data-parallel-primitive moves of the two halves, no LDS round trips).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    const double o = __hiloint2double(hi, lo);
+    // lanes outside the row mask (or without a source lane) receive +0.0
+    return v + o;
+}
+__device__ __forceinline__ double wave_sum_to_last_lane(double v) {
+    v = dpp_add_f64<0x111, 0xf>(v);     // row_shr:1
+    v = dpp_add_f64<0x112, 0xf>(v);     // row_shr:2
+    v = dpp_add_f64<0x114, 0xf>(v);     // row_shr:4
+    v = dpp_add_f64<0x118, 0xf>(v);     // row_shr:8: lane 15 of every row holds the row's sum
+    v = dpp_add_f64<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3
+    v = dpp_add_f64<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    return v;
+}
+
 // ------------------------------------ power / magnitude rows, one wave per run of frames
 // The statistics pass of the Wiener stage.  A wave walks consecutive frames alone (no workgroup barrier after
 // the tables are staged), keeps the 17 values of its bins for four frames in registers and writes them as one
 // 16-byte store per bin: S[signal][frame / 4][bin][frame % 4].  Every store instruction of a wave is 1 KB of
 // consecutive bytes, no transposition through LDS and nothing for the waves to wait for each other; the row
 // statistics read a bin's values as one 16-byte piece per group of four frames.
-template <int W, int NCH>
+// VADE: the kernel also adds up the energy of the voice-activity frames (src/wiener_filter.py:17-26: frames of
+// frame_len samples, frame_len >= the hop) from the samples it holds anyway.  A run owns the first hop of each of
+// its frames (the signal's last run: everything up to the signal's end); per lane two binary64 accumulators, for
+// the voice-activity frame the run is in and for the next one; a finished frame's sum goes to vad_e[frame] with
+// one atomic addition per run that holds a part of it -- at most two runs, so the sum does not depend on their order.
+template <int W, int NCH, bool VADE>
 __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_rows_wave(const float *__restrict__ x, Signals sg, Tables<float> tb, int64_t n_sig, int64_t runs_per_sig,
-                 int groups_per_run, int64_t sig_stride, int power, float *__restrict__ S, float *__restrict__ dummy) {
+                 int groups_per_run, int64_t sig_stride, int power, float *__restrict__ S, float *__restrict__ dummy,
+                 double *__restrict__ vad_e, int64_t frame_len, int64_t nv_max) {
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int H = 512;
     c2 *bufs = reinterpret_cast<c2 *>(smem);                                          // [W][WBUF] exchange
@@ -1520,6 +1546,43 @@ void k_rows_wave(const float *__restrict__ x, Signals sg, Tables<float> tb, int6
     float m0[17], m1[17], m2[17], m3[17];                  // the lane's bins of the group's four frames
 #pragma unroll
     for (int i = 0; i < 17; ++i) m0[i] = m1[i] = m2[i] = m3[i] = 0.0f;
+    // voice-activity energies: accA belongs to frame vcur, accB to frame vcur + 1
+    double accA = 0.0, accB = 0.0;
+    int64_t vcur = -1;
+    double *ve = VADE ? vad_e + sig * nv_max : nullptr;
+    auto vad_flush = [&](double v, int64_t fr) {
+        v = wave_sum_to_last_lane(v);
+        if (lane0 == 63 && fr >= 0 && fr < nv_max) atomicAdd(&ve[fr], v);
+    };
+    // the hop at sample P; the lane holds its samples 2 lane + 128 j (+ 1) in s[j]
+    auto vad_hop = [&](int64_t P, const c2 (&sv)[4], int lane) {
+        const int64_t v0 = P / frame_len;
+        if (vcur < 0) vcur = v0;
+        if (v0 != vcur) {                                  // a hop is not longer than a frame: v0 == vcur + 1
+            vad_flush(accA, vcur);
+            accA = accB;
+            accB = 0.0;
+            vcur = v0;
+        }
+        const int64_t left = (vcur + 1) * frame_len - P;   // samples of the hop that still belong to frame vcur
+        const int rel = left < H ? (int)left : H;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i0 = 2 * lane + 128 * j;
+            const double d0 = (double)sv[j].x * (double)sv[j].x, d1 = (double)sv[j].y * (double)sv[j].y;
+            if (i0 < rel) accA += d0; else accB += d0;
+            if (i0 + 1 < rel) accA += d1; else accB += d1;
+        }
+    };
+    auto vad_hop_from_memory = [&](int64_t P, int lane) {
+        c2 sv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t q = P + 2 * lane + 128 * j;
+            sv[j] = c2{fold_sample(xs, q, n, sg.n_ch), fold_sample(xs, q + 1, n, sg.n_ch)};
+        }
+        vad_hop(P, sv, lane);
+    };
 #pragma unroll 1
     for (int t = 4 * g0; t < 4 * g1; ++t) {
         int lane = lane0;
@@ -1532,7 +1595,12 @@ void k_rows_wave(const float *__restrict__ x, Signals sg, Tables<float> tb, int6
             c2 r[16];
             if (pf_mode) {
                 window_fetched(r, pf, wv, lane);
+                if (VADE) {
+                    const c2 sv[4] = {fold_point(pf[0]), fold_point(pf[1]), fold_point(pf[2]), fold_point(pf[3])};
+                    vad_hop((int64_t)t * H, sv, lane);
+                }
             } else {
+                if (VADE) vad_hop_from_memory((int64_t)t * H, lane);
                 stage_frame_half_window(buf, xs, n, sg.n_ch, (int64_t)t * H, wtab, lane);
                 wave_sync();
                 const c2 *nb = buf + lane;
@@ -1588,6 +1656,13 @@ void k_rows_wave(const float *__restrict__ x, Signals sg, Tables<float> tb, int6
             float4 *dm = lane == 0 ? dst + 512 : reinterpret_cast<float4 *>(dummy) + lane;
             *dm = float4{m0[16], m1[16], m2[16], m3[16]};
         }
+    }
+    if (VADE) {
+        // the signal's last run also owns what lies beyond the first hop of the last frame
+        if (g1 == g_all)
+            for (int64_t P = (int64_t)Tn * H; P < n; P += H) vad_hop_from_memory(P, lane0);
+        vad_flush(accA, vcur);
+        vad_flush(accB, vcur + 1);
     }
 }
 
@@ -1718,11 +1793,12 @@ int rows_fast(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &
 }
 
 bool rows_wave_ok(const Signals &sg, int n_fft) { return n_fft == 2048 && sg.hop == 512; }
+int64_t rows_wave_vad_max_frame() { return 4 * 4 * 512; }      // the shortest run: four groups of four hops
 
 // Rows in groups of four frames: S[(s * sig_stride) + ((t / 4) * 1025 + k) * 4 + t % 4]; sig_stride >= 4100 * ceil(Tmax / 4).
 // The caller has reserved APPLY_WS_BYTES of workspace beyond what it took.
 int rows_wave(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &tb, int64_t n_sig, int64_t Tmax,
-              int power, float *S, int64_t sig_stride) {
+              int power, float *S, int64_t sig_stride, double *vad_e, int64_t frame_len, int64_t nv_max) {
     constexpr int W = 4;
     if (c->ws_used + APPLY_WS_BYTES > c->ws_bytes) {
         set_error("internal: the caller of the rows kernel did not reserve its scratch line");
@@ -1737,10 +1813,14 @@ int rows_wave(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &
     const int64_t wgs = ceil_div(n_sig * runs_per_sig, (int64_t)W);
     ADN_REQUIRE(wgs < (int64_t)0x7FFFFFFF, "batch too large for one launch");
     const size_t lds = fast::rows_wave_lds(W);
-    auto kern = sg.n_ch == 2 ? fast::k_rows_wave<W, 2> : fast::k_rows_wave<W, 1>;
+    // voice-activity energies on the way (vad_e: n_sig x nv_max sums, zero on entry): a voice-activity frame must
+    // not be longer than a run, so that at most two runs hold parts of it
+    if (vad_e) ADN_REQUIRE(frame_len >= 512 && frame_len <= rows_wave_vad_max_frame(), "internal: voice-activity frame of %lld samples", (long long)frame_len);
+    auto kern = vad_e ? (sg.n_ch == 2 ? fast::k_rows_wave<W, 2, true> : fast::k_rows_wave<W, 1, true>)
+                      : (sg.n_ch == 2 ? fast::k_rows_wave<W, 2, false> : fast::k_rows_wave<W, 1, false>);
     ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ADN_LAUNCH_NAMED("k_rows_wave", kern, dim3((unsigned)wgs), dim3(W * 64), lds, c->stream, d_x, sg, tb, n_sig, runs_per_sig,
-                     (int)gpr, sig_stride, power, S, dummy);
+                     (int)gpr, sig_stride, power, S, dummy, vad_e, frame_len, nv_max);
     ADN_HIP(hipGetLastError());
     return ADN_OK;
 }
