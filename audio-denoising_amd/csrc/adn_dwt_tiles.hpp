@@ -18,7 +18,8 @@ namespace tiles {
 
 enum { MODE_STATS = 0, MODE_APPLY = 1 };
 constexpr int TL_MAX = 4;
-constexpr int THREADS = 256;
+constexpr int THREADS_MAX = 256;
+constexpr int TILE_SMALL_TL = 2;
 
 template <typename T> struct Pk;
 template <> struct Pk<float> { typedef float type __attribute__((ext_vector_type(2))); };
@@ -195,7 +196,7 @@ template <> struct Vec2T<double> { using type = double2; };
 // owned level-TL approximation to top).  APPLY: analysis, shrink, synthesis of TL levels; the
 // level-TL approximation comes from `top` when use_top (output of k_deep), else from the
 // tile's own analysis.
-template <typename T, int F, int TL, int S, int MODE>
+template <typename T, int F, int TL, int S, int THREADS, int MODE>
 __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__restrict__ y,
                                                   BlockGeom g, int tiles_per_block,
                                                   TapsF<T, F> tp, const double *__restrict__ thresh,
@@ -498,18 +499,22 @@ __global__ __launch_bounds__(512) void k_deep(T *__restrict__ top, int64_t top_s
     for (int i = tid; i < NN[TL]; i += NT) tp_io[i] = lds[offA[TL] + i];
 }
 
-template <typename T> struct TileS;
-template <> struct TileS<float> { static constexpr int S = 4096; };
-template <> struct TileS<double> { static constexpr int S = 2048; };
+// Samples and threads of a tile.  Up to two levels in the tile: one wave per tile of 1024 (binary32) samples, so
+// that the barriers between the levels cost nothing and a CU holds a dozen independent tiles; the halo a tile
+// recomputes grows with 2^levels, so deeper tiles stay large (4096 samples, four waves).
+template <typename T, int TL> struct TileS {
+    static constexpr int S = (TL <= TILE_SMALL_TL ? 1024 : 4096) / (int)(sizeof(T) / 4);
+    static constexpr int THREADS = TL <= TILE_SMALL_TL ? 64 : 256;
+};
 
 template <typename T, int F, int TL, int MODE>
 static void launch_tile(Ctx *c, const T *x, T *y, const BlockGeom &g, int64_t max_frames, int wavelet,
                         const double *thresh, int thr_mode, int64_t *zeroed, T *d1, int64_t d1_stride,
                         T *top, int64_t top_stride, int use_top) {
-    constexpr int S = TileS<T>::S;
+    constexpr int S = TileS<T, TL>::S, THREADS = TileS<T, TL>::THREADS;
     const int tiles = (int)ceil_div(max_frames + 1, S);
     const TapsF<T, F> tp = make_taps_f<T, F>(wavelet);
-    ADN_LAUNCH((k_tile<T, F, TL, S, MODE>), dim3((unsigned)(tiles * g.n_blocks)), dim3(THREADS),
+    ADN_LAUNCH((k_tile<T, F, TL, S, THREADS, MODE>), dim3((unsigned)(tiles * g.n_blocks)), dim3(THREADS),
                        0, c->stream, x, y, g, tiles, tp, thresh, thr_mode, zeroed, d1, d1_stride, top,
                        top_stride, use_top, c->ablate);
 }
@@ -598,7 +603,7 @@ static int wavelet_denoise_fused(Ctx *c, const T *d_in, T *d_out, BlockGeom g, i
                                  double *d_thresh, int64_t *d_zeroed, const double *d_thresh_given, bool *handled) {
     *handled = false;
     if (c->force_generic || max_frames >= (int64_t(1) << 30)) return ADN_OK;
-    const int64_t tiles = ceil_div(max_frames + 1, tiles::TileS<T>::S);
+    const int64_t tiles = ceil_div(max_frames + 1, tiles::TileS<T, 1>::S);       // the smallest tile
     if (tiles * g.n_blocks >= (int64_t)0x7FFFFFFF) return ADN_OK;
     if (filter_bank(wavelet).F == 8)
         return tiles::denoise_f<T, 8>(c, d_in, d_out, g, max_frames, wavelet, level, thr_mode, d_sigma,

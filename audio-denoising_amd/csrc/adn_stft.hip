@@ -1102,7 +1102,9 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     const int64_t Tmax = stft_frames(max_len, n_fft, hop, 1);
     const int64_t nv_max = vad_guided ? (ceil_div(max_len, frame_len) < 1 ? 1 : ceil_div(max_len, frame_len)) : 1;
     const int64_t Ts = row_stride(Tmax);
-    const size_t nS = (size_t)n_sig * F * Ts, nR = (size_t)n_sig * F;
+    // (the grouped layout of binary32 rows pads the bins: slightly more per signal than F * Ts)
+    const int64_t sig_floats = std::max<int64_t>((int64_t)F * Ts, rows_wave_sig_floats(Tmax));
+    const size_t nS = (size_t)n_sig * sig_floats, nR = (size_t)n_sig * F;
     ADN_TRY(ws_reserve(c, ws_need(nS, sizeof(T)) + ws_need(n_sig, 8) + 2 * ws_need(nR, 8) + ws_need(nR, sizeof(T)) +
                               ws_need((size_t)n_sig * nv_max, 1) + ws_need((size_t)n_sig * Ts, 1) + ws_need(n_sig, 4) +
                               2 * select_ws_bytes(n_sig * F, Tmax) + 2 * APPLY_WS_BYTES + ws_need((size_t)n_sig * nv_max, 8)));
@@ -1133,16 +1135,16 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     if (grouped) {
         if (vad_in_rows) ADN_HIP(hipMemsetAsync(vad_e, 0, (size_t)n_sig * nv_max * sizeof(double), c->stream));
         if constexpr (std::is_same<T, float>::value)
-            ADN_TRY(rows_wave(c, d_x, sg, tb, n_sig, Tmax, 1, S, (int64_t)F * Ts, vad_in_rows ? vad_e : nullptr, frame_len, nv_max));
+            ADN_TRY(rows_wave(c, d_x, sg, tb, n_sig, Tmax, 1, S, sig_floats, vad_in_rows ? vad_e : nullptr, frame_len, nv_max));
         if (vad_in_rows) {
             ADN_LAUNCH(k_vad_flags, dim3((unsigned)ceil_div(n_sig * nv_max, 256)), dim3(256), 0, c->stream, sg, n_sig,
                        frame_len, nv_max, vad_e, speech);
             ADN_LAUNCH(k_vad_map, dim3((unsigned)ceil_div(n_sig * Ts, 256)), dim3(256), 0, c->stream, sg, n_sig,
                        frame_len, nv_max, Ts, speech, vad);
         }
-        sa.quad_stride = F;
+        sa.quad_stride = ROWS_GROUP_STRIDE;
         sa.blk_rows = F;
-        sa.blk_sig_stride = (int64_t)F * Ts;
+        sa.blk_sig_stride = sig_floats;
     } else {
         ADN_TRY(rows_dispatch<T>(c, d_x, sg, tb, n_sig, Ts, 1, S, nullptr));
     }

@@ -1645,7 +1645,7 @@ void k_rows_wave(const float *__restrict__ x, Signals sg, Tables<float> tb, int6
         } else {
 #pragma unroll
             for (int i = 0; i < 17; ++i) m3[i] = p[i];
-            float4 *dst = Sg + (int64_t)(t >> 2) * 1025;
+            float4 *dst = Sg + (int64_t)(t >> 2) * ROWS_GROUP_STRIDE;
             float4 *dlo = dst + lane, *dhi = dst + 1024 - lane;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -1793,9 +1793,11 @@ int rows_fast(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &
 }
 
 bool rows_wave_ok(const Signals &sg, int n_fft) { return n_fft == 2048 && sg.hop == 512; }
+int64_t rows_wave_sig_floats(int64_t Tmax) { return ceil_div(Tmax, (int64_t)4) * ROWS_GROUP_STRIDE * 4; }
 int64_t rows_wave_vad_max_frame() { return 4 * 4 * 512; }      // the shortest run: four groups of four hops
 
-// Rows in groups of four frames: S[(s * sig_stride) + ((t / 4) * 1025 + k) * 4 + t % 4]; sig_stride >= 4100 * ceil(Tmax / 4).
+// Rows in groups of four frames: S[(s * sig_stride) + ((t / 4) * ROWS_GROUP_STRIDE + k) * 4 + t % 4];
+// sig_stride >= rows_wave_sig_floats(Tmax).
 // The caller has reserved APPLY_WS_BYTES of workspace beyond what it took.
 int rows_wave(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &tb, int64_t n_sig, int64_t Tmax,
               int power, float *S, int64_t sig_stride, double *vad_e, int64_t frame_len, int64_t nv_max) {

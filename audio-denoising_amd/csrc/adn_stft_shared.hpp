@@ -108,6 +108,10 @@ static constexpr size_t APPLY_WS_BYTES = 4096;
 // register-resident path (binary32, n_fft = 2048)
 bool apply_fast_ok(int n_fft, int hop, int st, int sf);
 // binary32 rows in groups of four frames (see k_rows_wave); the caller reserves APPLY_WS_BYTES beyond what it took
+// 16-byte slots per group of four frames: the 1025 bins padded to a multiple of eight, so that the eight rows
+// whose pieces share a 128-byte line are the same eight rows in every group
+constexpr int64_t ROWS_GROUP_STRIDE = 1032;
+int64_t rows_wave_sig_floats(int64_t Tmax);                // floats of one signal's rows
 bool rows_wave_ok(const Signals &sg, int n_fft);
 // vad_e (may be null): n_sig x nv_max binary64 sums, zero on entry, receive the energy of every voice-activity frame
 // of frame_len samples (512 <= frame_len <= rows_wave_vad_max_frame())
