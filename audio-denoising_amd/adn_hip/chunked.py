@@ -119,9 +119,10 @@ class OrderStatSearch:
     def finished(self):
         return self.done_bits >= self.key_bits
 
-    def local_hist(self, vals, offs, lens, absdev=False, centers=None):
+    def local_hist(self, vals, offs, lens, absdev=False, centers=None, max_len=None):
         hist = torch.empty((self.rank.numel(), 256), dtype=torch.int32, device=self.e.torch_device)
-        self.e.select_hist(vals, offs, lens, self.prefix, self.done_bits, hist, absdev=absdev, centers=centers)
+        self.e.select_hist(vals, offs, lens, self.prefix, self.done_bits, hist, absdev=absdev, centers=centers,
+                           max_len=max_len)
         return hist
 
     def resolve(self, hist_total):
@@ -133,16 +134,25 @@ class OrderStatSearch:
 
 
 def order_statistics(engine, parts, ranks_list, dtype, reducer, absdev=False, centers=None):
-    """parts: list of (vals, offs, lens) per local chunk (device tensors; offs / lens int64 per segment).
-    ranks_list: list of rank arrays; returns one float64 tensor of values per rank array."""
-    out = []
-    for ranks in ranks_list:
-        s = OrderStatSearch(engine, ranks, dtype)
-        while not s.finished:
-            hists = [s.local_hist(v, o, l, absdev, centers) for (v, o, l) in parts]
-            s.resolve(reducer.sum(hists))
-        out.append(s.values())
-    return out
+    """parts: list of (vals, offs, lens[, max_len]) per local chunk (device tensors; offs / lens int64 per segment;
+    max_len = the longest segment of the chunk, saves a device round trip).  ranks_list: list of rank arrays, one
+    rank per segment each; returns one float64 tensor of values per rank array.  All rank arrays descend together:
+    the segments are simply listed once per rank array, so a median costs the rounds of ONE order statistic."""
+    R = len(ranks_list)
+    n_seg = len(ranks_list[0])
+    ranks = np.concatenate([np.asarray(r, dtype=np.int64) for r in ranks_list])
+    rep = []
+    for part in parts:
+        v, o, l = part[0], part[1], part[2]
+        ml = part[3] if len(part) > 3 else None
+        rep.append((v, o.repeat(R), l.repeat(R), ml))
+    cen = None if centers is None else centers.repeat(R)
+    s = OrderStatSearch(engine, ranks, dtype)
+    while not s.finished:
+        hists = [s.local_hist(v, o, l, absdev, cen, ml) for (v, o, l, ml) in rep]
+        s.resolve(reducer.sum(hists))
+    vals = s.values()
+    return [vals[i * n_seg:(i + 1) * n_seg] for i in range(R)]
 
 
 def _median_ranks(n):
@@ -164,7 +174,7 @@ def wavelet_block_threshold(engine, chunk_bufs, owned_lens, halo, block_len, wav
     parts = []
     for buf, owned in zip(chunk_bufs, owned_lens):
         cd1 = e.wavedec(buf, wavelet, 1, "per")[1][halo // 2: halo // 2 + owned // 2].contiguous()
-        parts.append((cd1, e._i64([0]), e._i64([cd1.numel()])))
+        parts.append((cd1, e._i64([0]), e._i64([cd1.numel()]), cd1.numel()))
     n = block_len // 2
     r0, r1 = _median_ranks(n)
     a, b = order_statistics(e, parts, [[r0], [r1]], dtype, reducer)
@@ -212,7 +222,7 @@ def wiener_chunk_stats(engine, sub, frames_owned, vad_buf, vad_base, n_total, t0
     F, ts = S.shape
     offs = e._i64(np.arange(F, dtype=np.int64) * ts)
     lens = e._i64(np.full(F, frames_owned, dtype=np.int64))
-    return {"S": S, "part": (S.view(-1), offs, lens), "sums": sums, "count": count}
+    return {"S": S, "part": (S.view(-1), offs, lens, frames_owned), "sums": sums, "count": count}
 
 
 def wiener_gain_from_chunks(engine, stats, frames_total, dtype, reducer, kernel_bins=5, vad_guided=True):
