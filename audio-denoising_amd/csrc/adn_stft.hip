@@ -988,6 +988,9 @@ static int apply_dispatch(Ctx *c, const ApplyArgs<T> &a, int64_t n_sig, int64_t 
         // the register-resident kernel is built for the reference's 3-frame time smoothing
         const bool st_ok = MODE == APPLY_GAIN || a.st == 3;
         if (!c->force_generic && st_ok && apply_fast_ok(N, a.sg.hop, a.st, a.sf)) return apply_fast<MODE>(c, a, n_sig, Tmax);
+    } else {
+        if (!c->force_generic && (c->ablate & 256) == 0 && apply_wave64_ok(N, a.sg.hop, a.st, a.sf, MODE))
+            return apply_wave64<MODE>(c, a, n_sig, Tmax);
     }
     if (need(8) <= 160 * 1024) return launch_apply<T, 8, MODE>(c, a, n_sig, Tmax);
     if (need(4) <= 160 * 1024 && min_w <= 4) return launch_apply<T, 4, MODE>(c, a, n_sig, Tmax);

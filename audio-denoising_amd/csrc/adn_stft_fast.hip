@@ -96,29 +96,74 @@ __device__ __forceinline__ c2 conj_sub_rot(c2 a, c2 b) {
 // (explicit fused multiply-adds where a kernel's result must not depend on how the compiler contracts the
 // expression in that kernel: the rows kernels and the fused kernels have to agree bit for bit)
 __device__ __forceinline__ float norm2(c2 z) { return __builtin_fmaf(z.x, z.x, z.y * z.y); }
-
-// v * W16^M (forward) or its conjugate (inverse)
-template <int M, bool INV>
-__device__ __forceinline__ c2 mul_w16(c2 v) {
-    constexpr float C1 = 0.9238795325112867f, S1 = 0.3826834323650898f, R = 0.7071067811865476f;
-    if (M == 0) return v;
-    if (M == 4) {                                          // -i v  /  i v
-        c2 r;
-        if (INV) asm("v_pk_add_f32 %0, %1, 0 op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(r) : "v"(v));
-        else asm("v_pk_add_f32 %0, %1, 0 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(v));
-        return r;
-    }
-    if (M == 2) return add_rot<INV>(v, v) * R;             // (x + y, y - x) R  /  (x - y, x + y) R
-    if (M == 6) return add_rot<!INV>(v, v) * (-R);         // (y - x, -x - y) R  /  (-x - y, x - y) R
-    // generic: W = (c, -s) forward
-    constexpr float c = M == 1 ? C1 : (M == 3 ? S1 : -C1);     // M in {1, 3, 9}
-    constexpr float sn = M == 1 ? S1 : (M == 3 ? C1 : -S1);
-    return INV ? mulc_k(v, c2{c, -sn}) : mul_k(v, c2{c, -sn});
+// (xk.x - xm.x, xk.y + xm.y)
+__device__ __forceinline__ c2 sub_add(c2 a, c2 b) {
+    c2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// -i v (forward) / i v (inverse)
+template <bool INV>
+__device__ __forceinline__ c2 rot90(c2 v) {
+    c2 r;
+    if (INV) asm("v_pk_add_f32 %0, %1, 0 op_sel:[1,0] op_sel_hi:[0,0] neg_lo:[1,0]" : "=v"(r) : "v"(v));
+    else asm("v_pk_add_f32 %0, %1, 0 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(v));
+    return r;
 }
 
+// The same vocabulary for binary64 (the reference's precision): plain component arithmetic, there are no packed
+// binary64 instructions.  The kernels below are written once against this vocabulary.
+typedef double z2 __attribute__((ext_vector_type(2)));
+typedef double z4 __attribute__((ext_vector_type(4)));
+static_assert(sizeof(z2) == sizeof(double2), "z2 is layout-compatible with double2");
+__device__ __forceinline__ const z2 *as_c2(const double2 *p) { return reinterpret_cast<const z2 *>(p); }
 template <bool INV>
-__device__ __forceinline__ void bfly4(c2 &a0, c2 &a1, c2 &a2, c2 &a3) {
-    const c2 s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
+__device__ __forceinline__ z2 add_rot(z2 a, z2 b) { return INV ? z2{a.x - b.y, a.y + b.x} : z2{a.x + b.y, a.y - b.x}; }
+template <bool INV>
+__device__ __forceinline__ z2 sub_rot(z2 a, z2 b) { return add_rot<!INV>(a, b); }
+__device__ __forceinline__ z2 mul(z2 v, z2 w) { return z2{fma(-v.y, w.y, v.x * w.x), fma(v.y, w.x, v.x * w.y)}; }
+__device__ __forceinline__ z2 mulc(z2 v, z2 w) { return z2{fma(v.y, w.y, v.x * w.x), fma(v.y, w.x, -(v.x * w.y))}; }
+__device__ __forceinline__ z2 mul_k(z2 v, z2 w) { return mul(v, w); }
+__device__ __forceinline__ z2 mulc_k(z2 v, z2 w) { return mulc(v, w); }
+__device__ __forceinline__ z2 add_conj(z2 a, z2 b) { return z2{a.x + b.x, a.y - b.y}; }
+__device__ __forceinline__ z2 odd_part(z2 a, z2 b) { return z2{a.y + b.y, b.x - a.x}; }
+__device__ __forceinline__ z2 conj_sub_rot(z2 a, z2 b) { return z2{a.x + b.y, b.x - a.y}; }
+__device__ __forceinline__ double norm2(z2 z) { return fma(z.x, z.x, z.y * z.y); }
+__device__ __forceinline__ z2 sub_add(z2 a, z2 b) { return z2{a.x - b.x, a.y + b.y}; }
+template <bool INV>
+__device__ __forceinline__ z2 rot90(z2 v) { return INV ? z2{-v.y, v.x} : z2{v.y, -v.x}; }
+
+// scalar type of a complex type, and the types a frame is fetched in
+template <typename C> struct ReOf;
+template <> struct ReOf<c2> { typedef float type; };
+template <> struct ReOf<z2> { typedef double type; };
+template <typename C> using Re = typename ReOf<C>::type;
+template <typename R> struct CxOf;
+template <> struct CxOf<float> { typedef c2 type; };
+template <> struct CxOf<double> { typedef z2 type; };
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ double fast_rsq(double x) { return 1.0 / sqrt(x); }
+
+// v * W16^M (forward) or its conjugate (inverse)
+template <int M, bool INV, typename C>
+__device__ __forceinline__ C mul_w16(C v) {
+    typedef Re<C> R;
+    constexpr R C1 = (R)0.9238795325112867, S1 = (R)0.3826834323650898, RH = (R)0.7071067811865476;
+    if (M == 0) return v;
+    if (M == 4) return rot90<INV>(v);                      // -i v  /  i v
+    if (M == 2) return add_rot<INV>(v, v) * RH;            // (x + y, y - x) R  /  (x - y, x + y) R
+    if (M == 6) return add_rot<!INV>(v, v) * (-RH);        // (y - x, -x - y) R  /  (-x - y, x - y) R
+    // generic: W = (c, -s) forward
+    constexpr R c = M == 1 ? C1 : (M == 3 ? S1 : -C1);     // M in {1, 3, 9}
+    constexpr R sn = M == 1 ? S1 : (M == 3 ? C1 : -S1);
+    return INV ? mulc_k(v, C{c, -sn}) : mul_k(v, C{c, -sn});
+}
+
+template <bool INV, typename C>
+__device__ __forceinline__ void bfly4(C &a0, C &a1, C &a2, C &a3) {
+    const C s02 = a0 + a2, d02 = a0 - a2, s13 = a1 + a3, d13 = a1 - a3;
     a0 = s02 + s13;
     a1 = add_rot<INV>(d02, d13);
     a2 = s02 - s13;
@@ -128,8 +173,8 @@ __device__ __forceinline__ void bfly4(c2 &a0, c2 &a1, c2 &a2, c2 &a3) {
 // 16-point DFT in registers.  Input r[n]; output X[k] at r[P16(k)].
 __host__ __device__ constexpr int P16(int k) { return 4 * (k & 3) + (k >> 2); }
 
-template <bool INV>
-__device__ __forceinline__ void dft16(c2 (&r)[16]) {
+template <bool INV, typename C>
+__device__ __forceinline__ void dft16(C (&r)[16]) {
     bfly4<INV>(r[0], r[4], r[8], r[12]);
     bfly4<INV>(r[1], r[5], r[9], r[13]);
     bfly4<INV>(r[2], r[6], r[10], r[14]);
@@ -152,11 +197,13 @@ __device__ __forceinline__ void dft16(c2 (&r)[16]) {
 
 // Twiddles of the two inter-pass multiplications, one copy per workgroup in LDS:
 //   t1[(k1-1)*64 + lane] = W1024^(lane*k1),  t2[(c-1)*4 + b] = W64^(b*c),  k1, c = 1..15
-static constexpr int TWTAB = 15 * 64 + 15 * 4;     // float2 entries
-struct LaneTw {
-    const c2 *t1;   // + lane
-    const c2 *t2;   // + (lane & 3)
+static constexpr int TWTAB = 15 * 64 + 15 * 4;     // complex entries
+template <typename C>
+struct LaneTwT {
+    const C *t1;   // + lane
+    const C *t2;   // + (lane & 3)
 };
+typedef LaneTwT<c2> LaneTw;
 
 // tw holds exp(-2 pi i k / 1024) for k < 512
 __device__ __forceinline__ c2 w1024(const c2 *__restrict__ tw, int k) {
@@ -172,21 +219,26 @@ __device__ __forceinline__ void fill_tw_table(c2 *tab, const float2 *__restrict_
     float4 *dst = reinterpret_cast<float4 *>(tab);
     for (int i = tid; i < TWTAB / 2; i += nthreads) dst[i] = src[i];
 }
+__device__ __forceinline__ void fill_tw_table(z2 *tab, const double2 *__restrict__ image, int tid, int nthreads) {
+    const z2 *src = reinterpret_cast<const z2 *>(image);
+    for (int i = tid; i < TWTAB; i += nthreads) tab[i] = src[i];
+}
 
-__device__ __forceinline__ LaneTw lane_tw(const c2 *tab, int lane) {
-    return LaneTw{tab + lane, tab + 15 * 64 + (lane & 3)};
+template <typename C>
+__device__ __forceinline__ LaneTwT<C> lane_tw(const C *tab, int lane) {
+    return LaneTwT<C>{tab + lane, tab + 15 * 64 + (lane & 3)};
 }
 
 // In: lane l, r[j] = x[l + 64 j].
 // Out: lane l = 16*cq + k1, r[4*cc + d] = X[k1 + 16 * (4*cq + cc) + 256 * d].
 // Three passes (16 x 16 x 4 points), all butterflies in registers, two exchanges through the
 // wave's LDS buffer E (16 rows of RS float2).
-template <bool INV>
-__device__ __forceinline__ void wave_fft1024(c2 (&r)[16], c2 *E, const LaneTw &t, int lane) {
+template <bool INV, typename C>
+__device__ __forceinline__ void wave_fft1024(C (&r)[16], C *E, const LaneTwT<C> &t, int lane) {
     dft16<INV>(r);
 #pragma unroll
     for (int k1 = 0; k1 < 16; ++k1) {
-        c2 v = r[P16(k1)];
+        C v = r[P16(k1)];
         if (k1) v = INV ? mulc(v, t.t1[(k1 - 1) * 64]) : mul(v, t.t1[(k1 - 1) * 64]);
         E[k1 * RS + lane] = v;
     }
@@ -201,17 +253,23 @@ __device__ __forceinline__ void wave_fft1024(c2 (&r)[16], c2 *E, const LaneTw &t
     // c; row k1 of E takes the values at column 4*c + b
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-        c2 v = r[P16(c)];
+        C v = r[P16(c)];
         if (c) v = INV ? mulc(v, t.t2[(c - 1) * 4]) : mul(v, t.t2[(c - 1) * 4]);
         E[row + 4 * c] = v;
     }
     wave_sync();
-    const float4 *src = reinterpret_cast<const float4 *>(E + (lane & 15) * RS + (lane >> 4) * 16);
+    if constexpr (sizeof(C) == 8) {
+        const float4 *src = reinterpret_cast<const float4 *>(E + (lane & 15) * RS + (lane >> 4) * 16);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const float4 q = src[i];
-        r[2 * i] = c2{q.x, q.y};
-        r[2 * i + 1] = c2{q.z, q.w};
+        for (int i = 0; i < 8; ++i) {
+            const float4 q = src[i];
+            r[2 * i] = C{q.x, q.y};
+            r[2 * i + 1] = C{q.z, q.w};
+        }
+    } else {
+        const C *src = E + (lane & 15) * RS + (lane >> 4) * 16;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) r[i] = src[i];
     }
     wave_sync();
 #pragma unroll
@@ -219,7 +277,8 @@ __device__ __forceinline__ void wave_fft1024(c2 (&r)[16], c2 *E, const LaneTw &t
 }
 
 // Natural-order (padded) store of the layout produced by wave_fft1024.
-__device__ __forceinline__ void store_natural(const c2 (&r)[16], c2 *buf, int lane) {
+template <typename C>
+__device__ __forceinline__ void store_natural(const C (&r)[16], C *buf, int lane) {
     const int base = (lane & 15) + 64 * (lane >> 4);          // k1 + 16 * 4 * cq
 #pragma unroll
     for (int cc = 0; cc < 4; ++cc)
@@ -311,9 +370,11 @@ __device__ __forceinline__ void window_prefetched(c2 (&r)[16], const float4 (&pf
 
 // Real-signal spectrum of the packed transform held in buf (natural, padded).
 // lo[j] = X[k], hi[j] = X[1024-k] for k = lane + 64 j (lane 0, j 0: X[0] and X[1024]); mid = X[512].
-struct Spec {
-    c2 lo[8], hi[8], mid;
+template <typename C>
+struct SpecT {
+    C lo[8], hi[8], mid;
 };
+typedef SpecT<c2> Spec;
 
 // Addresses of the two kinds of accesses to the natural (padded) spectrum image: bin lane + 64 j
 // and its mirror 1024 - lane - 64 j.  Both are one base address per lane plus compile-time
@@ -321,37 +382,41 @@ struct Spec {
 // 8 (j >> 2); for lane >= 1 the mirror is (64 - lane) + 64 (15 - j) + 8 ((15 - j) >> 2); lane 0
 // sits exactly on the padding steps and needs 8 more for j = 4, 8, 12 (its j = 0 mirror is bin 0,
 // handled by the callers, and the address formed for it stays inside the buffer).
-struct NatAddr {
-    const c2 *fwd;     // buf + lane
-    const c2 *mir;     // buf + 64 - lane
-    const c2 *mir4;    // the same, + 8 for lane 0: mirror base of j = 4, 8, 12
+template <typename C>
+struct NatAddrT {
+    const C *fwd;     // buf + lane
+    const C *mir;     // buf + 64 - lane
+    const C *mir4;    // the same, + 8 for lane 0: mirror base of j = 4, 8, 12
 };
-__device__ __forceinline__ NatAddr nat_addr(const c2 *buf, int lane) {
-    return NatAddr{buf + lane, buf + 64 - lane, buf + 64 - lane + (lane == 0 ? 8 : 0)};
+typedef NatAddrT<c2> NatAddr;
+template <typename C>
+__device__ __forceinline__ NatAddrT<C> nat_addr(const C *buf, int lane) {
+    return NatAddrT<C>{buf + lane, buf + 64 - lane, buf + 64 - lane + (lane == 0 ? 8 : 0)};
 }
 template <int J> __device__ __forceinline__ int nat_fwd_off() { return 64 * J + 8 * (J >> 2); }
 template <int J> __device__ __forceinline__ int nat_mir_off() { return 64 * (15 - J) + 8 * ((15 - J) >> 2); }
 
-template <int J>
-__device__ __forceinline__ void split_bin(Spec &s, const NatAddr &na, const c2 (&rtw)[8], float hs, float scale, int lane) {
-    const c2 zk = na.fwd[nat_fwd_off<J>()];
-    const c2 zm = ((J & 3) == 0 ? na.mir4 : na.mir)[nat_mir_off<J>()];
-    const c2 e = add_conj(zk, zm);                         // (zk.x + zm.x, zk.y - zm.y)
-    const c2 o = odd_part(zk, zm);                         // (zk.y + zm.y, zm.x - zk.x)
-    const c2 wo = mul(o, rtw[J]);
+template <int J, typename C>
+__device__ __forceinline__ void split_bin(SpecT<C> &s, const NatAddrT<C> &na, const C (&rtw)[8], Re<C> hs, Re<C> scale, int lane) {
+    const C zk = na.fwd[nat_fwd_off<J>()];
+    const C zm = ((J & 3) == 0 ? na.mir4 : na.mir)[nat_mir_off<J>()];
+    const C e = add_conj(zk, zm);                          // (zk.x + zm.x, zk.y - zm.y)
+    const C o = odd_part(zk, zm);                          // (zk.y + zm.y, zm.x - zk.x)
+    const C wo = mul(o, rtw[J]);
     s.lo[J] = (e + wo) * hs;
-    s.hi[J] = (e - wo) * c2{hs, -hs};                      // conjugated
+    s.hi[J] = (e - wo) * C{hs, -hs};                       // conjugated
     if (J == 0 && lane == 0) {
-        s.lo[0] = c2{(zk.x + zk.y) * scale, 0.0f};
-        s.hi[0] = c2{(zk.x - zk.y) * scale, 0.0f};
+        s.lo[0] = C{(zk.x + zk.y) * scale, 0};
+        s.hi[0] = C{(zk.x - zk.y) * scale, 0};
     }
 }
 
-__device__ __forceinline__ void split_spectrum(Spec &s, const c2 *buf, const c2 (&rtw)[8], float scale, int lane) {
+template <typename C>
+__device__ __forceinline__ void split_spectrum(SpecT<C> &s, const C *buf, const C (&rtw)[8], Re<C> scale, int lane) {
     // Z[k] = E[k] + W^k O[k] with E = (z[k] + conj(z[N-k])) / 2, O = -i (z[k] - conj(z[N-k])) / 2;
     // the halves are folded into the scale
-    const float hs = 0.5f * scale;
-    const NatAddr na = nat_addr(buf, lane);
+    const Re<C> hs = (Re<C>)0.5 * scale;
+    const NatAddrT<C> na = nat_addr(buf, lane);
     split_bin<0>(s, na, rtw, hs, scale, lane);
     split_bin<1>(s, na, rtw, hs, scale, lane);
     split_bin<2>(s, na, rtw, hs, scale, lane);
@@ -360,8 +425,8 @@ __device__ __forceinline__ void split_spectrum(Spec &s, const c2 *buf, const c2 
     split_bin<5>(s, na, rtw, hs, scale, lane);
     split_bin<6>(s, na, rtw, hs, scale, lane);
     split_bin<7>(s, na, rtw, hs, scale, lane);
-    const c2 z = buf[nat(512)];
-    s.mid = c2{z.x * scale, -z.y * scale};
+    const C z = buf[nat(512)];
+    s.mid = C{z.x * scale, -z.y * scale};
 }
 
 // Inverse of split_spectrum: writes the packed spectrum Z' (natural, padded) into buf.
@@ -397,27 +462,28 @@ __device__ __forceinline__ void merge_spectrum(const Spec &s, c2 *buf, const c2 
 // The same for a wave that transforms the result itself: the lower half of the packed spectrum, Z'[lane + 64 j]
 // for j < 8, is what the inverse transform wants in r[j] of this very lane, so it stays in registers; only the
 // mirrored bins (the upper half, owned by other lanes) go through buf.
-template <int J>
-__device__ __forceinline__ void merge_bin_keep(const Spec &s, c2 (&r)[16], const NatAddr &na, const c2 (&rtw)[8], int lane) {
-    const c2 xk = s.lo[J], xm = s.hi[J];
-    c2 *mir = const_cast<c2 *>((J & 3) == 0 ? na.mir4 : na.mir);
-    const c2 e = add_conj(xk, xm) * 0.5f;                  // ((xk.x + xm.x) / 2, (xk.y - xm.y) / 2)
-    c2 d;                                                  // (xk.x - xm.x, xk.y + xm.y)
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(d) : "v"(xk), "v"(xm));
-    const c2 o = mulc(d * 0.5f, rtw[J]);
+template <int J, typename C>
+__device__ __forceinline__ void merge_bin_keep(const SpecT<C> &s, C (&r)[16], const NatAddrT<C> &na, const C (&rtw)[8], int lane) {
+    typedef Re<C> R;
+    const C xk = s.lo[J], xm = s.hi[J];
+    C *mir = const_cast<C *>((J & 3) == 0 ? na.mir4 : na.mir);
+    const C e = add_conj(xk, xm) * (R)0.5;                 // ((xk.x + xm.x) / 2, (xk.y - xm.y) / 2)
+    const C d = sub_add(xk, xm);                           // (xk.x - xm.x, xk.y + xm.y)
+    const C o = mulc(d * (R)0.5, rtw[J]);
     r[J] = add_rot<true>(e, o);                            // e + i o = (e.x - o.y, e.y + o.x)
-    const c2 m = conj_sub_rot(e, o);                       // conj(e - i o) = (e.x + o.y, o.x - e.y)
+    const C m = conj_sub_rot(e, o);                        // conj(e - i o) = (e.x + o.y, o.x - e.y)
     if (J == 0) {
         // lane 0: bins 0 and 1024 are real and pack into Z'[0]; its mirror slot is not a bin
-        if (lane == 0) r[0] = c2{(xk.x + xm.x) * 0.5f, (xk.x - xm.x) * 0.5f};
+        if (lane == 0) r[0] = C{(xk.x + xm.x) * (R)0.5, (xk.x - xm.x) * (R)0.5};
         else mir[nat_mir_off<J>()] = m;
     } else {
         mir[nat_mir_off<J>()] = m;
     }
 }
 
-__device__ __forceinline__ void merge_spectrum_keep(const Spec &s, c2 (&r)[16], c2 *buf, const c2 (&rtw)[8], int lane) {
-    const NatAddr na = nat_addr(buf, lane);
+template <typename C>
+__device__ __forceinline__ void merge_spectrum_keep(const SpecT<C> &s, C (&r)[16], C *buf, const C (&rtw)[8], int lane) {
+    const NatAddrT<C> na = nat_addr(buf, lane);
     merge_bin_keep<0>(s, r, na, rtw, lane);
     merge_bin_keep<1>(s, r, na, rtw, lane);
     merge_bin_keep<2>(s, r, na, rtw, lane);
@@ -426,7 +492,7 @@ __device__ __forceinline__ void merge_spectrum_keep(const Spec &s, c2 (&r)[16], 
     merge_bin_keep<5>(s, r, na, rtw, lane);
     merge_bin_keep<6>(s, r, na, rtw, lane);
     merge_bin_keep<7>(s, r, na, rtw, lane);
-    if (lane == 0) buf[nat(512)] = c2{s.mid.x, -s.mid.y};
+    if (lane == 0) buf[nat(512)] = C{s.mid.x, -s.mid.y};
 }
 
 __device__ __forceinline__ void load_rtw(c2 (&rtw)[8], const c2 *tab, int lane) {
@@ -435,24 +501,28 @@ __device__ __forceinline__ void load_rtw(c2 (&rtw)[8], const c2 *tab, int lane) 
 }
 
 // exp(-2 pi i (lane + 64 j) / 2048) = rtw0 * exp(-i pi j / 16)
-__device__ __forceinline__ void derive_rtw(c2 (&rtw)[8], c2 rtw0) {
+template <typename C>
+__device__ __forceinline__ void derive_rtw(C (&rtw)[8], C rtw0) {
+    typedef Re<C> R;
     rtw[0] = rtw0;
-    rtw[1] = mul_k(rtw0, c2{0.9807852804032304f, -0.19509032201612825f});
-    rtw[2] = mul_k(rtw0, c2{0.9238795325112867f, -0.3826834323650898f});
-    rtw[3] = mul_k(rtw0, c2{0.8314696123025452f, -0.5555702330196022f});
-    rtw[4] = mul_k(rtw0, c2{0.7071067811865476f, -0.7071067811865476f});
-    rtw[5] = mul_k(rtw0, c2{0.5555702330196022f, -0.8314696123025452f});
-    rtw[6] = mul_k(rtw0, c2{0.3826834323650898f, -0.9238795325112867f});
-    rtw[7] = mul_k(rtw0, c2{0.19509032201612825f, -0.9807852804032304f});
+    rtw[1] = mul_k(rtw0, C{(R)0.9807852804032304, (R)-0.19509032201612825});
+    rtw[2] = mul_k(rtw0, C{(R)0.9238795325112867, (R)-0.3826834323650898});
+    rtw[3] = mul_k(rtw0, C{(R)0.8314696123025452, (R)-0.5555702330196022});
+    rtw[4] = mul_k(rtw0, C{(R)0.7071067811865476, (R)-0.7071067811865476});
+    rtw[5] = mul_k(rtw0, C{(R)0.5555702330196022, (R)-0.8314696123025452});
+    rtw[6] = mul_k(rtw0, C{(R)0.3826834323650898, (R)-0.9238795325112867});
+    rtw[7] = mul_k(rtw0, C{(R)0.19509032201612825, (R)-0.9807852804032304});
 }
 
 // Raw samples of the frame at padded position p0, requested into registers (no arithmetic, so
 // that the loads stay in flight).  NCH = 1: pf[j] is packed point lane + 64 j; NCH = 2: pf[j] holds
 // the two (left, right) pairs of packed point lane + 64 j.  Returns false when the frame needs the
 // generic loader instead (tail of the signal, odd alignment, another channel count).
-template <int NCH> struct FetchT;
-template <> struct FetchT<1> { typedef c2 type; };
-template <> struct FetchT<2> { typedef float4 type; };
+template <int NCH, typename R> struct FetchT;
+template <> struct FetchT<1, float> { typedef c2 type; };
+template <> struct FetchT<2, float> { typedef float4 type; };
+template <> struct FetchT<1, double> { typedef z2 type; };
+template <> struct FetchT<2, double> { typedef z4 type; };
 
 typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ c2 load_streaming(const c2 *p) { return __builtin_nontemporal_load(p); }
@@ -460,11 +530,13 @@ __device__ __forceinline__ float4 load_streaming(const float4 *p) {
     const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));
     return float4{v.x, v.y, v.z, v.w};
 }
+__device__ __forceinline__ z2 load_streaming(const z2 *p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ z4 load_streaming(const z4 *p) { return __builtin_nontemporal_load(p); }
 
-template <int NCH>
-__device__ __forceinline__ bool fetch_frame(typename FetchT<NCH>::type (&pf)[16], const float *__restrict__ xs, int64_t n,
+template <int NCH, typename R>
+__device__ __forceinline__ bool fetch_frame(typename FetchT<NCH, R>::type (&pf)[16], const R *__restrict__ xs, int64_t n,
                                             int n_ch, int64_t p0, int lane) {
-    typedef typename FetchT<NCH>::type V;
+    typedef typename FetchT<NCH, R>::type V;
     const bool ok = p0 + 2048 <= n && n_ch == NCH && (reinterpret_cast<uintptr_t>(xs + NCH * p0) & (sizeof(V) - 1)) == 0;
     // No branch around the loads (a join between the loads and their first use would make the
     // compiler wait for every younger memory operation as well): a frame that cannot be fetched this
@@ -472,7 +544,7 @@ __device__ __forceinline__ bool fetch_frame(typename FetchT<NCH>::type (&pf)[16]
     // load size, and the result is ignored.  Every signal holds at least one whole frame; rounding
     // down stays inside the caller's buffer because only element offsets inside it can be odd.
     // (pointer arithmetic only: an integer round trip would turn the loads into flat ones)
-    const float *src = ok ? xs + NCH * p0 : xs - ((reinterpret_cast<uintptr_t>(xs) & (sizeof(V) - 1)) >> 2);
+    const R *src = ok ? xs + NCH * p0 : xs - ((reinterpret_cast<uintptr_t>(xs) & (sizeof(V) - 1)) / sizeof(R));
     const V *xv = reinterpret_cast<const V *>(src) + lane;
     __builtin_amdgcn_sched_barrier(0);
     // the first quarter of a frame is the hop that no later frame of the run reads again: it is loaded
@@ -487,28 +559,31 @@ __device__ __forceinline__ bool fetch_frame(typename FetchT<NCH>::type (&pf)[16]
 
 __device__ __forceinline__ c2 fold_point(const c2 &q) { return q; }
 __device__ __forceinline__ c2 fold_point(const float4 &q) { return c2{(q.x + q.y) / 2.0f, (q.z + q.w) / 2.0f}; }
+__device__ __forceinline__ z2 fold_point(const z2 &q) { return q; }
+__device__ __forceinline__ z2 fold_point(const z4 &q) { return z2{(q.x + q.y) / 2.0, (q.z + q.w) / 2.0}; }
 
 // Windowed packed frame r[j] = z[lane + 64 j] from the fetched samples; wv = first half of the window
-template <typename V>
-__device__ __forceinline__ void window_fetched(c2 (&r)[16], const V (&pf)[16], const c2 *wv, int lane) {
+template <typename V, typename C>
+__device__ __forceinline__ void window_fetched(C (&r)[16], const V (&pf)[16], const C *wv, int lane) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const c2 w = wv[lane + 64 * j];
-        const c2 lo = fold_point(pf[j]), hi = fold_point(pf[j + 8]);
+        const C w = wv[lane + 64 * j];
+        const C lo = fold_point(pf[j]), hi = fold_point(pf[j + 8]);
         r[j] = lo * w;
         r[j + 8] = __builtin_elementwise_fma(-hi, w, hi);  // w[n + 1024] = 1 - w[n]
     }
 }
 
 // Any frame (zero-padded tail, odd alignment, any channel count): staged through the wave's buffer.
-__device__ __noinline__ void stage_frame_half_window(c2 *buf, const float *__restrict__ xs, int64_t n, int n_ch,
-                                                     int64_t p0, const float *__restrict__ whalf, int lane) {
+template <typename C, typename R>
+__device__ __noinline__ void stage_frame_half_window(C *buf, const R *__restrict__ xs, int64_t n, int n_ch,
+                                                     int64_t p0, const R *__restrict__ whalf, int lane) {
 #pragma unroll 1
     for (int i = lane; i < NC; i += 64) {
-        const float u = fold_sample(xs, p0 + 2 * i, n, n_ch), v = fold_sample(xs, p0 + 2 * i + 1, n, n_ch);
+        const R u = fold_sample(xs, p0 + 2 * i, n, n_ch), v = fold_sample(xs, p0 + 2 * i + 1, n, n_ch);
         const int wi = 2 * (i & 511);
-        const float w0 = whalf[wi], w1 = whalf[wi + 1];
-        buf[nat(i)] = i < 512 ? c2{u * w0, v * w1} : c2{__builtin_fmaf(-u, w0, u), __builtin_fmaf(-v, w1, v)};
+        const R w0 = whalf[wi], w1 = whalf[wi + 1];
+        buf[nat(i)] = i < 512 ? C{u * w0, v * w1} : C{fma(-u, w0, u), fma(-v, w1, v)};
     }
 }
 
@@ -1097,19 +1172,22 @@ static constexpr int GROW = 1032;                 // floats of a gain / noise ro
 
 // NCH: the channel count whose frames are fetched straight into registers (other counts, and frames
 // at the zero-padded tail of a signal, take the staged loader)
-template <int W, int MODE, int NCH, bool PROF>
-__global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(MODE == APPLY_SUBTRACT ? 2 : 3, MODE == APPLY_SUBTRACT ? 2 : 3)))
-void k_apply_wave(ApplyArgs<float> a) {
+// R: binary32 (two or three waves per SIMD) or binary64 (one wave per SIMD: a frame alone is 64 registers)
+template <typename R, int W, int MODE, int NCH, bool PROF>
+__global__ __launch_bounds__(W * 64)
+__attribute__((amdgpu_waves_per_eu(sizeof(R) == 8 ? 1 : (MODE == APPLY_SUBTRACT ? 2 : 3), sizeof(R) == 8 ? 1 : (MODE == APPLY_SUBTRACT ? 2 : 3))))
+void k_apply_wave(ApplyArgs<R> a) {
+    typedef typename CxOf<R>::type C;
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int H = 512;
     constexpr int SLOT = MODE == APPLY_SUBTRACT ? PARK : 0;                          // float2 per wave beside the exchange buffer
-    const Tables<float> &tb = a.tb;
-    c2 *bufs = reinterpret_cast<c2 *>(smem);                                          // [W][WBUF] exchange
-    c2 *slots = bufs + (size_t)W * WBUF;                                              // [W][SLOT] parked spectrum / gain row
-    c2 *twtab = slots + (size_t)W * SLOT;
-    float *wtab = reinterpret_cast<float *>(twtab + TWTAB);                           // [1024] first half of the window
-    float *ntab = wtab + 1024;                                                        // [512] scale / full-overlap norm
-    float *nrow = ntab + 512;                                                         // [GROW] the signal's noise row (SUBTRACT) / gain row (GAIN)
+    const Tables<R> &tb = a.tb;
+    C *bufs = reinterpret_cast<C *>(smem);                                          // [W][WBUF] exchange
+    C *slots = bufs + (size_t)W * WBUF;                                              // [W][SLOT] parked spectrum / gain row
+    C *twtab = slots + (size_t)W * SLOT;
+    R *wtab = reinterpret_cast<R *>(twtab + TWTAB);                           // [1024] first half of the window
+    R *ntab = wtab + 1024;                                                        // [512] scale / full-overlap norm
+    R *nrow = ntab + 512;                                                         // [GROW] the signal's noise row (SUBTRACT) / gain row (GAIN)
     // the wave index as a scalar: the run's bounds, pointers and counters then live in scalar registers
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane0 = threadIdx.x & 63, tid = threadIdx.x;
     // the waves of a workgroup work on one signal (segs_per_sig is a multiple of W) and share its noise / gain row
@@ -1117,19 +1195,19 @@ void k_apply_wave(ApplyArgs<float> a) {
     const int64_t sig = gid / a.segs_per_sig;
     const int run = (int)(gid % a.segs_per_sig);
     const bool have_sig = sig < a.n_sig;
-    const float *row = a.row + (have_sig ? sig : 0) * a.row_stride;
+    const R *row = a.row + (have_sig ? sig : 0) * a.row_stride;
     fill_tw_table(twtab, tb.fast_tw, tid, W * 64);
     for (int i = tid; i < 1024; i += W * 64) wtab[i] = tb.window[i];
-    const float fscale = (float)(1.0 / tb.wsum);
-    const float iscale = (float)(tb.wsum / 1024.0);
+    const R fscale = (R)(1.0 / tb.wsum);
+    const R iscale = (R)(tb.wsum / 1024.0);
     for (int i = tid; i < 512; i += W * 64) {
-        float sq = 0.0f;
+        R sq = (R)0.0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float w = tb.window[i + q * H];
+            const R w = tb.window[i + q * H];
             sq += w * w;
         }
-        ntab[i] = iscale / (sq > 1e-10f ? sq : 1.0f);
+        ntab[i] = iscale / (sq > (R)1e-10 ? sq : (R)1.0);
     }
     if (MODE == APPLY_SUBTRACT || a.row_t_stride == 0)
         for (int i = tid; i <= 1024; i += W * 64) nrow[i] = row[i];
@@ -1145,49 +1223,49 @@ void k_apply_wave(ApplyArgs<float> a) {
     const int jb = (ja + a.seg_hops < Tn + 1) ? ja + a.seg_hops : Tn + 1;            // exclusive
     const int ta = ja - 3 < 0 ? 0 : ja - 3;                // first frame synthesised (fills the partial hops)
     const int tb_ = jb - 1 < Tn - 1 ? jb - 1 : Tn - 1;     // last frame synthesised
-    const float *xs = a.x + a.sg.off[sig];
-    float *ys = a.y + a.y_off[sig];
+    const R *xs = a.x + a.sg.off[sig];
+    R *ys = a.y + a.y_off[sig];
     int16_t *ps = a.pcm ? a.pcm + a.y_off[sig] : nullptr;
-    c2 *buf = bufs + wave * WBUF;
-    float *bufr = reinterpret_cast<float *>(buf);
-    c2 *park = slots + wave * SLOT;
-    float *grow_lds = nrow;
-    const c2 *wv = reinterpret_cast<const c2 *>(wtab);
-    const c2 *nv = reinterpret_cast<const c2 *>(ntab);
-    const c2 rtw0 = as_c2(tb.rtw)[lane0];
+    C *buf = bufs + wave * WBUF;
+    R *bufr = reinterpret_cast<R *>(buf);
+    C *park = slots + wave * SLOT;
+    R *grow_lds = nrow;
+    const C *wv = reinterpret_cast<const C *>(wtab);
+    const C *nv = reinterpret_cast<const C *>(ntab);
+    const C rtw0 = as_c2(tb.rtw)[lane0];
     const bool y_vec = (reinterpret_cast<uintptr_t>(ys) & 7) == 0;
     const bool p_vec = (reinterpret_cast<uintptr_t>(ps) & 3) == 0;
     const bool gain_in_lds = MODE == APPLY_GAIN && a.row_t_stride == 0;
-    auto wfull = [&](int idx) { return idx < 1024 ? wtab[idx] : 1.0f - wtab[idx - 1024]; };
+    auto wfull = [&](int idx) { return idx < 1024 ? wtab[idx] : (R)1.0 - wtab[idx - 1024]; };
 
     // one finished hop: normalise, clip, optional PCM16, store
-    auto emit = [&](int j, const c2 (&v)[4], int mlane) {
+    auto emit = [&](int j, const C (&v)[4], int mlane) {
         const bool full = j >= 3 && j <= Tn - 1;
         const int64_t base = (int64_t)(j - 2) * H + 2 * mlane;               // the lane's first sample of the hop
-        float *yp0 = ys + base;
+        R *yp0 = ys + base;
         int16_t *pp0 = ps + base;
 #pragma unroll
         for (int cc = 0; cc < 4; ++cc) {
             const int i = 2 * (mlane + 16 * cc);           // sample of the hop (and i + 1)
-            c2 o;
+            C o;
             if (full) {
                 o = v[cc] * nv[mlane + 16 * cc];
             } else {
-                float nx_ = 0.0f, ny_ = 0.0f;
+                R nx_ = (R)0.0, ny_ = (R)0.0;
                 int t_lo = j - 3;
                 t_lo = t_lo < 0 ? 0 : t_lo;
                 const int t_hi = j < Tn - 1 ? j : Tn - 1;
 #pragma unroll 1
                 for (int tt = t_lo; tt <= t_hi; ++tt) {
-                    const float w0 = wfull((j - tt) * H + i), w1 = wfull((j - tt) * H + i + 1);
+                    const R w0 = wfull((j - tt) * H + i), w1 = wfull((j - tt) * H + i + 1);
                     nx_ += w0 * w0;
                     ny_ += w1 * w1;
                 }
-                o = c2{v[cc].x * iscale / (nx_ > 1e-10f ? nx_ : 1.0f), v[cc].y * iscale / (ny_ > 1e-10f ? ny_ : 1.0f)};
+                o = C{v[cc].x * iscale / (nx_ > (R)1e-10 ? nx_ : (R)1.0), v[cc].y * iscale / (ny_ > (R)1e-10 ? ny_ : (R)1.0)};
             }
             if (!a.no_clip) {
-                o.x = o.x < -1.0f ? -1.0f : (o.x > 1.0f ? 1.0f : o.x);
-                o.y = o.y < -1.0f ? -1.0f : (o.y > 1.0f ? 1.0f : o.y);
+                o.x = o.x < -(R)1.0 ? -(R)1.0 : (o.x > (R)1.0 ? (R)1.0 : o.x);
+                o.y = o.y < -(R)1.0 ? -(R)1.0 : (o.y > (R)1.0 ? (R)1.0 : o.y);
             }
             if (ps) {
                 const int k0 = pcm_int32(o.x) >> 16, k1 = pcm_int32(o.y) >> 16;
@@ -1198,11 +1276,11 @@ void k_apply_wave(ApplyArgs<float> a) {
                     pp[0] = (int16_t)k0;
                     pp[1] = (int16_t)k1;
                 }
-                o = c2{(float)k0 * (1.0f / 32768.0f), (float)k1 * (1.0f / 32768.0f)};
+                o = C{(R)k0 * ((R)1.0 / (R)32768.0), (R)k1 * ((R)1.0 / (R)32768.0)};
             }
-            float *yp = yp0 + 32 * cc;
+            R *yp = yp0 + 32 * cc;
             if (y_vec) {
-                *reinterpret_cast<c2 *>(yp) = o;
+                *reinterpret_cast<C *>(yp) = o;
             } else {
                 yp[0] = o.x;
                 yp[1] = o.y;
@@ -1213,12 +1291,12 @@ void k_apply_wave(ApplyArgs<float> a) {
     // frames analysed: SUBTRACT also needs the magnitude rows of the frames around [ta, tb_]
     const int u0 = MODE == APPLY_SUBTRACT ? (ta > 0 ? ta - 1 : 0) : ta;
     const int u1 = MODE == APPLY_SUBTRACT ? (tb_ + 1 < Tn - 1 ? tb_ + 1 : Tn - 1) : tb_;
-    c2 acc0[4], acc1[4], acc2[4];
+    C acc0[4], acc1[4], acc2[4];
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) acc0[cc] = acc1[cc] = acc2[cc] = c2{0.0f, 0.0f};
+    for (int cc = 0; cc < 4; ++cc) acc0[cc] = acc1[cc] = acc2[cc] = C{(R)0.0, (R)0.0};
     // SUBTRACT: frequency-smoothed magnitude rows at the lane's bins (lo: k = lane + 64 j, hi: 1024 - k, mid: 512)
-    float m1_lo[8], m1_hi[8], m1_mid = 0.0f;               // row of the previous frame
-    float s2_lo[8], s2_hi[8], s2_mid = 0.0f;               // sum of the rows of the two previous frames
+    R m1_lo[8], m1_hi[8], m1_mid = (R)0.0;               // row of the previous frame
+    R s2_lo[8], s2_hi[8], s2_mid = (R)0.0;               // sum of the rows of the two previous frames
     const int s_end = MODE == APPLY_SUBTRACT ? tb_ + 1 : tb_;
     // diagnostics (PROF): shader-clock totals of the phases of this wave's frames
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1231,10 +1309,10 @@ void k_apply_wave(ApplyArgs<float> a) {
             tk = now;
         }
     };
-    c2 pend[4];                                            // finished hop waiting to be stored
+    C pend[4];                                            // finished hop waiting to be stored
     int pend_j = -1;
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) pend[cc] = c2{0.0f, 0.0f};
+    for (int cc = 0; cc < 4; ++cc) pend[cc] = C{(R)0.0, (R)0.0};
 
 #pragma unroll 1
     for (int s = u0; s <= s_end; ++s) {
@@ -1244,11 +1322,11 @@ void k_apply_wave(ApplyArgs<float> a) {
         int lane = lane0;
         asm volatile("" : "+v"(lane));
         const int mlane = (lane & 15) + 64 * (lane >> 4);  // packed point of r[4 cc + d] is mlane + 16 cc + 256 d
-        const LaneTw tw = lane_tw(twtab, lane);
-        Spec sp;
+        const LaneTwT<C> tw = lane_tw(twtab, lane);
+        SpecT<C> sp;
         const bool analyse = s <= u1;
         // the frame's samples are requested first, THEN the hop finished by the previous step is stored
-        typename FetchT<NCH>::type pf[16];
+        typename FetchT<NCH, R>::type pf[16];
         bool pf_mode = false;
         // (a step without analysis fetches, and ignores, the run's last frame again)
         pf_mode = fetch_frame<NCH>(pf, xs, n, a.sg.n_ch, (int64_t)(analyse ? s : u1) * H, lane) && analyse;
@@ -1258,10 +1336,10 @@ void k_apply_wave(ApplyArgs<float> a) {
         // their first use makes the compiler's wait conservative (it would wait for the stores too).
         const bool pend_fast = pend_j >= 3 && pend_j <= Tn - 1 && y_vec && ps == nullptr;
         {
-            const float lim = a.no_clip ? __builtin_inff() : 1.0f;
+            const R lim = a.no_clip ? (R)__builtin_inf() : (R)1.0;
             // a hop that is not stored here goes to a scratch line instead (unconditional stores)
-            float *yp0 = pend_fast ? ys + ((int64_t)(pend_j - 2) * H + 2 * mlane) : a.dummy + 2 * mlane;
-            c2 o[4];
+            R *yp0 = pend_fast ? ys + ((int64_t)(pend_j - 2) * H + 2 * mlane) : a.dummy + 2 * mlane;
+            C o[4];
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
                 o[cc] = pend[cc] * nv[mlane + 16 * cc];
@@ -1269,10 +1347,10 @@ void k_apply_wave(ApplyArgs<float> a) {
                 o[cc].y = o[cc].y < -lim ? -lim : (o[cc].y > lim ? lim : o[cc].y);
             }
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) __builtin_nontemporal_store(o[cc], reinterpret_cast<c2 *>(yp0 + 32 * cc));
+            for (int cc = 0; cc < 4; ++cc) __builtin_nontemporal_store(o[cc], reinterpret_cast<C *>(yp0 + 32 * cc));
         }
         __builtin_amdgcn_sched_barrier(0);
-        c2 r[16];                                          // the frame being transformed (either direction)
+        C r[16];                                          // the frame being transformed (either direction)
         if (analyse) {
             // ---- frame s: window the fetched samples, forward transform, real-signal spectrum
             if (pf_mode) {
@@ -1280,7 +1358,7 @@ void k_apply_wave(ApplyArgs<float> a) {
             } else {
                 stage_frame_half_window(buf, xs, n, a.sg.n_ch, (int64_t)s * H, wtab, lane);
                 wave_sync();
-                const c2 *nb = buf + lane;
+                const C *nb = buf + lane;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) r[j] = nb[64 * j + 8 * (j >> 2)];        // nat(lane + 64 j)
                 wave_sync();
@@ -1295,7 +1373,7 @@ void k_apply_wave(ApplyArgs<float> a) {
             tick(1);
             store_natural(r, buf, lane);
             wave_sync();
-            c2 rtw[8];
+            C rtw[8];
             derive_rtw(rtw, rtw0);
             split_spectrum(sp, buf, rtw, fscale, lane);
             wave_sync();
@@ -1304,38 +1382,38 @@ void k_apply_wave(ApplyArgs<float> a) {
         __builtin_amdgcn_sched_barrier(0);
         int t = s;                                          // frame synthesised in this step
         if (MODE == APPLY_SUBTRACT) {
-            float mc_lo[8], mc_hi[8], mc_mid;
+            R mc_lo[8], mc_hi[8], mc_mid;
             if (analyse) {
                 // clean magnitudes of the lane's bins -> raw row in the wave's buffer (RAWPAD spare
                 // bins at both ends for the box filter's edge replication)
-                float *rawm = bufr + RAWPAD;
+                R *rawm = bufr + RAWPAD;
                 {
                     // mirrored bins 1024 - lane - 64 j are addressed upwards from the lowest one (j = 7):
                     // LDS instructions take unsigned offsets only
-                    const float *nlo = nrow + lane, *nhi = nrow + 576 - lane;
-                    float *wlo = rawm + lane, *whi = rawm + 576 - lane;
+                    const R *nlo = nrow + lane, *nhi = nrow + 576 - lane;
+                    R *wlo = rawm + lane, *whi = rawm + 576 - lane;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float m0 = __builtin_amdgcn_sqrtf(norm2(sp.lo[j]));
-                        const float m1 = __builtin_amdgcn_sqrtf(norm2(sp.hi[j]));
-                        wlo[64 * j] = fmaxf(m0 - a.alpha * nlo[64 * j], a.beta * m0);
-                        whi[64 * (7 - j)] = fmaxf(m1 - a.alpha * nhi[64 * (7 - j)], a.beta * m1);
+                        const R m0 = fast_sqrt(norm2(sp.lo[j]));
+                        const R m1 = fast_sqrt(norm2(sp.hi[j]));
+                        wlo[64 * j] = fmax(m0 - a.alpha * nlo[64 * j], a.beta * m0);
+                        whi[64 * (7 - j)] = fmax(m1 - a.alpha * nhi[64 * (7 - j)], a.beta * m1);
                     }
                 }
                 if (lane == 0) {
-                    const float mm = __builtin_amdgcn_sqrtf(norm2(sp.mid));
-                    rawm[512] = fmaxf(mm - a.alpha * nrow[512], a.beta * mm);
+                    const R mm = fast_sqrt(norm2(sp.mid));
+                    rawm[512] = fmax(mm - a.alpha * nrow[512], a.beta * mm);
                 }
                 // park the new spectrum, take the previous frame's
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const c2 plo = park[j * 64 + lane], phi = park[(8 + j) * 64 + lane];
+                    const C plo = park[j * 64 + lane], phi = park[(8 + j) * 64 + lane];
                     park[j * 64 + lane] = sp.lo[j];
                     park[(8 + j) * 64 + lane] = sp.hi[j];
                     sp.lo[j] = plo;
                     sp.hi[j] = phi;
                 }
-                const c2 pm = park[1024];
+                const C pm = park[1024];
                 wave_sync();
                 if (lane == 0) park[1024] = sp.mid;
                 sp.mid = pm;
@@ -1347,13 +1425,13 @@ void k_apply_wave(ApplyArgs<float> a) {
                 __builtin_amdgcn_sched_barrier(0);
                 // box mean over five bins (the only frequency smoothing this kernel is launched for);
                 // same summation order as the shape-generic kernel
-                const float inv_sf = 1.0f / 5.0f;
-                const float *blo = rawm + lane - 2, *bhi = rawm + 576 - lane - 2;     // first bin of each window
-                auto box = [&](const float *p) {
-                    float rv[5];
+                const R inv_sf = (R)1.0 / (R)5.0;
+                const R *blo = rawm + lane - 2, *bhi = rawm + 576 - lane - 2;     // first bin of each window
+                auto box = [&](const R *p) {
+                    R rv[5];
 #pragma unroll
                     for (int d = 0; d < 5; ++d) rv[d] = p[d];
-                    float fs = 0.0f;
+                    R fs = (R)0.0;
 #pragma unroll
                     for (int d = 0; d < 5; ++d) fs += rv[d];
                     return fs * inv_sf;
@@ -1384,20 +1462,20 @@ void k_apply_wave(ApplyArgs<float> a) {
                 for (int j = 0; j < 8; ++j) {
                     m1_lo[j] = mc_lo[j];
                     m1_hi[j] = mc_hi[j];
-                    s2_lo[j] = s2_hi[j] = 0.0f;
+                    s2_lo[j] = s2_hi[j] = (R)0.0;
                 }
                 m1_mid = mc_mid;
-                s2_mid = 0.0f;
+                s2_mid = (R)0.0;
             }
             t = s - 1;
             if (t >= ta) {
                 // smoothed magnitude of frame t = (row[t-1] + row[t] + row[t+1]) / 3, phase of its spectrum kept:
                 // clean * exp(i angle(Z)) = clean * Z / |Z|, and angle(0) = 0
-                const float inv_st = 1.0f / (float)FAST_ST;
-                auto rephase = [&](c2 z, float sm) {
-                    const float p2 = norm2(z);
-                    const float g = sm * __builtin_amdgcn_rsqf(p2);
-                    return p2 > 0.0f ? z * g : c2{sm, 0.0f};
+                const R inv_st = (R)1.0 / (R)FAST_ST;
+                auto rephase = [&](C z, R sm) {
+                    const R p2 = norm2(z);
+                    const R g = sm * fast_rsq(p2);
+                    return p2 > (R)0.0 ? z * g : C{sm, (R)0.0};
                 };
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -1418,7 +1496,7 @@ void k_apply_wave(ApplyArgs<float> a) {
             m1_mid = mc_mid;
         } else {
             if (gain_in_lds) {
-                const float *glo = grow_lds + lane, *ghi = grow_lds + 576 - lane;     // upwards from bin 1024 - lane - 448
+                const R *glo = grow_lds + lane, *ghi = grow_lds + 576 - lane;     // upwards from bin 1024 - lane - 448
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     sp.lo[j] = sp.lo[j] * glo[64 * j];
@@ -1426,8 +1504,8 @@ void k_apply_wave(ApplyArgs<float> a) {
                 }
                 sp.mid = sp.mid * grow_lds[512];
             } else {
-                const float *grow = row + (int64_t)t * a.row_t_stride;     // per-frame gain rows (masks)
-                const float *glo = grow + lane, *ghi = grow + 1024 - lane;
+                const R *grow = row + (int64_t)t * a.row_t_stride;     // per-frame gain rows (masks)
+                const R *glo = grow + lane, *ghi = grow + 1024 - lane;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     sp.lo[j] = sp.lo[j] * glo[64 * j];
@@ -1442,13 +1520,13 @@ void k_apply_wave(ApplyArgs<float> a) {
             __builtin_amdgcn_sched_barrier(0);
             // ---- frame t: back to the packed spectrum, inverse transform
             {
-                c2 rtw[8];
+                C rtw[8];
                 derive_rtw(rtw, rtw0);
                 merge_spectrum_keep(sp, r, buf, rtw, lane);
             }
             wave_sync();
             {
-                const c2 *nb = buf + lane;
+                const C *nb = buf + lane;
 #pragma unroll
                 for (int j = 8; j < 16; ++j) r[j] = nb[64 * j + 8 * (j >> 2)];        // nat(lane + 64 j)
             }
@@ -1462,9 +1540,9 @@ void k_apply_wave(ApplyArgs<float> a) {
             // ---- synthesis window (first half stored: w[n + 1024] = 1 - w[n]), overlap-add
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
-                const c2 w0 = wv[mlane + 16 * cc], w1 = wv[mlane + 16 * cc + 256];
-                const c2 q0 = r[4 * cc] * w0, q1 = r[4 * cc + 1] * w1;
-                const c2 q2 = r[4 * cc + 2] - r[4 * cc + 2] * w0, q3 = r[4 * cc + 3] - r[4 * cc + 3] * w1;
+                const C w0 = wv[mlane + 16 * cc], w1 = wv[mlane + 16 * cc + 256];
+                const C q0 = r[4 * cc] * w0, q1 = r[4 * cc + 1] * w1;
+                const C q2 = r[4 * cc + 2] - r[4 * cc + 2] * w0, q3 = r[4 * cc + 3] - r[4 * cc + 3] * w1;
                 pend[cc] = acc0[cc] + q0;                  // oldest frame first, like a sequential overlap-add
                 acc0[cc] = acc1[cc] + q1;
                 acc1[cc] = acc2[cc] + q2;
@@ -1590,7 +1668,7 @@ void k_rows_wave(const float *__restrict__ x, Signals sg, Tables<float> tb, int6
         float p[17];
         if (t < Tn) {
             const LaneTw tw = lane_tw(twtab, lane);
-            typename FetchT<NCH>::type pf[16];
+            typename FetchT<NCH, float>::type pf[16];
             const bool pf_mode = fetch_frame<NCH>(pf, xs, n, sg.n_ch, (int64_t)t * H, lane);
             c2 r[16];
             if (pf_mode) {
@@ -1668,9 +1746,9 @@ void k_rows_wave(const float *__restrict__ x, Signals sg, Tables<float> tb, int6
 
 static size_t rows_wave_lds(int W) { return (size_t)W * WBUF * sizeof(c2) + (size_t)TWTAB * sizeof(c2) + 1024 * sizeof(float); }
 
-static size_t apply_wave_lds(int W, int mode) {
-    return (size_t)W * WBUF * sizeof(c2) + (size_t)W * (mode == APPLY_SUBTRACT ? PARK : 0) * sizeof(c2) +
-           (size_t)TWTAB * sizeof(c2) + (1024 + 512 + GROW) * sizeof(float);
+static size_t apply_wave_lds(int W, int mode, size_t real_bytes) {
+    return ((size_t)W * WBUF * 2 + (size_t)W * (mode == APPLY_SUBTRACT ? PARK : 0) * 2 + (size_t)TWTAB * 2 +
+            (1024 + 512 + GROW)) * real_bytes;
 }
 
 static size_t apply_lds(int W, int mode, int hop) {
@@ -1684,14 +1762,17 @@ static size_t apply_lds(int W, int mode, int hop) {
 }  // namespace fast
 
 // hop 512: one wave per run of hops
-template <int MODE>
-static int apply_wave(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
-    constexpr int W = MODE == APPLY_SUBTRACT ? 8 : 4;
+template <typename R, int MODE>
+static int apply_wave(Ctx *c, ApplyArgs<R> a, int64_t n_sig, int64_t Tmax) {
+    // binary32: eight waves (SUBTRACT, two per SIMD) / four (GAIN, three workgroups per CU); binary64: a wave's
+    // exchange buffer and parked spectrum are 34 KB, three waves (SUBTRACT) / four (GAIN) fill the LDS of a CU
+    constexpr int W = sizeof(R) == 8 ? (MODE == APPLY_SUBTRACT ? 3 : 4) : (MODE == APPLY_SUBTRACT ? 8 : 4);
+    constexpr int WAVES_PER_CU = sizeof(R) == 8 ? W : (MODE == APPLY_SUBTRACT ? 8 : 12);
     const int64_t out_hops = Tmax - 1;
     if (out_hops <= 0) return ADN_OK;
     // two rounds of runs over the waves a full chip holds; a run pays three warm-up frames (and two
     // analysis-only frames in SUBTRACT mode), so it is not made shorter than 16 hops
-    int64_t run = ceil_div(n_sig * out_hops, (int64_t)c->num_cus * 8 * 2);
+    int64_t run = ceil_div(n_sig * out_hops, (int64_t)c->num_cus * WAVES_PER_CU * 2);
     run = run < 16 ? 16 : (run > 1024 ? 1024 : run);
     a.seg_hops = (int)run;
     a.segs_per_sig = ceil_div(out_hops, run);
@@ -1703,15 +1784,15 @@ static int apply_wave(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
         set_error("internal: the caller of the fused STFT kernel did not reserve its scratch line");
         return ADN_ERR_NOMEM;
     }
-    a.dummy = ws_take<float>(c, APPLY_WS_BYTES / sizeof(float));
-    const size_t lds = fast::apply_wave_lds(W, MODE);
+    a.dummy = ws_take<R>(c, APPLY_WS_BYTES / sizeof(R));
+    const size_t lds = fast::apply_wave_lds(W, MODE, sizeof(R));
     a.dbg = nullptr;
     if (c->ablate & 16) {       // diagnostics: per-phase cycle totals, printed after the launch
         ADN_HIP(hipMalloc(&a.dbg, 8 * sizeof(unsigned long long)));
         ADN_HIP(hipMemset(a.dbg, 0, 8 * sizeof(unsigned long long)));
     }
-    auto kern = a.sg.n_ch == 2 ? (a.dbg ? fast::k_apply_wave<W, MODE, 2, true> : fast::k_apply_wave<W, MODE, 2, false>)
-                               : (a.dbg ? fast::k_apply_wave<W, MODE, 1, true> : fast::k_apply_wave<W, MODE, 1, false>);
+    auto kern = a.sg.n_ch == 2 ? (a.dbg ? fast::k_apply_wave<R, W, MODE, 2, true> : fast::k_apply_wave<R, W, MODE, 2, false>)
+                               : (a.dbg ? fast::k_apply_wave<R, W, MODE, 1, true> : fast::k_apply_wave<R, W, MODE, 1, false>);
     ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t wgs = ceil_div(n_sig * a.segs_per_sig, (int64_t)W);
     ADN_REQUIRE(wgs < (int64_t)0x7FFFFFFF, "batch too large for one launch");
@@ -1734,7 +1815,7 @@ static int apply_wave(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
 template <int MODE>
 int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
     if (a.sg.hop == 512 && (c->ablate & ~16) == 0 && (MODE == APPLY_GAIN || (a.sf == 5 && a.st == fast::FAST_ST)))
-        return apply_wave<MODE>(c, a, n_sig, Tmax);
+        return apply_wave<float, MODE>(c, a, n_sig, Tmax);
     // 8 waves per workgroup.  4-wave workgroups, two per CU, measured the same in GAIN mode (the
     // overlap-add path handles W = 4 too) and do not fit LDS twice in SUBTRACT mode.
     constexpr int W = 8;
@@ -1826,6 +1907,17 @@ int rows_wave(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &
     ADN_HIP(hipGetLastError());
     return ADN_OK;
 }
+
+// binary64, n_fft 2048, hop 512: the one-wave-per-run kernels at the reference's precision
+bool apply_wave64_ok(int n_fft, int hop, int st, int sf, int mode) {
+    return n_fft == 2048 && hop == 512 && (mode == APPLY_GAIN || (sf == 5 && st == fast::FAST_ST));
+}
+template <int MODE>
+int apply_wave64(Ctx *c, ApplyArgs<double> a, int64_t n_sig, int64_t Tmax) {
+    return apply_wave<double, MODE>(c, a, n_sig, Tmax);
+}
+template int apply_wave64<APPLY_SUBTRACT>(Ctx *, ApplyArgs<double>, int64_t, int64_t);
+template int apply_wave64<APPLY_GAIN>(Ctx *, ApplyArgs<double>, int64_t, int64_t);
 
 template int apply_fast<APPLY_SUBTRACT>(Ctx *, ApplyArgs<float>, int64_t, int64_t);
 template int apply_fast<APPLY_GAIN>(Ctx *, ApplyArgs<float>, int64_t, int64_t);

@@ -107,6 +107,10 @@ static constexpr size_t APPLY_WS_BYTES = 4096;
 
 // register-resident path (binary32, n_fft = 2048)
 bool apply_fast_ok(int n_fft, int hop, int st, int sf);
+// the same kernels at binary64 (hop 512 only); the caller reserves APPLY_WS_BYTES beyond what it took
+bool apply_wave64_ok(int n_fft, int hop, int st, int sf, int mode);
+template <int MODE>
+int apply_wave64(Ctx *c, ApplyArgs<double> a, int64_t n_sig, int64_t Tmax);
 // binary32 rows in groups of four frames (see k_rows_wave); the caller reserves APPLY_WS_BYTES beyond what it took
 // 16-byte slots per group of four frames: the 1025 bins padded to a multiple of eight, so that the eight rows
 // whose pieces share a 128-byte line are the same eight rows in every group
