@@ -1547,8 +1547,15 @@ static constexpr int SEL_CK = 8;                        // candidate keys per la
 // alike.  (a) runs in groups of eight compares followed by their eight counts: a scalar instruction that reads
 // a register the vector unit has just written waits for that instruction to leave the vector pipeline, and with
 // the compares grouped the wait is paid once per group.
-template <int N>
-__device__ __forceinline__ uint32_t count_below(const uint32_t (&key)[N], uint32_t trial) {
+__device__ __forceinline__ void count_add_vector(uint32_t &vc, uint32_t key, uint32_t trial) {
+    asm volatile("v_cmp_gt_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc" : "+v"(vc) : "v"(key), "s"(trial) : "vcc");
+}
+__device__ __forceinline__ void count_add_vector(uint32_t &vc, uint64_t key, uint64_t trial) {
+    asm volatile("v_cmp_gt_u64_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc" : "+v"(vc) : "v"(key), "s"(trial) : "vcc");
+}
+
+template <typename K, int N>
+__device__ __forceinline__ uint32_t count_below(const K (&key)[N], K trial) {
     uint32_t cnt = 0, vc = 0;
 #pragma unroll
     for (int g = 0; g < N; g += 12) {
@@ -1558,11 +1565,7 @@ __device__ __forceinline__ uint32_t count_below(const uint32_t (&key)[N], uint32
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 8; i < 12; ++i)
-            if (g + i < N)
-                asm volatile("v_cmp_gt_u32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, 0, %0, vcc"
-                             : "+v"(vc)
-                             : "v"(key[g + i]), "s"(trial)
-                             : "vcc");
+            if (g + i < N) count_add_vector(vc, key[g + i], trial);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             if (g + i < N) cnt += (uint32_t)__builtin_popcountll(m[i]);
@@ -1576,13 +1579,24 @@ __device__ __forceinline__ uint32_t count_below(const uint32_t (&key)[N], uint32
     return cnt;
 }
 
-template <int XF, bool MASKED, int KPL>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KPL <= 96 ? 3 : 2))) void k_select_wave(const float *__restrict__ vals, const int64_t *__restrict__ seg_off,
+// four consecutive values of a row as one load
+template <typename T> struct Quad4;
+template <> struct Quad4<float> { typedef float4 type; };
+template <> struct Quad4<double> { typedef double4 type; };
+
+// T: binary32 (keys of 32 bits, three waves per SIMD up to 96 keys per lane) or binary64 (64-bit keys: twice the registers)
+template <typename T, int XF, bool MASKED, int KPL>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? (KPL <= 96 ? 2 : 1) : (KPL <= 96 ? 3 : 2))))
+void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_off,
                                                      int64_t seg_stride, const int64_t *__restrict__ seg_len,
                                                      int64_t len_div, int64_t uniform_len, int64_t n_seg, int mode,
                                                      double q, const double *__restrict__ center,
                                                      double *__restrict__ out, MaskedMean mm, int max_bits,
                                                      int64_t quad_stride, int64_t blk_rows, int64_t blk_sig_stride) {
+    typedef typename KeyT<T>::type K;
+    typedef typename Quad4<T>::type Q4;
+    constexpr K KEY_MAX = ~(K)0;
     const int lane = threadIdx.x & 63;
     // the wave index as a scalar: the row's addresses then live in scalar registers and every load of the row
     // takes one 32-bit lane offset instead of a 64-bit address pair
@@ -1605,8 +1619,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KPL <= 96 ?
     double frac;
     big_ranks(n, mode, q, &r0l, &r1l, &frac);
     const uint32_t r0 = (uint32_t)r0l, r1 = (uint32_t)r1l;
-    const float c = XF == XF_ABSDEV ? (float)center[seg] : 0.0f;
-    const float *vrow = quad_stride != 1 ? vals + (seg / blk_rows) * blk_sig_stride + (seg % blk_rows) * 4
+    const T c = XF == XF_ABSDEV ? (T)center[seg] : (T)0;
+    const T *vrow = quad_stride != 1 ? vals + (seg / blk_rows) * blk_sig_stride + (seg % blk_rows) * 4
                                          : vals + (seg_off ? seg_off[seg] : seg * seg_stride);
     const uint32_t qs = (uint32_t)quad_stride;
     const unsigned char *mrow = MASKED ? mm.mask + (seg / mm.mask_div) * mm.mask_stride : nullptr;
@@ -1615,19 +1629,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KPL <= 96 ?
     // element 4 (lane + 64 i) + e is key[4 i + e] (a quad index beyond the row re-reads the row's last whole quad and
     // is ignored); the up to three elements after the last whole quad go to the extra slot key[KPL] of lanes 0..2.
     // Positions that hold no element of the row keep the largest key.
-    uint32_t key[KPL + 1];
-    float msum = 0.0f;
+    K key[KPL + 1];
+    T msum = 0;
     int mcnt = 0;
     bool saw_nan = false;
-    uint32_t kmin = 0xFFFFFFFFu, kmax = 0;
-    auto take = [&](int slot, float x, unsigned m, bool valid) {
+    K kmin = KEY_MAX, kmax = 0;
+    auto take = [&](int slot, T x, unsigned m, bool valid) {
         if (MASKED && valid && m) {
             msum += x;
             ++mcnt;
         }
-        if (XF == XF_ABSDEV) x = fabsf(x - c);
+        if (XF == XF_ABSDEV) x = (T)fabs(x - c);
         const bool is_nan = x != x;
-        const uint32_t k = (!valid || is_nan) ? 0xFFFFFFFFu : key_of(x);
+        const K k = (!valid || is_nan) ? KEY_MAX : key_of(x);
         saw_nan |= valid && is_nan;
         key[slot] = k;
         if (valid) {
@@ -1636,23 +1650,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KPL <= 96 ?
         }
     };
     const bool vec_ok = quad_stride != 1 ||
-                        ((reinterpret_cast<uintptr_t>(vrow) & 15) == 0 && (!MASKED || (reinterpret_cast<uintptr_t>(mrow) & 3) == 0));
+                        ((reinterpret_cast<uintptr_t>(vrow) & (sizeof(Q4) - 1)) == 0 && (!MASKED || (reinterpret_cast<uintptr_t>(mrow) & 3) == 0));
     // The loads go out in batches (all loads of a batch back to back, no branch between them) and a batch is
     // turned into keys before the next one is requested: the staging registers of ONE batch beside the keys keep
     // the kernel at three waves per SIMD, and it is the other waves that cover a wave's memory round trips.
     constexpr int SB = KPL < 16 ? KPL : 16;                 // single elements per batch (rows that are not 16-byte aligned)
-    constexpr int QB = KPL / 4 <= 24 ? KPL / 4 : 24;          // quads per batch
+    constexpr int QBMAX = sizeof(T) == 8 ? 12 : 24;
+    constexpr int QB = KPL / 4 <= QBMAX ? KPL / 4 : QBMAX;    // quads per batch
     if (vec_ok && n >= 4) {
         const int nq = n >> 2;                              // whole quads
-        const float4 *vv = reinterpret_cast<const float4 *>(vrow);
+        const Q4 *vv = reinterpret_cast<const Q4 *>(vrow);
         const uint32_t *mv = reinterpret_cast<const uint32_t *>(mrow);
         const int jt = 4 * nq + lane;                       // tail element of lanes 0..2
         const bool tail = lane < 3 && jt < n;
-        const float xt = vrow[tail ? (size_t)nq * 4 * qs + lane : 0];
+        const T xt = vrow[tail ? (size_t)nq * 4 * qs + lane : 0];
         const unsigned mt = MASKED ? mrow[tail ? jt : 0] : 0u;
 #pragma unroll
         for (int b0 = 0; b0 < KPL / 4; b0 += QB) {
-            float4 xq[QB];
+            Q4 xq[QB];
             uint32_t mq[QB];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1676,7 +1691,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KPL <= 96 ?
     } else {
 #pragma unroll
         for (int b0 = 0; b0 < KPL; b0 += SB) {
-            float xs[SB];
+            T xs[SB];
             unsigned ms[SB];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1690,11 +1705,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KPL <= 96 ?
 #pragma unroll
             for (int i = 0; i < SB; ++i) take(b0 + i, xs[i], ms[i], lane + 64 * (b0 + i) < n);
         }
-        key[KPL] = 0xFFFFFFFFu;
+        key[KPL] = KEY_MAX;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
-        const uint32_t a = __shfl_xor(kmin, d), b = __shfl_xor(kmax, d);
+        const K a = __shfl_xor(kmin, d), b = __shfl_xor(kmax, d);
         kmin = a < kmin ? a : kmin;
         kmax = b > kmax ? b : kmax;
         if (MASKED) {
@@ -1703,13 +1718,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KPL <= 96 ?
         }
     }
     const bool any_nan = __ballot(saw_nan) != 0;
-    if (MASKED && lane == 0) mm.out[seg] = (double)(msum / (float)(mcnt > 1 ? mcnt : 1));
+    if (MASKED && lane == 0) mm.out[seg] = (double)(msum / (T)(mcnt > 1 ? mcnt : 1));
     if (any_nan) {
         if (lane == 0) out[seg] = __longlong_as_double(0x7FF8000000000000ll);
         return;
     }
     // ---- selection on key - kmin (the padding keys stay above every trial value that can be accepted)
-    int bits = 32 - __clz(kmax - kmin);                    // 0 when all keys are equal
+    int bits = kmax == kmin ? 0 : (int)(8 * sizeof(K)) - (sizeof(K) == 8 ? __clzll((long long)(kmax - kmin)) : __clz((int)(kmax - kmin)));
     bits = bits < max_bits ? bits : max_bits;              // diagnostics (ADN_OPT_ABLATE): results become wrong
 #pragma unroll
     for (int i = 0; i <= KPL; ++i) key[i] -= kmin;
@@ -1717,13 +1732,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KPL <= 96 ?
     // keys that still share the decided prefix.  Once those candidates fit SEL_CK registers per lane they are
     // compacted (through the wave's LDS slot) and the remaining bits are decided on them alone: a row of some
     // thousand spread-out keys needs a handful of full sweeps, not one per bit.
-    uint32_t res = 0, lo_cnt = 0, hi_cnt = (uint32_t)n;
-    uint32_t ck[SEL_CK];
+    K res = 0;
+    uint32_t lo_cnt = 0, hi_cnt = (uint32_t)n;
+    K ck[SEL_CK];
     bool compact = false;
     int b = bits - 1;
     for (; b >= 0; --b) {
-        const uint32_t trial = res | (1u << b);
-        const uint32_t cnt = count_below<KPL + 1>(key, trial);
+        const K trial = res | ((K)1 << b);
+        const uint32_t cnt = count_below<K, KPL + 1>(key, trial);
         if (cnt <= r0) {                                    // the r0-th key (0-based) is >= trial
             res = trial;
             lo_cnt = cnt;
@@ -1736,9 +1752,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KPL <= 96 ?
         }
     }
     if (compact) {
-        __shared__ uint32_t cbuf_all[4][SEL_CK * 64];
-        uint32_t *cbuf = cbuf_all[threadIdx.x >> 6];
-        const uint32_t span = 1u << b;                      // candidates: res <= key < res + span
+        __shared__ K cbuf_all[4][SEL_CK * 64];
+        K *cbuf = cbuf_all[threadIdx.x >> 6];
+        const K span = (K)1 << b;                      // candidates: res <= key < res + span
         uint32_t base = 0;
 #pragma unroll
         for (int i = 0; i <= KPL; ++i) {
@@ -1753,17 +1769,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KPL <= 96 ?
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int i = 0; i < SEL_CK; ++i) ck[i] = lane + 64 * i < (int)base ? cbuf[lane + 64 * i] : 0xFFFFFFFFu;
+        for (int i = 0; i < SEL_CK; ++i) ck[i] = lane + 64 * i < (int)base ? cbuf[lane + 64 * i] : KEY_MAX;
         for (--b; b >= 0; --b) {
-            const uint32_t trial = res | (1u << b);
-            const uint32_t cnt = lo_cnt + count_below<SEL_CK>(ck, trial);
+            const K trial = res | ((K)1 << b);
+            const uint32_t cnt = lo_cnt + count_below<K, SEL_CK>(ck, trial);
             if (cnt <= r0) res = trial;
         }
     }
-    uint32_t k0 = res, k1 = res;
+    K k0 = res, k1 = res;
     if (r1 != r0) {
         // the next order statistic: the same value if it occurs often enough, else the smallest key above it
-        uint32_t cnt_le = 0, above = 0xFFFFFFFFu;
+        uint32_t cnt_le = 0;
+        K above = KEY_MAX;
 #pragma unroll
         for (int i = 0; i <= KPL; ++i) {
             cnt_le += (uint32_t)__builtin_popcountll(__ballot(key[i] <= res));
@@ -1773,27 +1790,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KPL <= 96 ?
         if (cnt_le <= r1) {
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) {
-                const uint32_t o = __shfl_xor(above, d);
+                const K o = __shfl_xor(above, d);
                 above = o < above ? o : above;
             }
             k1 = above;
         }
     }
-    if (lane == 0) out[seg] = select_result<float>(val_of(k0 + kmin), val_of(k1 + kmin), r0 == r1, frac, mode);
+    if (lane == 0) out[seg] = select_result<T>(val_of((K)(k0 + kmin)), val_of((K)(k1 + kmin)), r0 == r1, frac, mode);
 }
 
 static constexpr int64_t SEL_WAVE_MAX = 128 * 64;       // longest row the register-resident kernel takes
 
-template <int XF, bool MASKED>
-static int launch_select_wave(Ctx *c, const float *d_vals, const SelectArgs &a) {
+template <typename T, int XF, bool MASKED>
+static int launch_select_wave(Ctx *c, const T *d_vals, const SelectArgs &a) {
     MaskedMean mm{a.d_mask, a.mask_div, a.mask_stride, a.d_masked_mean};
     // (grouped rows: a multiple of 16 workgroups, so that the kernel's workgroup permutation is one)
     const int64_t wgs = a.quad_stride != 1 ? ceil_div(ceil_div(a.n_seg, (int64_t)4), (int64_t)16) * 16 : ceil_div(a.n_seg, (int64_t)4);
     dim3 grid((unsigned)wgs), block(256);
 #define ADN_SEL_WAVE(KPLV)                                                                                          \
-    ADN_LAUNCH_NAMED("k_select_wave<" #KPLV ">", (k_select_wave<XF, MASKED, KPLV>), grid, block, 0, c->stream, d_vals,  \
+    ADN_LAUNCH_NAMED("k_select_wave<" #KPLV ">", (k_select_wave<T, XF, MASKED, KPLV>), grid, block, 0, c->stream, d_vals,  \
                      a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len, a.n_seg, a.mode, a.q, a.d_center, \
-                     a.d_out, mm, (c->ablate & 32) ? 0 : 32, a.quad_stride, a.blk_rows, a.blk_sig_stride)
+                     a.d_out, mm, (c->ablate & 32) ? 0 : 64, a.quad_stride, a.blk_rows, a.blk_sig_stride)
     if (a.max_len <= 8 * 64) ADN_SEL_WAVE(8);
     else if (a.max_len <= 24 * 64) ADN_SEL_WAVE(24);
     else if (a.max_len <= 48 * 64) ADN_SEL_WAVE(48);
@@ -1811,10 +1828,10 @@ int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {
     if (a.n_seg <= 0) return ADN_OK;
     using K = typename KeyT<T>::type;
     if (a.quad_stride != 1) {
-        ADN_REQUIRE((std::is_same<T, float>::value) && a.max_len > 0 && a.max_len <= select_grouped_limit() &&
-                        a.mode != SEL_PERCENTILE_DB20 && (reinterpret_cast<uintptr_t>(d_vals) & 15) == 0 &&
+        ADN_REQUIRE(a.max_len > 0 && a.max_len <= select_grouped_limit() &&
+                        a.mode != SEL_PERCENTILE_DB20 && (reinterpret_cast<uintptr_t>(d_vals) & 31) == 0 &&
                         a.blk_sig_stride % 4 == 0 && (a.quad_stride * (a.max_len / 4 + 1)) < (int64_t(1) << 28),
-                    "internal: grouped rows are binary32 rows of at most %lld values", (long long)select_grouped_limit());
+                    "internal: grouped rows are rows of at most %lld values", (long long)select_grouped_limit());
     }
     if (a.max_len > BIG_THRESHOLD) {
         if (a.d_masked_mean) {
@@ -1824,15 +1841,14 @@ int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {
         return a.xform == XF_ABSDEV ? launch_select_big<T, XF_ABSDEV>(c, d_vals, a)
                                     : launch_select_big<T, XF_NONE>(c, d_vals, a);
     }
-    // binary32 rows of up to a few thousand values: one wave per row, keys in registers
-    if constexpr (std::is_same<T, float>::value) {
-        if ((!c->force_generic || a.quad_stride != 1) && a.max_len > 0 && a.max_len <= SEL_WAVE_MAX &&
-            a.mode != SEL_PERCENTILE_DB20) {
-            const bool masked = a.d_masked_mean != nullptr;
-            if (a.xform == XF_ABSDEV) return masked ? launch_select_wave<XF_ABSDEV, true>(c, d_vals, a)
-                                                    : launch_select_wave<XF_ABSDEV, false>(c, d_vals, a);
-            return masked ? launch_select_wave<XF_NONE, true>(c, d_vals, a) : launch_select_wave<XF_NONE, false>(c, d_vals, a);
-        }
+    // rows of up to a few thousand values: one wave per row, keys in registers (binary64: rows in the grouped
+    // layout only, the other binary64 rows keep the LDS kernels)
+    if ((!c->force_generic || a.quad_stride != 1) && a.max_len > 0 && a.max_len <= SEL_WAVE_MAX && a.mode != SEL_PERCENTILE_DB20 &&
+        (std::is_same<T, float>::value || a.quad_stride != 1)) {
+        const bool masked = a.d_masked_mean != nullptr;
+        if (a.xform == XF_ABSDEV) return masked ? launch_select_wave<T, XF_ABSDEV, true>(c, d_vals, a)
+                                                : launch_select_wave<T, XF_ABSDEV, false>(c, d_vals, a);
+        return masked ? launch_select_wave<T, XF_NONE, true>(c, d_vals, a) : launch_select_wave<T, XF_NONE, false>(c, d_vals, a);
     }
     // segments whose keys fit LDS take the lean kernel (LDS = the keys, several workgroups per CU)
     if (a.max_len > 0 && (size_t)a.max_len * sizeof(K) <= SEL_LDS_MAX_BYTES) {

@@ -1105,7 +1105,7 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     const int64_t Tmax = stft_frames(max_len, n_fft, hop, 1);
     const int64_t nv_max = vad_guided ? (ceil_div(max_len, frame_len) < 1 ? 1 : ceil_div(max_len, frame_len)) : 1;
     const int64_t Ts = row_stride(Tmax);
-    // (the grouped layout of binary32 rows pads the bins: slightly more per signal than F * Ts)
+    // (the grouped layout of the rows pads the bins: slightly more per signal than F * Ts)
     const int64_t sig_floats = std::max<int64_t>((int64_t)F * Ts, rows_wave_sig_floats(Tmax));
     const size_t nS = (size_t)n_sig * sig_floats, nR = (size_t)n_sig * F;
     ADN_TRY(ws_reserve(c, ws_need(nS, sizeof(T)) + ws_need(n_sig, 8) + 2 * ws_need(nR, 8) + ws_need(nR, sizeof(T)) +
@@ -1121,12 +1121,10 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     Signals sg{d_off, d_len, n_ch, n_fft, hop, 1};
     ADN_LAUNCH(k_frame_counts, dim3((unsigned)ceil_div(n_sig, 256)), dim3(256), 0, c->stream, sg, n_sig, Tn);
     SelectArgs sa;
-    // binary32 rows of up to a few thousand frames: power rows in groups of four frames, written by waves that
+    // rows of up to a few thousand frames: power rows in groups of four frames, written by waves that
     // work alone and read by the register-resident row select; the rows kernel adds up the voice-activity
     // frames' energies on the way when those frames are at least a hop long
-    bool grouped = false;
-    if constexpr (std::is_same<T, float>::value)
-        grouped = !c->force_generic && (c->ablate & 64) == 0 && rows_wave_ok(sg, n_fft) && Tmax <= select_grouped_limit();
+    const bool grouped = !c->force_generic && (c->ablate & 64) == 0 && rows_wave_ok(sg, n_fft) && Tmax <= select_grouped_limit();
     const bool vad_in_rows = grouped && vad_guided && (c->ablate & 128) == 0 && frame_len >= hop &&
                              frame_len <= rows_wave_vad_max_frame();
     if (vad_guided && !vad_in_rows) {
@@ -1137,8 +1135,7 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     }
     if (grouped) {
         if (vad_in_rows) ADN_HIP(hipMemsetAsync(vad_e, 0, (size_t)n_sig * nv_max * sizeof(double), c->stream));
-        if constexpr (std::is_same<T, float>::value)
-            ADN_TRY(rows_wave(c, d_x, sg, tb, n_sig, Tmax, 1, S, sig_floats, vad_in_rows ? vad_e : nullptr, frame_len, nv_max));
+        ADN_TRY(rows_wave<T>(c, d_x, sg, tb, n_sig, Tmax, 1, S, sig_floats, vad_in_rows ? vad_e : nullptr, frame_len, nv_max));
         if (vad_in_rows) {
             ADN_LAUNCH(k_vad_flags, dim3((unsigned)ceil_div(n_sig * nv_max, 256)), dim3(256), 0, c->stream, sg, n_sig,
                        frame_len, nv_max, vad_e, speech);

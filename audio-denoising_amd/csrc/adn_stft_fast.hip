@@ -115,6 +115,7 @@ __device__ __forceinline__ c2 rot90(c2 v) {
 // binary64 instructions.  The kernels below are written once against this vocabulary.
 typedef double z2 __attribute__((ext_vector_type(2)));
 typedef double z4 __attribute__((ext_vector_type(4)));
+typedef float f4v __attribute__((ext_vector_type(4)));
 static_assert(sizeof(z2) == sizeof(double2), "z2 is layout-compatible with double2");
 __device__ __forceinline__ const z2 *as_c2(const double2 *p) { return reinterpret_cast<const z2 *>(p); }
 template <bool INV>
@@ -138,9 +139,12 @@ template <typename C> struct ReOf;
 template <> struct ReOf<c2> { typedef float type; };
 template <> struct ReOf<z2> { typedef double type; };
 template <typename C> using Re = typename ReOf<C>::type;
+template <typename R> struct QuadOf;                   // four values of R as one vector
 template <typename R> struct CxOf;
 template <> struct CxOf<float> { typedef c2 type; };
 template <> struct CxOf<double> { typedef z2 type; };
+template <> struct QuadOf<float> { typedef f4v type; };
+template <> struct QuadOf<double> { typedef z4 type; };
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
@@ -524,7 +528,6 @@ template <> struct FetchT<2, float> { typedef float4 type; };
 template <> struct FetchT<1, double> { typedef z2 type; };
 template <> struct FetchT<2, double> { typedef z4 type; };
 
-typedef float f4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ c2 load_streaming(const c2 *p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ float4 load_streaming(const float4 *p) {
     const f4v v = __builtin_nontemporal_load(reinterpret_cast<const f4v *>(p));
@@ -1591,16 +1594,18 @@ __device__ __forceinline__ double wave_sum_to_last_lane(double v) {
 // its frames (the signal's last run: everything up to the signal's end); per lane two binary64 accumulators, for
 // the voice-activity frame the run is in and for the next one; a finished frame's sum goes to vad_e[frame] with
 // one atomic addition per run that holds a part of it -- at most two runs, so the sum does not depend on their order.
-template <int W, int NCH, bool VADE>
-__global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void k_rows_wave(const float *__restrict__ x, Signals sg, Tables<float> tb, int64_t n_sig, int64_t runs_per_sig,
-                 int groups_per_run, int64_t sig_stride, int power, float *__restrict__ S, float *__restrict__ dummy,
+template <typename R, int W, int NCH, bool VADE>
+__global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 8 ? 1 : 3, sizeof(R) == 8 ? 1 : 3)))
+void k_rows_wave(const R *__restrict__ x, Signals sg, Tables<R> tb, int64_t n_sig, int64_t runs_per_sig,
+                 int groups_per_run, int64_t sig_stride, int power, R *__restrict__ S, R *__restrict__ dummy,
                  double *__restrict__ vad_e, int64_t frame_len, int64_t nv_max) {
+    typedef typename CxOf<R>::type C;
+    typedef typename QuadOf<R>::type Q;                    // the four frames of a bin: one store
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int H = 512;
-    c2 *bufs = reinterpret_cast<c2 *>(smem);                                          // [W][WBUF] exchange
-    c2 *twtab = bufs + (size_t)W * WBUF;
-    float *wtab = reinterpret_cast<float *>(twtab + TWTAB);                           // [1024] first half of the window
+    C *bufs = reinterpret_cast<C *>(smem);                                          // [W][WBUF] exchange
+    C *twtab = bufs + (size_t)W * WBUF;
+    R *wtab = reinterpret_cast<R *>(twtab + TWTAB);                           // [1024] first half of the window
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane0 = threadIdx.x & 63, tid = threadIdx.x;
     fill_tw_table(twtab, tb.fast_tw, tid, W * 64);
     for (int i = tid; i < 1024; i += W * 64) wtab[i] = tb.window[i];
@@ -1615,15 +1620,15 @@ void k_rows_wave(const float *__restrict__ x, Signals sg, Tables<float> tb, int6
     if (4 * g0 >= Tn) return;
     const int g_all = (Tn + 3) >> 2;
     const int g1 = g0 + groups_per_run < g_all ? g0 + groups_per_run : g_all;
-    const float *xs = x + sg.off[sig];
-    float4 *Sg = reinterpret_cast<float4 *>(S + sig * sig_stride);
-    c2 *buf = bufs + wave * WBUF;
-    const c2 *wv = reinterpret_cast<const c2 *>(wtab);
-    const c2 rtw0 = as_c2(tb.rtw)[lane0];
-    const float scale = (float)(1.0 / tb.wsum);
-    float m0[17], m1[17], m2[17], m3[17];                  // the lane's bins of the group's four frames
+    const R *xs = x + sg.off[sig];
+    Q *Sg = reinterpret_cast<Q *>(S + sig * sig_stride);
+    C *buf = bufs + wave * WBUF;
+    const C *wv = reinterpret_cast<const C *>(wtab);
+    const C rtw0 = as_c2(tb.rtw)[lane0];
+    const R scale = (R)(1.0 / tb.wsum);
+    R m0[17], m1[17], m2[17], m3[17];                  // the lane's bins of the group's four frames
 #pragma unroll
-    for (int i = 0; i < 17; ++i) m0[i] = m1[i] = m2[i] = m3[i] = 0.0f;
+    for (int i = 0; i < 17; ++i) m0[i] = m1[i] = m2[i] = m3[i] = (R)0.0;
     // voice-activity energies: accA belongs to frame vcur, accB to frame vcur + 1
     double accA = 0.0, accB = 0.0;
     int64_t vcur = -1;
@@ -1633,7 +1638,7 @@ void k_rows_wave(const float *__restrict__ x, Signals sg, Tables<float> tb, int6
         if (lane0 == 63 && fr >= 0 && fr < nv_max) atomicAdd(&ve[fr], v);
     };
     // the hop at sample P; the lane holds its samples 2 lane + 128 j (+ 1) in s[j]
-    auto vad_hop = [&](int64_t P, const c2 (&sv)[4], int lane) {
+    auto vad_hop = [&](int64_t P, const C (&sv)[4], int lane) {
         const int64_t v0 = P / frame_len;
         if (vcur < 0) vcur = v0;
         if (v0 != vcur) {                                  // a hop is not longer than a frame: v0 == vcur + 1
@@ -1653,11 +1658,11 @@ void k_rows_wave(const float *__restrict__ x, Signals sg, Tables<float> tb, int6
         }
     };
     auto vad_hop_from_memory = [&](int64_t P, int lane) {
-        c2 sv[4];
+        C sv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int64_t q = P + 2 * lane + 128 * j;
-            sv[j] = c2{fold_sample(xs, q, n, sg.n_ch), fold_sample(xs, q + 1, n, sg.n_ch)};
+            sv[j] = C{fold_sample(xs, q, n, sg.n_ch), fold_sample(xs, q + 1, n, sg.n_ch)};
         }
         vad_hop(P, sv, lane);
     };
@@ -1665,23 +1670,23 @@ void k_rows_wave(const float *__restrict__ x, Signals sg, Tables<float> tb, int6
     for (int t = 4 * g0; t < 4 * g1; ++t) {
         int lane = lane0;
         asm volatile("" : "+v"(lane));                     // lane-derived addresses are re-derived per frame, not kept
-        float p[17];
+        R p[17];
         if (t < Tn) {
-            const LaneTw tw = lane_tw(twtab, lane);
-            typename FetchT<NCH, float>::type pf[16];
+            const LaneTwT<C> tw = lane_tw(twtab, lane);
+            typename FetchT<NCH, R>::type pf[16];
             const bool pf_mode = fetch_frame<NCH>(pf, xs, n, sg.n_ch, (int64_t)t * H, lane);
-            c2 r[16];
+            C r[16];
             if (pf_mode) {
                 window_fetched(r, pf, wv, lane);
                 if (VADE) {
-                    const c2 sv[4] = {fold_point(pf[0]), fold_point(pf[1]), fold_point(pf[2]), fold_point(pf[3])};
+                    const C sv[4] = {fold_point(pf[0]), fold_point(pf[1]), fold_point(pf[2]), fold_point(pf[3])};
                     vad_hop((int64_t)t * H, sv, lane);
                 }
             } else {
                 if (VADE) vad_hop_from_memory((int64_t)t * H, lane);
                 stage_frame_half_window(buf, xs, n, sg.n_ch, (int64_t)t * H, wtab, lane);
                 wave_sync();
-                const c2 *nb = buf + lane;
+                const C *nb = buf + lane;
 #pragma unroll
                 for (int j = 0; j < 16; ++j) r[j] = nb[64 * j + 8 * (j >> 2)];        // nat(lane + 64 j)
                 wave_sync();
@@ -1689,9 +1694,9 @@ void k_rows_wave(const float *__restrict__ x, Signals sg, Tables<float> tb, int6
             wave_fft1024<false>(r, buf, tw, lane);
             store_natural(r, buf, lane);
             wave_sync();
-            Spec sp;
+            SpecT<C> sp;
             {
-                c2 rtw[8];
+                C rtw[8];
                 derive_rtw(rtw, rtw0);
                 split_spectrum(sp, buf, rtw, scale, lane);
             }
@@ -1704,11 +1709,11 @@ void k_rows_wave(const float *__restrict__ x, Signals sg, Tables<float> tb, int6
             p[16] = norm2(sp.mid);
             if (!power) {
 #pragma unroll
-                for (int i = 0; i < 17; ++i) p[i] = __builtin_amdgcn_sqrtf(p[i]);
+                for (int i = 0; i < 17; ++i) p[i] = fast_sqrt(p[i]);
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 17; ++i) p[i] = 0.0f;      // frames past the signal's end inside its last group
+            for (int i = 0; i < 17; ++i) p[i] = (R)0.0;      // frames past the signal's end inside its last group
         }
         const int e = t & 3;
         if (e == 0) {
@@ -1723,16 +1728,16 @@ void k_rows_wave(const float *__restrict__ x, Signals sg, Tables<float> tb, int6
         } else {
 #pragma unroll
             for (int i = 0; i < 17; ++i) m3[i] = p[i];
-            float4 *dst = Sg + (int64_t)(t >> 2) * ROWS_GROUP_STRIDE;
-            float4 *dlo = dst + lane, *dhi = dst + 1024 - lane;
+            Q *dst = Sg + (int64_t)(t >> 2) * ROWS_GROUP_STRIDE;
+            Q *dlo = dst + lane, *dhi = dst + 1024 - lane;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                __builtin_nontemporal_store(f4v{m0[j], m1[j], m2[j], m3[j]}, reinterpret_cast<f4v *>(dlo + 64 * j));
-                __builtin_nontemporal_store(f4v{m0[8 + j], m1[8 + j], m2[8 + j], m3[8 + j]}, reinterpret_cast<f4v *>(dhi - 64 * j));
+                __builtin_nontemporal_store(Q{m0[j], m1[j], m2[j], m3[j]}, dlo + 64 * j);
+                __builtin_nontemporal_store(Q{m0[8 + j], m1[8 + j], m2[8 + j], m3[8 + j]}, dhi - 64 * j);
             }
             // bin 512 belongs to lane 0; the other lanes' (meaningless) values go to a scratch line
-            float4 *dm = lane == 0 ? dst + 512 : reinterpret_cast<float4 *>(dummy) + lane;
-            *dm = float4{m0[16], m1[16], m2[16], m3[16]};
+            Q *dm = lane == 0 ? dst + 512 : reinterpret_cast<Q *>(dummy) + lane;
+            *dm = Q{m0[16], m1[16], m2[16], m3[16]};
         }
     }
     if (VADE) {
@@ -1744,7 +1749,7 @@ void k_rows_wave(const float *__restrict__ x, Signals sg, Tables<float> tb, int6
     }
 }
 
-static size_t rows_wave_lds(int W) { return (size_t)W * WBUF * sizeof(c2) + (size_t)TWTAB * sizeof(c2) + 1024 * sizeof(float); }
+static size_t rows_wave_lds(int W, size_t real_bytes) { return ((size_t)W * WBUF * 2 + (size_t)TWTAB * 2 + 1024) * real_bytes; }
 
 static size_t apply_wave_lds(int W, int mode, size_t real_bytes) {
     return ((size_t)W * WBUF * 2 + (size_t)W * (mode == APPLY_SUBTRACT ? PARK : 0) * 2 + (size_t)TWTAB * 2 +
@@ -1880,33 +1885,39 @@ int64_t rows_wave_vad_max_frame() { return 4 * 4 * 512; }      // the shortest r
 // Rows in groups of four frames: S[(s * sig_stride) + ((t / 4) * ROWS_GROUP_STRIDE + k) * 4 + t % 4];
 // sig_stride >= rows_wave_sig_floats(Tmax).
 // The caller has reserved APPLY_WS_BYTES of workspace beyond what it took.
-int rows_wave(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &tb, int64_t n_sig, int64_t Tmax,
-              int power, float *S, int64_t sig_stride, double *vad_e, int64_t frame_len, int64_t nv_max) {
+template <typename R>
+int rows_wave(Ctx *c, const R *d_x, const Signals &sg, const Tables<R> &tb, int64_t n_sig, int64_t Tmax,
+              int power, R *S, int64_t sig_stride, double *vad_e, int64_t frame_len, int64_t nv_max) {
     constexpr int W = 4;
     if (c->ws_used + APPLY_WS_BYTES > c->ws_bytes) {
         set_error("internal: the caller of the rows kernel did not reserve its scratch line");
         return ADN_ERR_NOMEM;
     }
-    float *dummy = ws_take<float>(c, APPLY_WS_BYTES / sizeof(float));
+    R *dummy = ws_take<R>(c, APPLY_WS_BYTES / sizeof(R));
     const int64_t groups = ceil_div(Tmax, (int64_t)4);
     // about two rounds of runs over the waves a full chip holds
-    int64_t gpr = ceil_div(n_sig * groups, (int64_t)c->num_cus * 12 * 2);
+    int64_t gpr = ceil_div(n_sig * groups, (int64_t)c->num_cus * (sizeof(R) == 8 ? 4 : 12) * 2);
     gpr = gpr < 4 ? 4 : (gpr > 64 ? 64 : gpr);
     const int64_t runs_per_sig = ceil_div(groups, gpr);
     const int64_t wgs = ceil_div(n_sig * runs_per_sig, (int64_t)W);
     ADN_REQUIRE(wgs < (int64_t)0x7FFFFFFF, "batch too large for one launch");
-    const size_t lds = fast::rows_wave_lds(W);
+    const size_t lds = fast::rows_wave_lds(W, sizeof(R));
     // voice-activity energies on the way (vad_e: n_sig x nv_max sums, zero on entry): a voice-activity frame must
     // not be longer than a run, so that at most two runs hold parts of it
     if (vad_e) ADN_REQUIRE(frame_len >= 512 && frame_len <= rows_wave_vad_max_frame(), "internal: voice-activity frame of %lld samples", (long long)frame_len);
-    auto kern = vad_e ? (sg.n_ch == 2 ? fast::k_rows_wave<W, 2, true> : fast::k_rows_wave<W, 1, true>)
-                      : (sg.n_ch == 2 ? fast::k_rows_wave<W, 2, false> : fast::k_rows_wave<W, 1, false>);
+    auto kern = vad_e ? (sg.n_ch == 2 ? fast::k_rows_wave<R, W, 2, true> : fast::k_rows_wave<R, W, 1, true>)
+                      : (sg.n_ch == 2 ? fast::k_rows_wave<R, W, 2, false> : fast::k_rows_wave<R, W, 1, false>);
     ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ADN_LAUNCH_NAMED("k_rows_wave", kern, dim3((unsigned)wgs), dim3(W * 64), lds, c->stream, d_x, sg, tb, n_sig, runs_per_sig,
                      (int)gpr, sig_stride, power, S, dummy, vad_e, frame_len, nv_max);
     ADN_HIP(hipGetLastError());
     return ADN_OK;
 }
+
+template int rows_wave<float>(Ctx *, const float *, const Signals &, const Tables<float> &, int64_t, int64_t, int, float *,
+                              int64_t, double *, int64_t, int64_t);
+template int rows_wave<double>(Ctx *, const double *, const Signals &, const Tables<double> &, int64_t, int64_t, int, double *,
+                               int64_t, double *, int64_t, int64_t);
 
 // binary64, n_fft 2048, hop 512: the one-wave-per-run kernels at the reference's precision
 bool apply_wave64_ok(int n_fft, int hop, int st, int sf, int mode) {

@@ -120,8 +120,9 @@ bool rows_wave_ok(const Signals &sg, int n_fft);
 // vad_e (may be null): n_sig x nv_max binary64 sums, zero on entry, receive the energy of every voice-activity frame
 // of frame_len samples (512 <= frame_len <= rows_wave_vad_max_frame())
 int64_t rows_wave_vad_max_frame();
-int rows_wave(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &tb, int64_t n_sig, int64_t Tmax,
-              int power, float *S, int64_t sig_stride, double *vad_e, int64_t frame_len, int64_t nv_max);
+template <typename R>
+int rows_wave(Ctx *c, const R *d_x, const Signals &sg, const Tables<R> &tb, int64_t n_sig, int64_t Tmax,
+              int power, R *S, int64_t sig_stride, double *vad_e, int64_t frame_len, int64_t nv_max);
 template <int MODE>
 int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax);
 int rows_fast(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &tb, int64_t n_sig,

@@ -1,8 +1,8 @@
 #!/bin/bash
-# fp64 chain (16 clips per step): per-kernel times
+# fp64 chain (32 clips per step): per-kernel times
 set -e
 mkdir -p gpurun_out/qb
-timeout -k 10 300 python3 bench.py --dtype f64 --clips 16 --no-cpu-baseline --no-secondary > gpurun_out/qb/b64.json
+timeout -k 10 300 python3 bench.py --dtype f64 --clips 32 --no-cpu-baseline --no-secondary > gpurun_out/qb/b64.json
 python3 - <<'PY'
 import json
 d = json.loads(open("gpurun_out/qb/b64.json").read().strip().splitlines()[-1])
