@@ -1183,14 +1183,17 @@ void k_apply_wave(ApplyArgs<R> a) {
     typedef typename CxOf<R>::type C;
     extern __shared__ __align__(16) unsigned char smem[];
     constexpr int H = 512;
-    constexpr int SLOT = MODE == APPLY_SUBTRACT ? PARK : 0;                          // float2 per wave beside the exchange buffer
+    // binary64 SUBTRACT: four waves' exchange buffers and parked spectra fill the LDS of a CU to the last byte when
+    // the parked spectrum takes exactly its 1025 slots and the signal's noise row is read from memory instead
+    constexpr bool ROW_IN_LDS = !(sizeof(R) == 8 && MODE == APPLY_SUBTRACT);
+    constexpr int SLOT = MODE == APPLY_SUBTRACT ? (sizeof(R) == 8 ? 1025 : PARK) : 0;   // complex slots per wave beside the exchange buffer
     const Tables<R> &tb = a.tb;
     C *bufs = reinterpret_cast<C *>(smem);                                          // [W][WBUF] exchange
     C *slots = bufs + (size_t)W * WBUF;                                              // [W][SLOT] parked spectrum / gain row
     C *twtab = slots + (size_t)W * SLOT;
     R *wtab = reinterpret_cast<R *>(twtab + TWTAB);                           // [1024] first half of the window
     R *ntab = wtab + 1024;                                                        // [512] scale / full-overlap norm
-    R *nrow = ntab + 512;                                                         // [GROW] the signal's noise row (SUBTRACT) / gain row (GAIN)
+    R *nrow_lds = ntab + 512;                                                     // [GROW] the signal's noise row (SUBTRACT) / gain row (GAIN)
     // the wave index as a scalar: the run's bounds, pointers and counters then live in scalar registers
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane0 = threadIdx.x & 63, tid = threadIdx.x;
     // the waves of a workgroup work on one signal (segs_per_sig is a multiple of W) and share its noise / gain row
@@ -1213,7 +1216,8 @@ void k_apply_wave(ApplyArgs<R> a) {
         ntab[i] = iscale / (sq > (R)1e-10 ? sq : (R)1.0);
     }
     if (MODE == APPLY_SUBTRACT || a.row_t_stride == 0)
-        for (int i = tid; i <= 1024; i += W * 64) nrow[i] = row[i];
+        if (ROW_IN_LDS)
+            for (int i = tid; i <= 1024; i += W * 64) nrow_lds[i] = row[i];
     __syncthreads();                                       // the only workgroup barrier: every wave reaches it
 
     if (!have_sig) return;
@@ -1232,7 +1236,8 @@ void k_apply_wave(ApplyArgs<R> a) {
     C *buf = bufs + wave * WBUF;
     R *bufr = reinterpret_cast<R *>(buf);
     C *park = slots + wave * SLOT;
-    R *grow_lds = nrow;
+    const R *nrow = ROW_IN_LDS ? nrow_lds : row;
+    const R *grow_lds = nrow;
     const C *wv = reinterpret_cast<const C *>(wtab);
     const C *nv = reinterpret_cast<const C *>(ntab);
     const C rtw0 = as_c2(tb.rtw)[lane0];
@@ -1752,8 +1757,9 @@ void k_rows_wave(const R *__restrict__ x, Signals sg, Tables<R> tb, int64_t n_si
 static size_t rows_wave_lds(int W, size_t real_bytes) { return ((size_t)W * WBUF * 2 + (size_t)TWTAB * 2 + 1024) * real_bytes; }
 
 static size_t apply_wave_lds(int W, int mode, size_t real_bytes) {
-    return ((size_t)W * WBUF * 2 + (size_t)W * (mode == APPLY_SUBTRACT ? PARK : 0) * 2 + (size_t)TWTAB * 2 +
-            (1024 + 512 + GROW)) * real_bytes;
+    const bool row_in_lds = !(real_bytes == 8 && mode == APPLY_SUBTRACT);
+    const size_t slot = mode == APPLY_SUBTRACT ? (real_bytes == 8 ? 1025 : PARK) : 0;
+    return ((size_t)W * WBUF * 2 + (size_t)W * slot * 2 + (size_t)TWTAB * 2 + (1024 + 512 + (row_in_lds ? GROW : 0))) * real_bytes;
 }
 
 static size_t apply_lds(int W, int mode, int hop) {
@@ -1770,8 +1776,8 @@ static size_t apply_lds(int W, int mode, int hop) {
 template <typename R, int MODE>
 static int apply_wave(Ctx *c, ApplyArgs<R> a, int64_t n_sig, int64_t Tmax) {
     // binary32: eight waves (SUBTRACT, two per SIMD) / four (GAIN, three workgroups per CU); binary64: a wave's
-    // exchange buffer and parked spectrum are 34 KB, three waves (SUBTRACT) / four (GAIN) fill the LDS of a CU
-    constexpr int W = sizeof(R) == 8 ? (MODE == APPLY_SUBTRACT ? 3 : 4) : (MODE == APPLY_SUBTRACT ? 8 : 4);
+    // exchange buffer and parked spectrum are 34 KB: four waves, one per SIMD
+    constexpr int W = sizeof(R) == 8 ? 4 : (MODE == APPLY_SUBTRACT ? 8 : 4);
     constexpr int WAVES_PER_CU = sizeof(R) == 8 ? W : (MODE == APPLY_SUBTRACT ? 8 : 12);
     const int64_t out_hops = Tmax - 1;
     if (out_hops <= 0) return ADN_OK;
