@@ -1020,18 +1020,29 @@ int noise_psd(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const i
     const int F = n_fft / 2 + 1;
     const int64_t Tmax = stft_frames(max_len, n_fft, hop, padded);
     const int64_t Ts = row_stride(Tmax);
-    const size_t nS = (size_t)n_sig * F * Ts;
+    Signals sg{d_off, d_len, n_ch, n_fft, hop, padded};
+    // rows of up to a few thousand frames take the grouped layout (rows written by waves that work alone, read by
+    // the register-resident row select), like the statistics of the Wiener stage
+    const bool grouped = !c->force_generic && (c->ablate & 64) == 0 && rows_wave_ok(sg, n_fft) && Tmax <= select_grouped_limit();
+    const int64_t sig_floats = std::max<int64_t>((int64_t)F * Ts, rows_wave_sig_floats(Tmax));
+    const size_t nS = (size_t)n_sig * sig_floats;
     ADN_TRY(ws_reserve(c, ws_need(nS, sizeof(T)) + ws_need(n_sig, 8) * 2 + ws_need((size_t)n_sig * F, 8) +
-                              select_ws_bytes(n_sig * F, Tmax)));
+                              select_ws_bytes(n_sig * F, Tmax) + APPLY_WS_BYTES));
     T *S = ws_take<T>(c, nS);
     int64_t *Tn = ws_take<int64_t>(c, n_sig);
     unsigned long long *sig_max = ws_take<unsigned long long>(c, n_sig);
     double *P = ws_take<double>(c, (size_t)n_sig * F);
-    Signals sg{d_off, d_len, n_ch, n_fft, hop, padded};
     ADN_HIP(hipMemsetAsync(sig_max, 0, sizeof(unsigned long long) * n_sig, c->stream));
     ADN_LAUNCH(k_frame_counts, dim3((unsigned)ceil_div(n_sig, 256)), dim3(256), 0, c->stream, sg, n_sig, Tn);
-    ADN_TRY(rows_dispatch<T>(c, d_x, sg, tb, n_sig, Ts, 0, S, sig_max));
     SelectArgs sa;
+    if (grouped) {
+        ADN_TRY(rows_wave<T>(c, d_x, sg, tb, n_sig, Tmax, 0, S, sig_floats, nullptr, 0, 0, sig_max));
+        sa.quad_stride = ROWS_GROUP_STRIDE;
+        sa.blk_rows = F;
+        sa.blk_sig_stride = sig_floats;
+    } else {
+        ADN_TRY(rows_dispatch<T>(c, d_x, sg, tb, n_sig, Ts, 0, S, sig_max));
+    }
     sa.n_seg = n_sig * F;
     sa.seg_stride = Ts;
     sa.d_seg_len = Tn;

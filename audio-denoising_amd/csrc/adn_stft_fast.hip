@@ -1603,7 +1603,7 @@ template <typename R, int W, int NCH, bool VADE>
 __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 8 ? 1 : 3, sizeof(R) == 8 ? 1 : 3)))
 void k_rows_wave(const R *__restrict__ x, Signals sg, Tables<R> tb, int64_t n_sig, int64_t runs_per_sig,
                  int groups_per_run, int64_t sig_stride, int power, R *__restrict__ S, R *__restrict__ dummy,
-                 double *__restrict__ vad_e, int64_t frame_len, int64_t nv_max) {
+                 double *__restrict__ vad_e, int64_t frame_len, int64_t nv_max, unsigned long long *__restrict__ sig_max) {
     typedef typename CxOf<R>::type C;
     typedef typename QuadOf<R>::type Q;                    // the four frames of a bin: one store
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1634,6 +1634,7 @@ void k_rows_wave(const R *__restrict__ x, Signals sg, Tables<R> tb, int64_t n_si
     R m0[17], m1[17], m2[17], m3[17];                  // the lane's bins of the group's four frames
 #pragma unroll
     for (int i = 0; i < 17; ++i) m0[i] = m1[i] = m2[i] = m3[i] = (R)0.0;
+    R vmax = 0;                                            // largest value of the run (sig_max: the signal's maximum)
     // voice-activity energies: accA belongs to frame vcur, accB to frame vcur + 1
     double accA = 0.0, accB = 0.0;
     int64_t vcur = -1;
@@ -1716,6 +1717,11 @@ void k_rows_wave(const R *__restrict__ x, Signals sg, Tables<R> tb, int64_t n_si
 #pragma unroll
                 for (int i = 0; i < 17; ++i) p[i] = fast_sqrt(p[i]);
             }
+            if (sig_max != nullptr) {
+                // (bin 512 is lane 0's; the other lanes hold a copy of it, which changes no maximum)
+#pragma unroll
+                for (int i = 0; i < 17; ++i) vmax = fmax(vmax, p[i]);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < 17; ++i) p[i] = (R)0.0;      // frames past the signal's end inside its last group
@@ -1744,6 +1750,10 @@ void k_rows_wave(const R *__restrict__ x, Signals sg, Tables<R> tb, int64_t n_si
             Q *dm = lane == 0 ? dst + 512 : reinterpret_cast<Q *>(dummy) + lane;
             *dm = Q{m0[16], m1[16], m2[16], m3[16]};
         }
+    }
+    if (sig_max != nullptr) {
+        for (int d = 32; d >= 1; d >>= 1) vmax = fmax(vmax, __shfl_xor(vmax, d));
+        if (lane0 == 0) atomicMax(&sig_max[sig], (unsigned long long)key_of((double)vmax));
     }
     if (VADE) {
         // the signal's last run also owns what lies beyond the first hop of the last frame
@@ -1893,7 +1903,8 @@ int64_t rows_wave_vad_max_frame() { return 4 * 4 * 512; }      // the shortest r
 // The caller has reserved APPLY_WS_BYTES of workspace beyond what it took.
 template <typename R>
 int rows_wave(Ctx *c, const R *d_x, const Signals &sg, const Tables<R> &tb, int64_t n_sig, int64_t Tmax,
-              int power, R *S, int64_t sig_stride, double *vad_e, int64_t frame_len, int64_t nv_max) {
+              int power, R *S, int64_t sig_stride, double *vad_e, int64_t frame_len, int64_t nv_max,
+              unsigned long long *sig_max) {
     constexpr int W = 4;
     if (c->ws_used + APPLY_WS_BYTES > c->ws_bytes) {
         set_error("internal: the caller of the rows kernel did not reserve its scratch line");
@@ -1915,15 +1926,15 @@ int rows_wave(Ctx *c, const R *d_x, const Signals &sg, const Tables<R> &tb, int6
                       : (sg.n_ch == 2 ? fast::k_rows_wave<R, W, 2, false> : fast::k_rows_wave<R, W, 1, false>);
     ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ADN_LAUNCH_NAMED("k_rows_wave", kern, dim3((unsigned)wgs), dim3(W * 64), lds, c->stream, d_x, sg, tb, n_sig, runs_per_sig,
-                     (int)gpr, sig_stride, power, S, dummy, vad_e, frame_len, nv_max);
+                     (int)gpr, sig_stride, power, S, dummy, vad_e, frame_len, nv_max, sig_max);
     ADN_HIP(hipGetLastError());
     return ADN_OK;
 }
 
 template int rows_wave<float>(Ctx *, const float *, const Signals &, const Tables<float> &, int64_t, int64_t, int, float *,
-                              int64_t, double *, int64_t, int64_t);
+                              int64_t, double *, int64_t, int64_t, unsigned long long *);
 template int rows_wave<double>(Ctx *, const double *, const Signals &, const Tables<double> &, int64_t, int64_t, int, double *,
-                               int64_t, double *, int64_t, int64_t);
+                               int64_t, double *, int64_t, int64_t, unsigned long long *);
 
 // binary64, n_fft 2048, hop 512: the one-wave-per-run kernels at the reference's precision
 bool apply_wave64_ok(int n_fft, int hop, int st, int sf, int mode) {

@@ -122,7 +122,8 @@ bool rows_wave_ok(const Signals &sg, int n_fft);
 int64_t rows_wave_vad_max_frame();
 template <typename R>
 int rows_wave(Ctx *c, const R *d_x, const Signals &sg, const Tables<R> &tb, int64_t n_sig, int64_t Tmax,
-              int power, R *S, int64_t sig_stride, double *vad_e, int64_t frame_len, int64_t nv_max);
+              int power, R *S, int64_t sig_stride, double *vad_e, int64_t frame_len, int64_t nv_max,
+              unsigned long long *sig_max = nullptr);    // sig_max (may be null): per signal, atomic maximum of the keys of the values
 template <int MODE>
 int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax);
 int rows_fast(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &tb, int64_t n_sig,
