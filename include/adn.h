@@ -14,12 +14,19 @@
  *    pointers prefixed h_ are host pointers.  The caller owns every buffer.
  *  - Work is enqueued on the context's stream (adn_set_stream; default: the
  *    null stream) and is asynchronous with respect to the host; no entry point
- *    synchronises unless its comment says so.
+ *    synchronises unless its comment says so.  Two one-time exceptions: the first STFT
+ *    call of a context for a given (n_fft, precision) builds its window / twiddle tables
+ *    with a blocking allocation and copy, and a call that has to grow the workspace
+ *    waits for the stream before it frees the old one.
  *  - A context owns a device workspace that grows on demand (hipMalloc only on
  *    growth) and is re-used by later calls, so a context must not be used from
  *    two host threads at once.  Calls on one context are ordered by its stream.
  *  - _f32 entry points compute in IEEE binary32, _f64 in binary64 (the
- *    reference's own precision).  Order statistics are exact in either mode.
+ *    reference's own precision).  Order statistics are exact in either mode.  Where a
+ *    binary32 kernel replaces a division or square root by the hardware's approximate
+ *    reciprocal / square root (1 ulp: the soft threshold of mono wavelet blocks, the
+ *    magnitudes and phases of the spectral subtraction), its result is not that of a
+ *    correctly rounded binary32 restatement; the _f64 entry points use exact operations.
  */
 #ifndef ADN_H
 #define ADN_H
@@ -236,7 +243,9 @@ int adn_band_summary_f64(adn_ctx *ctx, const double *d_x, int64_t n_sig, const i
  * last one, bins in no band get zero masks.  kernel_size odd, <= 31.
  * d_yh / d_yp: outputs of adn_istft_out_samples(len[s], n_fft, hop) samples at d_y_off[s].
  * d_stats (may be NULL): 5 doubles per signal: harmonic RMS, percussive RMS, RMS of the mono
- * input, max|y| before scaling, number of transient frames. */
+ * input, max|y| before scaling, number of transient frames.
+ * Synchronises: every call uploads its per-bin band table from host memory and waits for the
+ * stream (hipStreamSynchronize) before it enqueues its kernels. */
 enum { ADN_MASK_SOFT = 0, ADN_MASK_HARD = 1, ADN_MASK_BINARY = 2 };
 int adn_hpss_f32(adn_ctx *ctx, const float *d_x, int64_t n_sig, const int64_t *d_off,
                  const int64_t *d_len, int64_t max_len, int n_ch, int sample_rate, int n_fft, int hop,
