@@ -1735,7 +1735,7 @@ void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_o
     K res = 0;
     uint32_t lo_cnt = 0, hi_cnt = (uint32_t)n;
     K ck[SEL_CK];
-    bool compact = false;
+    bool compact = false, unique = false;
     int b = bits - 1;
     for (; b >= 0; --b) {
         const K trial = res | ((K)1 << b);
@@ -1746,10 +1746,26 @@ void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_o
         } else {
             hi_cnt = cnt;
         }
+        if (b > 0 && hi_cnt - lo_cnt == 1) {                // ONE key shares the prefix: it is the answer
+            unique = true;
+            break;
+        }
         if (KPL > SEL_CK && b >= 3 && hi_cnt - lo_cnt <= SEL_CK * 64) {
             compact = true;
             break;
         }
+    }
+    if (unique) {
+        const K span = (K)1 << b;                           // the key in [res, res + span)
+        K mn = KEY_MAX;
+#pragma unroll
+        for (int i = 0; i <= KPL; ++i) mn = (key[i] - res < span && key[i] < mn) ? key[i] : mn;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const K o = __shfl_xor(mn, d);
+            mn = o < mn ? o : mn;
+        }
+        res = mn;
     }
     if (compact) {
         __shared__ K cbuf_all[4][SEL_CK * 64];
@@ -1770,10 +1786,29 @@ void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_o
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int i = 0; i < SEL_CK; ++i) ck[i] = lane + 64 * i < (int)base ? cbuf[lane + 64 * i] : KEY_MAX;
+        uint32_t lo2 = lo_cnt;
         for (--b; b >= 0; --b) {
             const K trial = res | ((K)1 << b);
             const uint32_t cnt = lo_cnt + count_below<K, SEL_CK>(ck, trial);
-            if (cnt <= r0) res = trial;
+            if (cnt <= r0) {
+                res = trial;
+                lo2 = cnt;
+            } else {
+                hi_cnt = cnt;
+            }
+            if (b > 0 && hi_cnt - lo2 == 1) {               // ONE candidate left
+                const K span = (K)1 << b;
+                K mn = KEY_MAX;
+#pragma unroll
+                for (int i = 0; i < SEL_CK; ++i) mn = (ck[i] - res < span && ck[i] < mn) ? ck[i] : mn;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const K o = __shfl_xor(mn, d);
+                    mn = o < mn ? o : mn;
+                }
+                res = mn;
+                break;
+            }
         }
     }
     K k0 = res, k1 = res;
