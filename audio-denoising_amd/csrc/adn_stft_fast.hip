@@ -1835,7 +1835,7 @@ static int apply_wave(Ctx *c, ApplyArgs<R> a, int64_t n_sig, int64_t Tmax) {
 
 template <int MODE>
 int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
-    if (a.sg.hop == 512 && (c->ablate & ~16) == 0 && (MODE == APPLY_GAIN || (a.sf == 5 && a.st == fast::FAST_ST)))
+    if (a.sg.hop == 512 && (c->ablate & 15) == 0 && (MODE == APPLY_GAIN || (a.sf == 5 && a.st == fast::FAST_ST)))
         return apply_wave<float, MODE>(c, a, n_sig, Tmax);
     // 8 waves per workgroup.  4-wave workgroups, two per CU, measured the same in GAIN mode (the
     // overlap-add path handles W = 4 too) and do not fit LDS twice in SUBTRACT mode.

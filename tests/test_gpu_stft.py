@@ -273,3 +273,33 @@ def test_wiener_long_rows(dt):
     want2, _ = orc.wiener(x, SR, vad_guided=False)
     y2, _ = e.wiener(dev(x, dt), [n], SR, vad_guided=False)
     chk(host(y2), want2)
+
+
+def test_statistics_paths_agree():
+    """The Wiener stage and the noise profile on the grouped-rows path (rows written by waves that work alone,
+    register-resident select, voice-activity energies added up by the rows kernel) against the transposed-rows
+    path with its separate voice-activity pass (diagnostic option bits 64 / 128 switch the new pieces off):
+    binary32 bit for bit (both paths transform a frame with the same arithmetic), binary64 to 1e-12 (the
+    transposed binary64 rows come from the shape-generic transform)."""
+    e = engine()
+    SR48 = 48000
+    n = 7 * SR48 + 123
+    for dt, tol in ((torch.float32, 0.0), (torch.float64, 1e-12)):
+        x = dev(synth.noisy_speech(n, SR48, 42, 930), dt)
+        xs = torch.cat([x, x[: 5 * SR48 + 77]])
+        lens = [n, 5 * SR48 + 77]
+        res = {}
+        for name, bits in (("grouped", 0), ("vad_apart", 128), ("transposed", 64)):
+            e.lib.adn_set_option(e._h, 2, bits)
+            try:
+                y, l, g = e.wiener(xs, lens, SR48, want_gain=True)
+                p = e.noise_psd(xs, lens)
+            finally:
+                e.lib.adn_set_option(e._h, 2, 0)
+            res[name] = (y.clone(), g.clone(), p.clone())
+        for name in ("vad_apart", "transposed"):
+            for a, b in zip(res["grouped"], res[name]):
+                if tol == 0.0 or name == "vad_apart":
+                    assert torch.equal(a, b), (str(dt), name)
+                else:
+                    assert float((a - b).abs().max()) <= tol, (str(dt), name)
