@@ -204,7 +204,7 @@ def test_frame_count_edges_all_kernels(hop, n_ch):
     shape-generic kernels forced, and in fp64."""
     e = engine()
     n_fft = 2048
-    counts = [5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 23, 24, 25, 26, 31, 32, 33, 34, 47, 48, 49, 97, 200]
+    counts = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15, 16, 17, 18, 23, 24, 25, 26, 31, 32, 33, 34, 47, 48, 49, 97, 200]
     rng = np.random.default_rng(hop + n_ch)
     lens = [(t - 1) * hop + int(rng.integers(0, hop)) for t in counts]
     lens = [max(n, n_fft) for n in lens]
@@ -284,16 +284,21 @@ def test_statistics_paths_agree():
     e = engine()
     SR48 = 48000
     n = 7 * SR48 + 123
-    for dt, tol in ((torch.float32, 0.0), (torch.float64, 1e-12)):
-        x = dev(synth.noisy_speech(n, SR48, 42, 930), dt)
-        xs = torch.cat([x, x[: 5 * SR48 + 77]])
+    for dt, tol, n_ch in ((torch.float32, 0.0, 1), (torch.float64, 1e-12, 1), (torch.float32, 0.0, 2), (torch.float64, 1e-12, 2)):
+        # two signals, the second at an odd offset (its frames take the staged loader); stereo: interleaved channels
+        if n_ch == 1:
+            x = dev(synth.noisy_speech(n, SR48, 42, 930), dt)
+            xs = torch.cat([x, x[: 5 * SR48 + 77]])
+        else:
+            x = dev(synth.stereo_noisy_speech(n, SR48, 42, 931), dt)
+            xs = torch.cat([x.reshape(-1), x[: 5 * SR48 + 77].reshape(-1)])
         lens = [n, 5 * SR48 + 77]
         res = {}
         for name, bits in (("grouped", 0), ("vad_apart", 128), ("transposed", 64)):
             e.lib.adn_set_option(e._h, 2, bits)
             try:
-                y, l, g = e.wiener(xs, lens, SR48, want_gain=True)
-                p = e.noise_psd(xs, lens)
+                y, l, g = e.wiener(xs, lens, SR48, n_ch=n_ch, want_gain=True)
+                p = e.noise_psd(xs, lens, n_ch=n_ch)
             finally:
                 e.lib.adn_set_option(e._h, 2, 0)
             res[name] = (y.clone(), g.clone(), p.clone())
