@@ -194,3 +194,47 @@ def test_chunk_plans():
     s0, s1, keep = ck.stft_chunk_window(500, frames - 1, frames, 320333)
     assert s0 == 498 * 512 and s1 == 320333 and keep == 1024
     assert ck.stft_chunk_window(500, 510, frames, 320333, reach=0) == (499 * 512, 511 * 512 + 2048, 512)
+
+
+def _spread_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(REPO, "audio-denoising_amd"))
+    from adn_hip import spread
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 5 * 512 * 7 + 301
+        full = torch.arange(n, dtype=torch.float64) * 0.5
+        ranges = spread.partition(n, world)
+        s, e = ranges[rank]
+        sig = spread.SpreadSignal(full[s:e].clone(), ranges, rank)
+
+        def wants_of(r):            # halos of 700 samples round rank r's range, wrapping round the signal, + a far piece
+            a, b = ranges[r]
+            w = []
+            if a - 700 < 0:
+                w.append((a - 700 + n, n))
+            w.append((max(a - 700, 0), min(b + 700, n)))
+            if b + 700 > n:
+                w.append((0, b + 700 - n))
+            w.append(((r * 1234) % (n - 50), (r * 1234) % (n - 50) + 50))
+            return w
+
+        got = sig.fetch(wants_of)
+        ok = all(torch.equal(g, full[a:b]) for g, (a, b) in zip(got, wants_of(rank)))
+        np.savez(os.path.join(out_dir, "s%d.npz" % rank), ok=ok, ranges=np.array(ranges))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_three_rank_range_fetch(tmp_path):
+    """A signal spread over three ranks: every rank fetches halos (wrapping round the ends) and a far interval
+    from the others, point to point, after the same plan."""
+    world, port = 3, 33500 + (os.getpid() % 2000)
+    mp.spawn(_spread_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for k in range(world):
+        r = np.load(str(tmp_path / ("s%d.npz" % k)))
+        assert bool(r["ok"])
+        rg = r["ranges"]
+        assert rg[0][0] == 0 and rg[-1][1] == 5 * 512 * 7 + 301 and all(rg[i][1] == rg[i + 1][0] for i in range(world - 1))
+        assert all(int(a) % 512 == 0 for a, _ in rg)
