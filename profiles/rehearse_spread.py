@@ -15,9 +15,15 @@ from adn_hip import Engine, spread
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 100.0
 dt = torch.float32 if (len(sys.argv) > 2 and sys.argv[2] == "f32") else torch.float64
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo")
-torch.cuda.set_device(0)
-e = Engine(0)
+local = int(os.environ.get("LOCAL_RANK", "0"))
+if torch.cuda.device_count() >= world:                         # one GPU per rank: RCCL, halos device to device
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    e, backend = Engine(local), "nccl, one GPU per rank"
+else:                                                           # fewer GPUs than ranks: share GPU 0, gloo
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    e, backend = Engine(0), "gloo, one GPU"
 SR = 48000
 n = int(seconds * SR) // 40 * 40                                # ten blocks, each a multiple of 2^level
 x = e.synth_noisy_speech(n, SR, stream=77).to(dt)               # every rank can make the whole recording: cheap here
@@ -44,6 +50,6 @@ res = {"rank": rank, "range": [s, t],
 out = [None] * world
 dist.all_gather_object(out, res)
 if rank == 0:
-    print(json.dumps({"workload": "one %.0f s 48 kHz mono recording, %s, spread over %d ranks (gloo, one GPU)" % (seconds, str(dt), world),
+    print(json.dumps({"workload": "one %.0f s 48 kHz mono recording, %s, spread over %d ranks (%s)" % (seconds, str(dt), world, backend),
                       "samples": n, "spread_ms": spread_ms, "ranks": out}))
 dist.destroy_process_group()
