@@ -1791,9 +1791,9 @@ static int apply_wave(Ctx *c, ApplyArgs<R> a, int64_t n_sig, int64_t Tmax) {
     constexpr int WAVES_PER_CU = sizeof(R) == 8 ? W : (MODE == APPLY_SUBTRACT ? 8 : 12);
     const int64_t out_hops = Tmax - 1;
     if (out_hops <= 0) return ADN_OK;
-    // two rounds of runs over the waves a full chip holds; a run pays three warm-up frames (and two
+    // one round of runs over the waves a full chip holds (measured against two: -3 %); a run pays three warm-up frames (and two
     // analysis-only frames in SUBTRACT mode), so it is not made shorter than 16 hops
-    int64_t run = ceil_div(n_sig * out_hops, (int64_t)c->num_cus * WAVES_PER_CU * 2);
+    int64_t run = ceil_div(n_sig * out_hops, (int64_t)c->num_cus * WAVES_PER_CU * 1);
     run = run < 16 ? 16 : (run > 1024 ? 1024 : run);
     a.seg_hops = (int)run;
     a.segs_per_sig = ceil_div(out_hops, run);
