@@ -106,17 +106,30 @@ struct Cap {
         for (int l = 1; l <= TL; ++l) ic[l] = (ic[l - 1] + F) / 2 + 3;
         gc[TL] = ic[TL];
         for (int l = TL - 1; l >= 0; --l) gc[l] = 2 * (gc[l + 1] - 1) + F + 3;
+        // Level 0 (the samples) is dead once level 1 exists, and the arrays of all deeper levels together are
+        // shorter than it: they take its place, which lets a third more tiles share a CU.
+        int deeper = 0;
+        for (int l = 2; l <= TL; ++l) deeper += ((gc[l] + 3) & ~1) + ((ic[l] + 3) & ~1);
+        const int sizeA0 = (gc[0] + 3) & ~1;
+        const bool alias = TL >= 2 && deeper <= sizeA0;
         int off = 0;
-        for (int l = 0; l <= TL; ++l) {
-            offA[l] = off;
-            off += (gc[l] + 3) & ~1;    // +1 for the alignment shift, rounded to even
-        }
+        offA[0] = 0;
+        off += sizeA0;
         offD[0] = off;
-        for (int l = 1; l <= TL; ++l) {
-            offD[l] = off;
-            off += (ic[l] + 3) & ~1;
+        if (TL >= 1) {
+            offA[1] = off;
+            off += (gc[1] + 3) & ~1;    // +1 for the alignment shift, rounded to even
+            offD[1] = off;
+            off += (ic[1] + 3) & ~1;
         }
-        total = off;
+        int o2 = alias ? 0 : off;
+        for (int l = 2; l <= TL; ++l) {
+            offA[l] = o2;
+            o2 += (gc[l] + 3) & ~1;
+            offD[l] = o2;
+            o2 += (ic[l] + 3) & ~1;
+        }
+        total = alias ? off : o2;
     }
 };
 
@@ -253,24 +266,7 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
         if (interior) {
             const int off_lo = 2 * dr.s + F / 2 - sr.s - F + 1;   // window start of output 0
             const int dI = ir.s - dr.s;
-            for (int i = tid; i < dr.c; i += THREADS) {
-                const V2 *w = reinterpret_cast<const V2 *>(src + off_lo + 2 * i);
-                // window element t pairs with tap F-1-t; pywt's summation order (tap 0 first);
-                // both filters advance together in one two-wide fused multiply-add per tap
-                T v[F];
-#pragma unroll
-                for (int t = 0; t < F / 2; ++t) {
-                    const V2 q = w[t];
-                    v[2 * t] = q.x;
-                    v[2 * t + 1] = q.y;
-                }
-                P acc = {(T)0, (T)0};
-#pragma unroll
-                for (int j = 0; j < F; ++j) {
-                    const P vv = {v[F - 1 - j], v[F - 1 - j]};
-                    acc = __builtin_elementwise_fma(tp.hg[j], vv, acc);
-                }
-                const T sa = acc.x, sd = acc.y;
+            auto put = [&](int i, T sa, T sd) {
                 dA[i] = sa;
                 if (MODE == MODE_APPLY) {
                     // shrink on the way into LDS; a tile counts the zeroed coefficients it owns
@@ -284,6 +280,31 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
                     const int k = dr.s + i;
                     if (k >= p.own_lo[1] && k < p.own_hi[1]) d1_out[b * d1_stride + k] = sd;
                 }
+            };
+            // A thread takes two neighbouring outputs: their windows share all but two elements, so the pair
+            // costs F / 2 + 1 eight-byte LDS reads instead of F.  (The read past the window of a last, single
+            // output stays inside the LDS arrays and is not used.)
+            for (int i = 2 * tid; i < dr.c; i += 2 * THREADS) {
+                const V2 *w = reinterpret_cast<const V2 *>(src + off_lo + 2 * i);
+                // window element t pairs with tap F-1-t; pywt's summation order (tap 0 first);
+                // both filters advance together in one two-wide fused multiply-add per tap
+                T v[F + 2];
+#pragma unroll
+                for (int t = 0; t < F / 2 + 1; ++t) {
+                    const V2 q = w[t];
+                    v[2 * t] = q.x;
+                    v[2 * t + 1] = q.y;
+                }
+                P acc0 = {(T)0, (T)0}, acc1 = {(T)0, (T)0};
+#pragma unroll
+                for (int j = 0; j < F; ++j) {
+                    const P v0 = {v[F - 1 - j], v[F - 1 - j]};
+                    const P v1 = {v[F + 1 - j], v[F + 1 - j]};
+                    acc0 = __builtin_elementwise_fma(tp.hg[j], v0, acc0);
+                    acc1 = __builtin_elementwise_fma(tp.hg[j], v1, acc1);
+                }
+                put(i, acc0.x, acc0.y);
+                if (i + 1 < dr.c) put(i + 1, acc1.x, acc1.y);
             }
         } else {
             for (int i = tid; i < dr.c; i += THREADS) {
@@ -353,28 +374,7 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
                                 ((reinterpret_cast<uintptr_t>(out) & (2 * sizeof(T) - 1)) == 0);
         if (interior) {
             const int m0 = orr.s >> 1, m1 = (orr.s + orr.c - 1) >> 1;
-            for (int m = m0 + tid; m <= m1; m += THREADS) {
-                if (ablate & 8) {
-                    const int io = 2 * m - orr.s;
-                    if (io >= 0) out[io] = ra[(m - ir.s) & 1023];
-                    if (io + 1 < orr.c) out[io + 1] = rd[(m - ir.s) & 1023];
-                    continue;
-                }
-                const int lb = m - F / 4 - ir.s;
-                T a[F / 2 + 1], d[F / 2 + 1];
-#pragma unroll
-                for (int q = 0; q <= F / 2; ++q) {
-                    a[q] = ra[lb + q];
-                    d[q] = rd[lb + q];
-                }
-                P acc = {(T)0, (T)0};           // (y[2m], y[2m+1])
-#pragma unroll
-                for (int q = 0; q < F / 2; ++q) {
-                    const P av = {a[F / 2 - 1 - q], a[F / 2 - q]};
-                    const P dv = {d[F / 2 - 1 - q], d[F / 2 - q]};
-                    acc = __builtin_elementwise_fma(tp.rlp[q], av, acc);
-                    acc = __builtin_elementwise_fma(tp.rhp[q], dv, acc);
-                }
+            auto put = [&](int m, P acc) {
                 const int io = 2 * m - orr.s;
                 if (l == 1 && pair_store && io >= 0 && io + 1 < orr.c) {
                     V2 o2;
@@ -382,9 +382,46 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
                     o2.y = acc.y;
                     *reinterpret_cast<V2 *>(out + io) = o2;
                 } else {
-                    if (io >= 0) out[io] = acc.x;
-                    if (io + 1 < orr.c) out[io + 1] = acc.y;
+                    if (io >= 0 && io < orr.c) out[io] = acc.x;
+                    if (io + 1 >= 0 && io + 1 < orr.c) out[io + 1] = acc.y;
                 }
+            };
+            // A thread takes two neighbouring output pairs m, m + 1: they share all but one coefficient of each
+            // band.  The first pair starts at an even index of the coefficient arrays (one pair earlier than m0
+            // if need be: that pair's outputs lie before the range and are dropped), so that the F / 2 + 2
+            // coefficients of a band are F / 4 + 1 eight-byte LDS reads.  Reads one element past either end of the
+            // needed coefficients stay inside the LDS arrays and feed dropped outputs only.
+            const int ma = m0 - ((m0 - F / 4 - ir.s) & 1);
+            for (int m = ma + 2 * tid; m <= m1; m += 2 * THREADS) {
+                if (ablate & 8) {
+                    const int io = 2 * m - orr.s;
+                    if (io >= 0) out[io] = ra[(m - ir.s) & 1023];
+                    if (io + 1 < orr.c) out[io + 1] = rd[(m - ir.s) & 1023];
+                    continue;
+                }
+                const int lb = m - F / 4 - ir.s;
+                const V2 *ra2 = reinterpret_cast<const V2 *>(ra + lb), *rd2 = reinterpret_cast<const V2 *>(rd + lb);
+                T a[F / 2 + 2], d[F / 2 + 2];
+#pragma unroll
+                for (int q = 0; q < F / 4 + 1; ++q) {
+                    const V2 qa = ra2[q], qd = rd2[q];
+                    a[2 * q] = qa.x;
+                    a[2 * q + 1] = qa.y;
+                    d[2 * q] = qd.x;
+                    d[2 * q + 1] = qd.y;
+                }
+                P acc0 = {(T)0, (T)0}, acc1 = {(T)0, (T)0};           // (y[2m], y[2m+1]), (y[2m+2], y[2m+3])
+#pragma unroll
+                for (int q = 0; q < F / 2; ++q) {
+                    const P av0 = {a[F / 2 - 1 - q], a[F / 2 - q]}, av1 = {a[F / 2 - q], a[F / 2 + 1 - q]};
+                    const P dv0 = {d[F / 2 - 1 - q], d[F / 2 - q]}, dv1 = {d[F / 2 - q], d[F / 2 + 1 - q]};
+                    acc0 = __builtin_elementwise_fma(tp.rlp[q], av0, acc0);
+                    acc0 = __builtin_elementwise_fma(tp.rhp[q], dv0, acc0);
+                    acc1 = __builtin_elementwise_fma(tp.rlp[q], av1, acc1);
+                    acc1 = __builtin_elementwise_fma(tp.rhp[q], dv1, acc1);
+                }
+                put(m, acc0);
+                if (m + 1 <= m1) put(m + 1, acc1);
             }
         } else {
             for (int i = tid; i < orr.c; i += THREADS) {
