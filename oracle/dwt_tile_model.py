@@ -1,6 +1,6 @@
 """Index model of the fused DWT tile kernels (TEST INFRASTRUCTURE, numpy).
 
-The HIP tile kernels of csrc/adn_dwt_fused.hip keep, for every in-tile level, a
+The HIP tile kernels of csrc/adn_dwt_tiles.hpp keep, for every in-tile level, a
 CANONICAL CONTIGUOUS RANGE (start s, count c, indices taken modulo the level length)
 of the approximation / detail arrays in LDS.  This model executes exactly the same
 plan and index arithmetic on numpy arrays so that the range planning, the interior
