@@ -1587,7 +1587,7 @@ template <> struct Quad4<double> { typedef double4 type; };
 // T: binary32 (keys of 32 bits, three waves per SIMD up to 96 keys per lane) or binary64 (64-bit keys: twice the registers)
 template <typename T, int XF, bool MASKED, int KPL>
 __global__ __launch_bounds__(256)
-__attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? (KPL <= 96 ? 2 : 1) : (KPL <= 96 ? 3 : 2))))
+__attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? (KPL <= 96 ? 2 : 1) : (KPL <= 88 ? 4 : (KPL <= 96 ? 3 : 2)))))
 void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_off,
                                                      int64_t seg_stride, const int64_t *__restrict__ seg_len,
                                                      int64_t len_div, int64_t uniform_len, int64_t n_seg, int mode,
@@ -1849,6 +1849,7 @@ static int launch_select_wave(Ctx *c, const T *d_vals, const SelectArgs &a) {
     if (a.max_len <= 8 * 64) ADN_SEL_WAVE(8);
     else if (a.max_len <= 24 * 64) ADN_SEL_WAVE(24);
     else if (a.max_len <= 48 * 64) ADN_SEL_WAVE(48);
+    else if (a.max_len <= 88 * 64 && sizeof(T) == 4) ADN_SEL_WAVE(88);     // binary32: four waves per SIMD still
     else if (a.max_len <= 96 * 64) ADN_SEL_WAVE(96);
     else ADN_SEL_WAVE(128);
 #undef ADN_SEL_WAVE
