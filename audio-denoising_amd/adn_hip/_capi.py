@@ -30,6 +30,7 @@ _PLAIN = {
     "adn_set_option": (_i, [_vp, _i, _i]),
     "adn_workspace_bytes": (_i64, [_vp]),
     "adn_kernel_times": (_i64, [_vp, C.c_char_p, _i64]),
+    "adn_kernel_timing_only": (_i, [_vp, C.c_char_p]),
     "adn_select_resolve": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "adn_wavelet_denoise_noalloc_f32": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _i, _i, _i,
                                              _vp, _vp, _vp]),

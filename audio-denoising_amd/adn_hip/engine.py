@@ -75,8 +75,10 @@ class Engine:
         per-block fallback selection (independent of force_generic)."""
         self._check(self.lib.adn_set_option(self._h, 3, int(bool(on))))
 
-    def kernel_timing(self, on=True):
-        """Record HIP events on the library's stream around every kernel launch."""
+    def kernel_timing(self, on=True, only=None):
+        """Record HIP events on the library's stream around every kernel launch, or around the
+        launches of the one site called `only` (a name as kernel_times() reports it)."""
+        self._check(self.lib.adn_kernel_timing_only(self._h, only.encode() if only else None))
         self._check(self.lib.adn_set_option(self._h, 4, int(bool(on))))
 
     def kernel_times(self):

@@ -169,6 +169,12 @@ int adn_set_option(adn_ctx *c, int option, int value) {
     return ADN_OK;
 }
 
+int adn_kernel_timing_only(adn_ctx *c, const char *name) {
+    ADN_REQUIRE(c != nullptr, "ctx is null");
+    c->ktime_only = name ? name : "";
+    return ADN_OK;
+}
+
 int64_t adn_kernel_times(adn_ctx *c, char *buf, int64_t cap) {
     if (!c || !buf || cap < 1) return -1;
     adn::DeviceGuard dg(c->device);

@@ -69,6 +69,7 @@ struct Ctx {
     int ablate = 0;               // diagnostics: stages the fused STFT kernel skips (timing only)
     bool ktime = false;           // ADN_OPT_KERNEL_TIMING: event pairs around the launches
     std::vector<KernelRec> krecs; // launches timed since the option was set / the last report
+    std::string ktime_only;       // adn_kernel_timing_only: the one launch site that is timed ("" = all)
 };
 
 void drop_kernel_records(Ctx *c);
@@ -79,6 +80,7 @@ struct KScope {
     int idx = -1;
     KScope(Ctx *ctx, const char *name) : c(ctx) {
         if (!c->ktime || c->ws_fixed) return;      // creating events allocates: never on the path that allocates nothing
+        if (!c->ktime_only.empty() && c->ktime_only != name) return;
         KernelRec r{name, nullptr, nullptr};
         if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
         (void)hipEventRecord(r.start, c->stream);

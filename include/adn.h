@@ -83,6 +83,11 @@ int adn_set_option(adn_ctx *ctx, int option, int value);
  * NUL-terminated, into buf and forgets the records.  Returns the text length, -1 on failure, or
  * minus the capacity needed when cap is too small (records are dropped then too). */
 int64_t adn_kernel_times(adn_ctx *ctx, char *buf, int64_t cap);
+/* Measurement aid (no counterpart in the reference): while kernel timing is on, only launches of the
+ * site called `name` (as adn_kernel_times() prints it) get their event pair; NULL or "" = every launch.
+ * An event pair is a marker the GPU's command processor handles between two kernels: around every
+ * launch of a chain of twenty kernels they cost a few percent, around one kernel nothing measurable. */
+int adn_kernel_timing_only(adn_ctx *ctx, const char *name);
 /* Bytes of device workspace currently held by the context. */
 int64_t adn_workspace_bytes(adn_ctx *ctx);
 
