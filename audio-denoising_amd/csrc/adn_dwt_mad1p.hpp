@@ -33,7 +33,9 @@
 template <typename T>
 struct M1 {
     using K = typename KeyT<T>::type;
-    static constexpr int S = 16384;                // sample keys per block (LDS resident: 64 / 128 KB)
+    // sample keys per block, LDS resident.  binary32: 15 per thread = 60 KB, so that with the two histograms two
+    // sampling workgroups share a CU; binary64: 128 KB
+    static constexpr int S = sizeof(T) == 4 ? 15360 : 16384;
     static constexpr double FRAC_M = 0.05;         // list capacities as fractions of the block: the brackets hold
     static constexpr double FRAC_A = 0.13;         // ~3.5 % and ~9 % of a Gaussian block
 };
@@ -230,8 +232,7 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_sample(const T *__restrict__ 
         for (int u = 0; u < PER; ++u) {
             const int j = tid + M1_THREADS * u;
             const int run = j / M1_RUN, w = j % M1_RUN;
-            // centre of run r: (r + 1/2) n / NRUN (n < 2^31, so the product fits 64 bits)
-            int64_t i = (int64_t)(((uint64_t)(2 * run + 1) * (uint64_t)n) / (uint64_t)(2 * NRUN)) - M1_RUN / 2 + w;
+            int64_t i = sample_run_start(n, NRUN, M1_RUN, run) + w;       // (n < 2^31: the products fit 64 bits)
             i = i < 0 ? 0 : (i < n ? i : n - 1);
             v0[u] = in[2 * i];
             v1[u] = in[2 * i + 1];

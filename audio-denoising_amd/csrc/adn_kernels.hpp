@@ -4,6 +4,21 @@
 
 namespace adn {
 
+// First element of sample run `run` of `nrun` runs of `len` consecutive elements over n elements (n >= nrun * len):
+// the run lies in its own stratum [run n / nrun, (run + 1) n / nrun) at a position that a hash of the run index
+// picks.  Evenly spaced runs would sample a periodic signal at one phase whenever n / nrun is close to a multiple
+// of the period, and brackets taken from such a sample miss.
+__host__ __device__ inline long long sample_run_start(long long n, int nrun, int len, int run) {
+    const long long a = (long long)(((unsigned long long)run * (unsigned long long)n) / (unsigned long long)nrun);
+    const long long b = (long long)(((unsigned long long)(run + 1) * (unsigned long long)n) / (unsigned long long)nrun);
+    const long long room = b - a - len;
+    unsigned int h = (unsigned int)run * 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA77u;
+    h ^= h >> 13;
+    return a + (room > 0 ? (long long)(((unsigned long long)h * (unsigned long long)(room + 1)) >> 32) : 0);
+}
+
 // ------------------------------------------------ segmented order statistics
 enum { SEL_MEDIAN = 0, SEL_PERCENTILE = 1, SEL_PERCENTILE_DB20 = 2 };
 enum { XF_NONE = 0, XF_ABSDEV = 1 };

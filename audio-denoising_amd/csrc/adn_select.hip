@@ -995,7 +995,7 @@ __global__ __launch_bounds__(SAMPLE_THREADS) void k_big_sample(const T *__restri
         for (int u = 0; u < PER; ++u) {
             const int j = tid + SAMPLE_THREADS * u;
             const int run = j / RUN, w = j % RUN;
-            int64_t i = (int64_t)(((double)run + 0.5) * (double)n / (double)NRUN) - RUN / 2 + w;
+            int64_t i = sample_run_start(n, NRUN, RUN, run) + w;
             i = i < 0 ? 0 : (i < n ? i : n - 1);
             xs[u] = v[i];
         }
