@@ -522,8 +522,8 @@ static size_t mad_ws_bytes(int64_t n_blocks, int64_t max_seg) {
            2 * select_ws_bytes(n_blocks, max_seg);
 }
 
-#include "adn_dwt_tiles.hpp"
 #include "adn_dwt_mad1p.hpp"
+#include "adn_dwt_tiles.hpp"
 
 template <typename T, int NCH>
 static int channel_denoise(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_frames,

@@ -71,6 +71,58 @@ __device__ __forceinline__ typename KeyT<T>::type m1_key(T x) {
     return x != x ? ~(K)0 : key_of(x);
 }
 
+// Where the coefficients come from.  A source knows how many coefficients a block of `frames` frames
+// has and forms any one of them from the block's samples; S is the size of the bracket sample and
+// FRAC_M / FRAC_A the candidate-list capacities (fractions of a block) that go with it: the brackets
+// of a Gaussian block hold ~3.5 % and ~9 % of it for a 16 K sample, ~7 % and ~19 % for a 4 K sample.
+template <typename T>
+struct SrcStereo {                 // d = w0 * left + w1 * right, one coefficient per frame
+    static constexpr bool STEREO = true;
+    static constexpr int S = M1<T>::S, SAMPLE_THREADS = M1_THREADS;
+    static constexpr double FRAC_M = M1<T>::FRAC_M, FRAC_A = M1<T>::FRAC_A;
+    T w0, w1;
+    __host__ __device__ static int64_t count(int64_t frames) { return frames; }
+    __device__ __forceinline__ T at(const T *__restrict__ in, int64_t frames, int64_t i) const {
+        return m1_d1(w0, w1, in[2 * i], in[2 * i + 1]);
+    }
+};
+// Finest detail band of a mono block, periodization: d[k] = sum_j g[j] xe[(2 k + F/2 - j) mod M], M = frames
+// rounded up to even, xe = the block with its last sample repeated when frames is odd.  Fused
+// multiply-adds in tap order from zero: the operation sequence of the tile kernels, so that every
+// kernel forms the same bits for a coefficient.
+template <typename T, int F_, int S_>
+struct SrcMono {
+    static constexpr bool STEREO = false;
+    static constexpr int F = F_, S = S_;
+    static constexpr int SAMPLE_THREADS = S_ <= 4096 ? 256 : M1_THREADS;     // a small sample: small workgroups, cheap barriers
+    static constexpr double FRAC_M = S_ <= 4096 ? 0.10 : (S_ <= 8192 ? 0.075 : 0.05);
+    static constexpr double FRAC_A = S_ <= 4096 ? 0.25 : (S_ <= 8192 ? 0.19 : 0.13);
+    T g[F_];
+    __host__ __device__ static int64_t count(int64_t frames) { return (frames + 1) >> 1; }
+    // the F samples under the taps of coefficient k (v[j] meets tap j): independent loads
+    __device__ __forceinline__ void window(const T *__restrict__ in, int64_t frames, int64_t k, T (&v)[F_]) const {
+        const int n = (int)frames, M = n + (n & 1);
+        const int idx0 = (int)((2 * k + F / 2) % M);
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+            int idx = idx0 - j;
+            while (idx < 0) idx += M;                // F/2 / M + 1 rounds at most
+            v[j] = in[idx < n ? idx : n - 1];
+        }
+    }
+    __device__ __forceinline__ T eval(const T (&v)[F_]) const {
+        T sd = 0;
+#pragma unroll
+        for (int j = 0; j < F; ++j) sd = fma(g[j], v[j], sd);
+        return sd;
+    }
+    __device__ __forceinline__ T at(const T *__restrict__ in, int64_t frames, int64_t k) const {
+        T v[F_];
+        window(in, frames, k, v);
+        return eval(v);
+    }
+};
+
 // Histogram update of a wave: when every active lane holds the same digit (constant data, or the
 // leading digits of narrow data) one lane adds the whole count, otherwise every lane adds its own.
 __device__ __forceinline__ void m1_hist_add(uint32_t *hist, uint32_t digit, bool active) {
@@ -86,12 +138,18 @@ __device__ __forceinline__ void m1_hist_add(uint32_t *hist, uint32_t digit, bool
     }
 }
 
-// Bin of `rank` in a histogram of M1_BINS counters: all M1_THREADS threads, two bins each.
+// Bin of `rank` in a histogram of M1_BINS counters: all NT threads, M1_BINS / NT consecutive bins each.
 // Returns through dig / bef (LDS words) the bin and the count of keys in lower bins.
-__device__ __forceinline__ void m1_find_bin(const uint32_t *hist, uint32_t rank, uint32_t *wtot, uint32_t *dig,
-                                            uint32_t *bef) {
+template <int NT>
+__device__ __forceinline__ uint32_t m1_scan_bins(const uint32_t *hist, uint32_t (&cbin)[M1_BINS / NT], uint32_t *wtot) {
+    constexpr int BPT = M1_BINS / NT;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t c0 = hist[2 * tid], c1 = hist[2 * tid + 1], sum = c0 + c1;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+        cbin[q] = hist[BPT * tid + q];
+        sum += cbin[q];
+    }
     uint32_t incl = sum;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -102,42 +160,38 @@ __device__ __forceinline__ void m1_find_bin(const uint32_t *hist, uint32_t rank,
     __syncthreads();
     uint32_t base = 0;
     for (int w = 0; w < wave; ++w) base += wtot[w];
-    incl += base;
-    const uint32_t excl = incl - sum;
-    if (excl <= rank && rank < incl) {
-        const bool second = rank >= excl + c0;
-        *dig = (uint32_t)(2 * tid + (second ? 1 : 0));
-        *bef = excl + (second ? c0 : 0u);
+    return incl + base - sum;                       // keys in the bins below this thread's
+}
+template <int NT>
+__device__ __forceinline__ void m1_pick_bin(const uint32_t (&cbin)[M1_BINS / NT], uint32_t excl, uint32_t rank, uint32_t *dig,
+                                            uint32_t *bef) {
+    constexpr int BPT = M1_BINS / NT;
+    uint32_t lo = excl;
+#pragma unroll
+    for (int q = 0; q < BPT; ++q) {
+        if (lo <= rank && rank < lo + cbin[q]) {
+            *dig = (uint32_t)(BPT * threadIdx.x + q);
+            *bef = lo;
+        }
+        lo += cbin[q];
     }
+}
+template <int NT = M1_THREADS>
+__device__ __forceinline__ void m1_find_bin(const uint32_t *hist, uint32_t rank, uint32_t *wtot, uint32_t *dig,
+                                            uint32_t *bef) {
+    uint32_t cbin[M1_BINS / NT];
+    const uint32_t excl = m1_scan_bins<NT>(hist, cbin, wtot);
+    m1_pick_bin<NT>(cbin, excl, rank, dig, bef);
     __syncthreads();
 }
 // The bins of two ranks of the SAME histogram from one scan: results in dig[0..1], bef[0..1].
+template <int NT = M1_THREADS>
 __device__ __forceinline__ void m1_find_bin2(const uint32_t *hist, uint32_t ra, uint32_t rb, uint32_t *wtot,
                                              uint32_t *dig, uint32_t *bef) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t c0 = hist[2 * tid], c1 = hist[2 * tid + 1], sum = c0 + c1;
-    uint32_t incl = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = __shfl_up(incl, d);
-        if (lane >= d) incl += o;
-    }
-    if (lane == 63) wtot[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0;
-    for (int w = 0; w < wave; ++w) base += wtot[w];
-    incl += base;
-    const uint32_t excl = incl - sum;
-    if (excl <= ra && ra < incl) {
-        const bool second = ra >= excl + c0;
-        dig[0] = (uint32_t)(2 * tid + (second ? 1 : 0));
-        bef[0] = excl + (second ? c0 : 0u);
-    }
-    if (excl <= rb && rb < incl) {
-        const bool second = rb >= excl + c0;
-        dig[1] = (uint32_t)(2 * tid + (second ? 1 : 0));
-        bef[1] = excl + (second ? c0 : 0u);
-    }
+    uint32_t cbin[M1_BINS / NT];
+    const uint32_t excl = m1_scan_bins<NT>(hist, cbin, wtot);
+    m1_pick_bin<NT>(cbin, excl, ra, &dig[0], &bef[0]);
+    m1_pick_bin<NT>(cbin, excl, rb, &dig[1], &bef[1]);
     __syncthreads();
 }
 
@@ -147,9 +201,9 @@ __device__ __forceinline__ void m1_find_bin2(const uint32_t *hist, uint32_t ra, 
 // give ka == kb exactly); the bits below them are rounded outwards (*ka <= key of rank ra,
 // *kb >= key of rank rb), which widens a bracket by less than 2^-10 of an octave.
 static constexpr int M1_PASSES = 2;
-template <typename K, int S>
+template <typename K, int S, int NT>
 __device__ void m1_select2(const K *sk, K kmin, K kmax, uint32_t ra, uint32_t rb, uint32_t (*hist)[M1_BINS],
-                           uint32_t (*wtot)[M1_THREADS / 64], uint32_t *s_dig, uint32_t *s_bef, K *ka, K *kb) {
+                           uint32_t (*wtot)[NT / 64], uint32_t *s_dig, uint32_t *s_bef, K *ka, K *kb) {
     constexpr int BITS = (int)sizeof(K) * 8;
     const int tid = threadIdx.x;
     const K width = kmax - kmin;
@@ -162,9 +216,9 @@ __device__ void m1_select2(const K *sk, K kmin, K kmax, uint32_t ra, uint32_t rb
         done = p + 1;
         const int shift = 11 * (passes - 1 - p);
         const bool same = pa == pb;
-        for (int i = tid; i < 2 * M1_BINS; i += M1_THREADS) (&hist[0][0])[i] = 0;
+        for (int i = tid; i < 2 * M1_BINS; i += NT) (&hist[0][0])[i] = 0;
         __syncthreads();
-        for (int j = tid; j < S; j += M1_THREADS) {
+        for (int j = tid; j < S; j += NT) {
             const K u = sk[j] - kmin;
             const K top = p == 0 ? (K)0 : (K)(u >> (shift + 11));
             const uint32_t digit = (uint32_t)(u >> shift) & (M1_BINS - 1);
@@ -173,10 +227,10 @@ __device__ void m1_select2(const K *sk, K kmin, K kmax, uint32_t ra, uint32_t rb
         }
         __syncthreads();
         if (same) {
-            m1_find_bin2(hist[0], ra, rb, wtot[0], s_dig, s_bef);
+            m1_find_bin2<NT>(hist[0], ra, rb, wtot[0], s_dig, s_bef);
         } else {
-            m1_find_bin(hist[0], ra, wtot[0], &s_dig[0], &s_bef[0]);
-            m1_find_bin(hist[1], rb, wtot[1], &s_dig[1], &s_bef[1]);
+            m1_find_bin<NT>(hist[0], ra, wtot[0], &s_dig[0], &s_bef[0]);
+            m1_find_bin<NT>(hist[1], rb, wtot[1], &s_dig[1], &s_bef[1]);
         }
         pa = (pa << 11) | (K)s_dig[0];
         pb = (pb << 11) | (K)s_dig[1];
@@ -190,20 +244,22 @@ __device__ void m1_select2(const K *sk, K kmin, K kmax, uint32_t ra, uint32_t rb
     *kb = top_b > width ? kmax : kmin + top_b;
 }
 
-template <typename T>
-__global__ __launch_bounds__(M1_THREADS) void k_m1_sample(const T *__restrict__ x, BlockGeom g, T w0, T w1,
-                                                          M1State *__restrict__ st) {
+template <typename T, typename Src>
+__global__ __launch_bounds__(Src::SAMPLE_THREADS) void k_m1_sample(const T *__restrict__ x, BlockGeom g, Src src,
+                                                          M1State *__restrict__ st, int64_t *__restrict__ counts) {
     using K = typename KeyT<T>::type;
-    constexpr int S = M1<T>::S, PER = S / M1_THREADS, NRUN = S / M1_RUN;
+    constexpr int S = Src::S, NT = Src::SAMPLE_THREADS, PER = S / NT, NRUN = S / M1_RUN;
     extern __shared__ __align__(16) unsigned char smem[];
     K *sk = reinterpret_cast<K *>(smem);
     __shared__ uint32_t hist[2][M1_BINS];
-    __shared__ uint32_t wtot[2][M1_THREADS / 64];
+    __shared__ uint32_t wtot[2][NT / 64];
     __shared__ uint32_t s_dig[2], s_bef[2];
     __shared__ K s_kmin, s_kmax;
     const int64_t b = blockIdx.x;
-    const int64_t n = g.frames[b];
+    const int64_t frames = g.frames[b];
+    const int64_t n = Src::count(frames);              // coefficients of the block
     const int tid = threadIdx.x, lane = tid & 63;
+    if (tid == 0 && counts) counts[b] = n;
     M1State s{};
     if (n <= S) {
         // short block: every coefficient is a candidate of both selections
@@ -225,12 +281,12 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_sample(const T *__restrict__ 
     }
     __syncthreads();
     K tmin = ~(K)0, tmax = 0;
-    {
+    if constexpr (Src::STEREO) {
         T v0[PER], v1[PER];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const int j = tid + M1_THREADS * u;
+            const int j = tid + NT * u;
             const int run = j / M1_RUN, w = j % M1_RUN;
             int64_t i = sample_run_start(n, NRUN, M1_RUN, run) + w;       // (n < 2^31: the products fit 64 bits)
             i = i < 0 ? 0 : (i < n ? i : n - 1);
@@ -240,10 +296,35 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_sample(const T *__restrict__ 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < PER; ++u) {
-            const K k = m1_key(m1_d1(w0, w1, v0[u], v1[u]));
-            sk[tid + M1_THREADS * u] = k;
+            const K k = m1_key(m1_d1(src.w0, src.w1, v0[u], v1[u]));
+            sk[tid + NT * u] = k;
             tmin = k < tmin ? k : tmin;
             tmax = k > tmax ? k : tmax;
+        }
+    } else {
+        // four coefficients at a time: their 4 F loads are in flight together
+        constexpr int G = PER < 4 ? PER : 4;
+        static_assert(PER % G == 0, "sample coefficients per thread");
+#pragma unroll
+        for (int u0 = 0; u0 < PER; u0 += G) {
+            T v[G][Src::F];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                const int j = tid + NT * (u0 + q);
+                const int run = j / M1_RUN, w = j % M1_RUN;
+                int64_t i = sample_run_start(n, NRUN, M1_RUN, run) + w;
+                i = i < 0 ? 0 : (i < n ? i : n - 1);
+                src.window(in, frames, i, v[q]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                const K k = m1_key(src.eval(v[q]));
+                sk[tid + NT * (u0 + q)] = k;
+                tmin = k < tmin ? k : tmin;
+                tmax = k > tmax ? k : tmax;
+            }
         }
     }
     for (int d = 32; d >= 1; d >>= 1) {
@@ -265,7 +346,7 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_sample(const T *__restrict__ 
     want_lo = open_lo ? 0 : want_lo;
     want_hi = open_hi ? S - 1 : want_hi;
     K klo = 0, khi = 0;
-    m1_select2<K, S>(sk, s_kmin, s_kmax, (uint32_t)want_lo, (uint32_t)want_hi, hist, wtot, s_dig, s_bef, &klo, &khi);
+    m1_select2<K, S, NT>(sk, s_kmin, s_kmax, (uint32_t)want_lo, (uint32_t)want_hi, hist, wtot, s_dig, s_bef, &klo, &khi);
     const T lo_v = val_of(klo), hi_v = val_of(khi);
     const bool finite = klo != ~(K)0 && khi != ~(K)0 && fabs(lo_v) <= (T)1e30 && fabs(hi_v) <= (T)1e30;
     if (!finite || open_lo || open_hi) {
@@ -294,7 +375,7 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_sample(const T *__restrict__ 
     __syncthreads();
     tmin = ~(K)0;
     tmax = 0;
-    for (int j = tid; j < S; j += M1_THREADS) {
+    for (int j = tid; j < S; j += NT) {
         const K kk = sk[j];
         const K k = kk == ~(K)0 ? kk : m1_key((T)fabs(val_of(kk) - mhat));
         sk[j] = k;
@@ -312,7 +393,7 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_sample(const T *__restrict__ 
     }
     __syncthreads();
     K kalo = 0, kahi = 0;
-    m1_select2<K, S>(sk, s_kmin, s_kmax, (uint32_t)want_lo, (uint32_t)want_hi, hist, wtot, s_dig, s_bef, &kalo, &kahi);
+    m1_select2<K, S, NT>(sk, s_kmin, s_kmax, (uint32_t)want_lo, (uint32_t)want_hi, hist, wtot, s_dig, s_bef, &kalo, &kahi);
     if (tid == 0) {
         const double eps_t = sizeof(T) == 4 ? 1.1920929e-7 : 2.220446049250313e-16;
         const bool open_above = kahi == ~(K)0 || !(fabs(val_of(kahi)) <= (T)1e30);
@@ -407,6 +488,82 @@ __device__ __forceinline__ void m1_classify(const T (&d)[16], const bool (&live_
     }
 }
 
+// Second half of a gather workgroup: the 16 coefficients of every thread (coefficient u * 256 + tid of the
+// tile that starts at coefficient f0 of block b, which has n of them) are classified, the counts and
+// the staged keys go to the block's state and lists.
+template <typename T, bool FULL>
+__device__ __forceinline__ void m1_gather_finish(const T (&d)[16], const bool (&live)[16], int64_t b, int64_t f0, int64_t n,
+                                                 typename KeyT<T>::type lo, typename KeyT<T>::type hi, T mhat, T alo, T ahi,
+                                                 M1State *__restrict__ st, T *__restrict__ cand_m, int64_t cap_m,
+                                                 T *__restrict__ cand_a, int64_t cap_a, T *stage_m, T *stage_a,
+                                                 unsigned long long *s_below_m, unsigned long long *s_below_a,
+                                                 unsigned int *s_fill_m, unsigned int *s_fill_a, unsigned int *s_base_m,
+                                                 unsigned int *s_base_a, int *s_nan) {
+    using K = typename KeyT<T>::type;
+    constexpr int BATCH = 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    unsigned int below_m = 0, below_a = 0;
+    bool saw_nan = false;
+    if (lo == 0 && hi == ~(K)0) {
+        // short block, every coefficient is a candidate of both lists: stored in place, no staging
+        T *dm = cand_m + b * cap_m + f0, *da = cand_a + b * cap_a + f0;
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int64_t f = (int64_t)u * 256 + tid;
+            if (live[u]) {
+                dm[f] = d[u];
+                da[f] = d[u];
+                saw_nan |= d[u] != d[u];
+            }
+        }
+        if (saw_nan) st[b].has_nan = 1;
+        if (tid == 0) {
+            const unsigned int cnt = (unsigned int)(n - f0 < M1_TILE ? n - f0 : M1_TILE);
+            atomicAdd(&st[b].n_m, cnt);
+            atomicAdd(&st[b].n_a, cnt);
+        }
+        return;
+    }
+    const bool tie_m = st[b].tie_m != 0, tie_a = st[b].tie_a != 0;
+    m1_classify<T, FULL>(d, live, lo, hi, mhat, alo, ahi, stage_m, stage_a, s_fill_m, s_fill_a, below_m, below_a, saw_nan,
+                         tie_m, tie_a);
+    for (int dd = 32; dd >= 1; dd >>= 1) {
+        below_m += __shfl_xor(below_m, dd);
+        below_a += __shfl_xor(below_a, dd);
+    }
+    if (lane == 0) {
+        if (below_m) atomicAdd(s_below_m, (unsigned long long)below_m);
+        if (below_a) atomicAdd(s_below_a, (unsigned long long)below_a);
+    }
+    if (saw_nan) *s_nan = 1;
+    __syncthreads();
+    // tied brackets: the keys are only counted (n_m / n_a), nothing is written
+    const unsigned int cm = tie_m ? 0u : (*s_fill_m < M1_STAGE_M ? *s_fill_m : M1_STAGE_M);
+    const unsigned int ca = tie_a ? 0u : (*s_fill_a < M1_STAGE_A ? *s_fill_a : M1_STAGE_A);
+    if (tid == 0) {
+        if ((!tie_m && *s_fill_m > M1_STAGE_M) || (!tie_a && *s_fill_a > M1_STAGE_A)) st[b].spill = 1;
+        const unsigned int add_m = tie_m ? *s_fill_m : cm, add_a = tie_a ? *s_fill_a : ca;
+        *s_base_m = add_m ? atomicAdd(&st[b].n_m, add_m) : 0u;
+        *s_base_a = add_a ? atomicAdd(&st[b].n_a, add_a) : 0u;
+        if (*s_below_m) atomicAdd(&st[b].below_m, *s_below_m);
+        if (*s_below_a) atomicAdd(&st[b].below_a, *s_below_a);
+        if (*s_nan) st[b].has_nan = 1;
+    }
+    __syncthreads();
+    {
+        const int64_t base = *s_base_m;
+        T *dst = cand_m + b * cap_m;
+        for (unsigned int p = tid; p < cm; p += 256)
+            if (base + p < cap_m) dst[base + p] = stage_m[p];      // beyond the capacity: seen by n_m > cap_m
+    }
+    {
+        const int64_t base = *s_base_a;
+        T *dst = cand_a + b * cap_a;
+        for (unsigned int p = tid; p < ca; p += 256)
+            if (base + p < cap_a) dst[base + p] = stage_a[p];
+    }
+}
+
 // One pass over the blocks: keys below each bracket counted, keys inside gathered.
 // FULL: workgroup (block b, tile t) of a grid of n_blocks x tiles_per_block takes the tile if it lies
 // inside the block (one frame per load instruction, no bounds); the other instantiation runs one
@@ -473,66 +630,104 @@ __global__ __launch_bounds__(256) void k_m1_gather(const T *__restrict__ x, Bloc
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) d[u] = m1_d1(w0, w1, v0[u], v1[u]);
     }
-    unsigned int below_m = 0, below_a = 0;
-    bool saw_nan = false;
-    if (lo == 0 && hi == ~(K)0) {
-        // short block, every coefficient is a candidate of both lists: stored in place, no staging
-        T *dm = cand_m + b * cap_m + f0, *da = cand_a + b * cap_a + f0;
-#pragma unroll
-        for (int u = 0; u < BATCH; ++u) {
-            const int64_t f = (int64_t)u * 256 + tid;
-            if (live[u]) {
-                dm[f] = d[u];
-                da[f] = d[u];
-                saw_nan |= d[u] != d[u];
-            }
-        }
-        if (saw_nan) st[b].has_nan = 1;
-        if (tid == 0) {
-            const unsigned int cnt = (unsigned int)(n - f0 < M1_TILE ? n - f0 : M1_TILE);
-            atomicAdd(&st[b].n_m, cnt);
-            atomicAdd(&st[b].n_a, cnt);
-        }
-        return;
-    }
-    const bool tie_m = st[b].tie_m != 0, tie_a = st[b].tie_a != 0;
-    m1_classify<T, FULL>(d, live, lo, hi, mhat, alo, ahi, stage_m, stage_a, &s_fill_m, &s_fill_a, below_m, below_a, saw_nan,
-                         tie_m, tie_a);
-    for (int dd = 32; dd >= 1; dd >>= 1) {
-        below_m += __shfl_xor(below_m, dd);
-        below_a += __shfl_xor(below_a, dd);
-    }
-    if (lane == 0) {
-        if (below_m) atomicAdd(&s_below_m, (unsigned long long)below_m);
-        if (below_a) atomicAdd(&s_below_a, (unsigned long long)below_a);
-    }
-    if (saw_nan) s_nan = 1;
-    __syncthreads();
-    // tied brackets: the keys are only counted (n_m / n_a), nothing is written
-    const unsigned int cm = tie_m ? 0u : (s_fill_m < M1_STAGE_M ? s_fill_m : M1_STAGE_M);
-    const unsigned int ca = tie_a ? 0u : (s_fill_a < M1_STAGE_A ? s_fill_a : M1_STAGE_A);
+    m1_gather_finish<T, FULL>(d, live, b, f0, n, lo, hi, mhat, alo, ahi, st, cand_m, cap_m, cand_a, cap_a, stage_m, stage_a,
+                              &s_below_m, &s_below_a, &s_fill_m, &s_fill_a, &s_base_m, &s_base_a, &s_nan);
+}
+
+// The same pass for the finest detail band of mono blocks.  A workgroup takes the tile of M1_TILE
+// coefficients that starts at coefficient k0 = tile * M1_TILE of block b: the 2 M1_TILE + F samples
+// xe[(2 k0 - F/2 + i) mod M] they are formed from are staged in LDS (16-byte loads when the tile
+// neither wraps nor touches the repeated last sample of an odd block, element by element with the
+// periodization index otherwise), thread tid forms coefficients k0 + u * 256 + tid from F/2 + 1
+// eight-byte LDS reads each (consecutive lanes read consecutive pairs: no bank conflicts).
+template <typename T, int F>
+__global__ __launch_bounds__(256) void k_d1_gather(const T *__restrict__ x, BlockGeom g, SrcMono<T, F, 0> src,
+                                                   M1State *__restrict__ st, T *__restrict__ cand_m, int64_t cap_m,
+                                                   T *__restrict__ cand_a, int64_t cap_a, int64_t tiles_per_block) {
+    using K = typename KeyT<T>::type;
+    using V2 = T __attribute__((ext_vector_type(2)));
+    using V4 = T __attribute__((ext_vector_type(4)));
+    constexpr int BATCH = 16, NS = 2 * M1_TILE + F;         // coefficients per thread, staged samples (a multiple of 4)
+    __shared__ __attribute__((aligned(16))) T xs[NS];
+    // the samples are dead once every thread holds its coefficients: the stages of the bracket keys take their place
+    static_assert(M1_STAGE_M + M1_STAGE_A <= NS, "stages fit the sample buffer");
+    T *stage_m = xs, *stage_a = xs + M1_STAGE_M;
+    __shared__ unsigned long long s_below_m, s_below_a;
+    __shared__ unsigned int s_fill_m, s_fill_a, s_base_m, s_base_a;
+    __shared__ int s_nan;
+    const int64_t b = blockIdx.x / tiles_per_block;
+    const int64_t frames = g.frames[b];
+    const int64_t n = (frames + 1) >> 1;                    // coefficients of the block
+    const int64_t k0 = (blockIdx.x % tiles_per_block) * M1_TILE;
+    if (k0 >= n) return;
+    const K lo = (K)st[b].lo_m, hi = (K)st[b].hi_m;
+    if (lo > hi) return;
+    const T mhat = (T)st[b].mhat, alo = (T)st[b].alo, ahi = (T)st[b].ahi;
+    const int tid = threadIdx.x;
     if (tid == 0) {
-        if ((!tie_m && s_fill_m > M1_STAGE_M) || (!tie_a && s_fill_a > M1_STAGE_A)) st[b].spill = 1;
-        const unsigned int add_m = tie_m ? s_fill_m : cm, add_a = tie_a ? s_fill_a : ca;
-        s_base_m = add_m ? atomicAdd(&st[b].n_m, add_m) : 0u;
-        s_base_a = add_a ? atomicAdd(&st[b].n_a, add_a) : 0u;
-        if (s_below_m) atomicAdd(&st[b].below_m, s_below_m);
-        if (s_below_a) atomicAdd(&st[b].below_a, s_below_a);
-        if (s_nan) st[b].has_nan = 1;
+        s_below_m = 0;
+        s_below_a = 0;
+        s_fill_m = 0;
+        s_fill_a = 0;
+        s_nan = 0;
+    }
+    const T *in = x + g.in_off[b];
+    const int64_t base = 2 * k0 - F / 2;                    // unwrapped sample index of xs[0]
+    if (base >= 0 && base + NS <= frames && (reinterpret_cast<uintptr_t>(in + base) & (sizeof(V4) - 1)) == 0) {
+        const V4 *v4 = reinterpret_cast<const V4 *>(in + base);
+        V4 *d4 = reinterpret_cast<V4 *>(xs);
+        V4 q[NS / 4 / 256 + 1];
+#pragma unroll
+        for (int u = 0; u < NS / 4 / 256 + 1; ++u) {
+            const int i = u * 256 + tid;
+            if (i < NS / 4) q[u] = __builtin_nontemporal_load(v4 + i);
+        }
+#pragma unroll
+        for (int u = 0; u < NS / 4 / 256 + 1; ++u) {
+            const int i = u * 256 + tid;
+            if (i < NS / 4) d4[i] = q[u];
+        }
+    } else {
+        // block lengths fit 32 bits; one division, then the index walks upwards with wrap
+        const int n_fr = (int)frames, M = n_fr + (n_fr & 1);
+        int s0 = (int)(base % M);
+        if (s0 < 0) s0 += M;
+        int idx = (int)(((int64_t)s0 + tid) % M);
+        const int step = 256 % M;
+        for (int i = tid; i < NS; i += 256) {
+            xs[i] = in[idx < n_fr ? idx : n_fr - 1];
+            idx += step;
+            idx = idx >= M ? idx - M : idx;
+        }
     }
     __syncthreads();
-    {
-        const int64_t base = s_base_m;
-        T *dst = cand_m + b * cap_m;
-        for (unsigned int p = tid; p < cm; p += 256)
-            if (base + p < cap_m) dst[base + p] = stage_m[p];      // beyond the capacity: seen by n_m > cap_m
+    T d[BATCH];
+    bool live[BATCH];
+    const V2 *xs2 = reinterpret_cast<const V2 *>(xs);
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+        const int kk = u * 256 + tid;
+        live[u] = k0 + kk < n;
+        // tap j meets the sample at unwrapped index 2 k + F/2 - j = xs[2 kk + F - j]
+        T v[F + 2];
+#pragma unroll
+        for (int t = 0; t < F / 2 + 1; ++t) {
+            const V2 q = xs2[kk + t];
+            v[2 * t] = q.x;
+            v[2 * t + 1] = q.y;
+        }
+        T sd = 0;
+#pragma unroll
+        for (int j = 0; j < F; ++j) sd = fma(src.g[j], v[F - j], sd);
+        d[u] = sd;
     }
-    {
-        const int64_t base = s_base_a;
-        T *dst = cand_a + b * cap_a;
-        for (unsigned int p = tid; p < ca; p += 256)
-            if (base + p < cap_a) dst[base + p] = stage_a[p];
-    }
+    __syncthreads();
+    if (k0 + M1_TILE <= n)
+        m1_gather_finish<T, true>(d, live, b, k0, n, lo, hi, mhat, alo, ahi, st, cand_m, cap_m, cand_a, cap_a, stage_m, stage_a,
+                                  &s_below_m, &s_below_a, &s_fill_m, &s_fill_a, &s_base_m, &s_base_a, &s_nan);
+    else
+        m1_gather_finish<T, false>(d, live, b, k0, n, lo, hi, mhat, alo, ahi, st, cand_m, cap_m, cand_a, cap_a, stage_m, stage_a,
+                                   &s_below_m, &s_below_a, &s_fill_m, &s_fill_a, &s_base_m, &s_base_a, &s_nan);
 }
 
 // Per block: are the wanted ranks inside the gathered lists?  Descriptors for the two selections.
@@ -583,32 +778,54 @@ __device__ __forceinline__ bool m1_verified(const M1State &s, double med, double
 // same key when enough keys tie with it, else the smallest larger key (one more sweep, no atomics).
 // Visits every key of the block: f(i, key) for i in [0, n), whole waves take every step and the loads
 // of UB steps are in flight together.
-template <typename T, typename F>
-__device__ __forceinline__ void m1_sweep(const T *in, int64_t n, T w0, T w1, bool absdev, T c, F f) {
-    using V2 = T __attribute__((ext_vector_type(2)));
-    constexpr int UB = 16;
-    const int64_t span = (int64_t)UB * M1_THREADS;
-    const int64_t n_pad = (n + span - 1) / span * span;
-    const bool vec = (reinterpret_cast<uintptr_t>(in) & (sizeof(V2) - 1)) == 0;      // one load per frame
-    for (int64_t i0 = threadIdx.x; i0 < n_pad; i0 += span) {
-        V2 q[UB];
-        if (vec && i0 - threadIdx.x + span <= n) {
-            const V2 *v2 = reinterpret_cast<const V2 *>(in);
+template <typename T, typename Src, typename F>
+__device__ __forceinline__ void m1_sweep(const Src &src, const T *in, int64_t frames, int64_t n, bool absdev, T c, F f) {
+    if constexpr (Src::STEREO) {
+        using V2 = T __attribute__((ext_vector_type(2)));
+        constexpr int UB = 16;
+        const int64_t span = (int64_t)UB * M1_THREADS;
+        const int64_t n_pad = (n + span - 1) / span * span;
+        const bool vec = (reinterpret_cast<uintptr_t>(in) & (sizeof(V2) - 1)) == 0;      // one load per frame
+        for (int64_t i0 = threadIdx.x; i0 < n_pad; i0 += span) {
+            V2 q[UB];
+            if (vec && i0 - threadIdx.x + span <= n) {
+                const V2 *v2 = reinterpret_cast<const V2 *>(in);
 #pragma unroll
-            for (int u = 0; u < UB; ++u) q[u] = v2[i0 + (int64_t)u * M1_THREADS];
-        } else {
+                for (int u = 0; u < UB; ++u) q[u] = v2[i0 + (int64_t)u * M1_THREADS];
+            } else {
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int64_t i = i0 + (int64_t)u * M1_THREADS;
+                    q[u].x = i < n ? in[2 * i] : (T)0;
+                    q[u].y = i < n ? in[2 * i + 1] : (T)0;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                T v = m1_d1(src.w0, src.w1, q[u].x, q[u].y);
+                if (absdev) v = fabs(v - c);
+                f(i0 + (int64_t)u * M1_THREADS < n, m1_key(v));
+            }
+        }
+    } else {
+        // any other source: the coefficients one by one (neighbouring lanes form neighbouring coefficients,
+        // their samples overlap in the cache)
+        constexpr int UB = 4;
+        const int64_t span = (int64_t)UB * M1_THREADS;
+        const int64_t n_pad = (n + span - 1) / span * span;
+        for (int64_t i0 = threadIdx.x; i0 < n_pad; i0 += span) {
+            T v[UB];
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
                 const int64_t i = i0 + (int64_t)u * M1_THREADS;
-                q[u].x = i < n ? in[2 * i] : (T)0;
-                q[u].y = i < n ? in[2 * i + 1] : (T)0;
+                v[u] = i < n ? src.at(in, frames, i) : (T)0;
             }
-        }
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            T v = m1_d1(w0, w1, q[u].x, q[u].y);
-            if (absdev) v = fabs(v - c);
-            f(i0 + (int64_t)u * M1_THREADS < n, m1_key(v));
+            for (int u = 0; u < UB; ++u) {
+                T w = v[u];
+                if (absdev) w = fabs(w - c);
+                f(i0 + (int64_t)u * M1_THREADS < n, m1_key(w));
+            }
         }
     }
 }
@@ -625,8 +842,8 @@ __device__ __forceinline__ void m1_list_sweep(const K *list, uint32_t cnt, F f) 
 // (list_cap keys of scratch memory, normally a few percent of the block) a second sweep gathers
 // them and the remaining digits - and usually the neighbour key of rank r1 - are found on the list;
 // otherwise every digit is a sweep over the block.
-template <typename T>
-__device__ void m1_slow_pair(const T *in, int64_t n, T w0, T w1, bool absdev, T c, uint64_t r0, uint64_t r1,
+template <typename T, typename Src>
+__device__ void m1_slow_pair(const Src &src, const T *in, int64_t frames, int64_t n, bool absdev, T c, uint64_t r0, uint64_t r1,
                              uint32_t *hist, uint32_t *wtot, uint32_t *s_dig, uint32_t *s_bef, unsigned long long *s_min,
                              uint32_t *s_fill, int *nan_seen, typename KeyT<T>::type *list, int64_t list_cap,
                              typename KeyT<T>::type *k0, typename KeyT<T>::type *k1) {
@@ -652,7 +869,7 @@ __device__ void m1_slow_pair(const T *in, int64_t n, T w0, T w1, bool absdev, T 
                 m1_hist_add(hist, (uint32_t)(k >> shift) & ((1u << width) - 1u), match);
             });
         } else {
-            m1_sweep<T>(in, n, w0, w1, absdev, c, [&](bool live, K k) {
+            m1_sweep<T>(src, in, frames, n, absdev, c, [&](bool live, K k) {
                 if (live && k == ~(K)0) *nan_seen = 1;
                 const bool match = live && (p == 0 || (K)(k >> up) == prefix);
                 m1_hist_add(hist, (uint32_t)(k >> shift) & ((1u << width) - 1u), match);
@@ -672,7 +889,7 @@ __device__ void m1_slow_pair(const T *in, int64_t n, T w0, T w1, bool absdev, T 
                 // gather the keys of the leading bin: the other digits are found among them
                 if (tid == 0) *s_fill = 0;
                 __syncthreads();
-                m1_sweep<T>(in, n, w0, w1, absdev, c, [&](bool live, K k) {
+                m1_sweep<T>(src, in, frames, n, absdev, c, [&](bool live, K k) {
                     const bool match = live && (K)(k >> shift) == prefix;
                     const unsigned long long bal = __ballot(match);
                     if (bal) {
@@ -705,7 +922,7 @@ __device__ void m1_slow_pair(const T *in, int64_t n, T w0, T w1, bool absdev, T 
             if (live && k > prefix && (unsigned long long)k < mn) mn = (unsigned long long)k;
         });
     } else {
-        m1_sweep<T>(in, n, w0, w1, absdev, c, [&](bool live, K k) {
+        m1_sweep<T>(src, in, frames, n, absdev, c, [&](bool live, K k) {
             if (live && k > prefix && (unsigned long long)k < mn) mn = (unsigned long long)k;
         });
     }
@@ -722,8 +939,8 @@ __device__ void m1_slow_pair(const T *in, int64_t n, T w0, T w1, bool absdev, T 
 // Last kernel of the statistics, one workgroup per block: the block's second selection is verified;
 // a block that is not resolved by then is selected exactly here; the universal threshold
 // sigma * sqrt(2 ln frames) is written (frames == 1 gives 0).
-template <typename T>
-__global__ __launch_bounds__(M1_THREADS) void k_m1_fallback(const T *__restrict__ x, BlockGeom g, T w0, T w1,
+template <typename T, typename Src>
+__global__ __launch_bounds__(M1_THREADS) void k_m1_fallback(const T *__restrict__ x, BlockGeom g, Src src,
                                                             const M1State *__restrict__ st, const int *__restrict__ resolved,
                                                             const int *__restrict__ valid_a, const double *__restrict__ pair_a,
                                                             double *med, double *mad, double *thresh, double *sigma_out,
@@ -735,10 +952,11 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_fallback(const T *__restrict_
     __shared__ unsigned long long s_min;
     __shared__ int s_nan;
     const int64_t b = blockIdx.x;
-    const int64_t n = g.frames[b];
+    const int64_t frames = g.frames[b];
+    const int64_t n = Src::count(frames);                  // coefficients of the block
     const double nan = __longlong_as_double(0x7FF8000000000000ll);
     auto finish = [&](double sigma) {
-        const double t = sigma * sqrt(2.0 * log((double)n));
+        const double t = sigma * sqrt(2.0 * log((double)frames));
         thresh[b] = t;
         if (sigma_out) sigma_out[b] = sigma;
         if (thresh_out) thresh_out[b] = t;
@@ -763,7 +981,7 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_fallback(const T *__restrict_
     K k0, k1;
     // the block's own candidate list (useless now) is the scratch of the exact selection
     K *list = reinterpret_cast<K *>(scratch + blockIdx.x * scratch_cap);
-    m1_slow_pair<T>(in, n, w0, w1, false, (T)0, r0, r1, hist, wtot, &s_dig, &s_bef, &s_min, &s_fill, &s_nan, list, scratch_cap,
+    m1_slow_pair<T>(src, in, frames, n, false, (T)0, r0, r1, hist, wtot, &s_dig, &s_bef, &s_min, &s_fill, &s_nan, list, scratch_cap,
                     &k0, &k1);
     __syncthreads();
     if (s_nan) {
@@ -777,7 +995,7 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_fallback(const T *__restrict_
     const T a = val_of(k0), bb = val_of(k1);
     const T m = r0 == r1 ? a : (T)((a + bb) / (T)2);
     K q0, q1;
-    m1_slow_pair<T>(in, n, w0, w1, true, m, r0, r1, hist, wtot, &s_dig, &s_bef, &s_min, &s_fill, &s_nan, list, scratch_cap,
+    m1_slow_pair<T>(src, in, frames, n, true, m, r0, r1, hist, wtot, &s_dig, &s_bef, &s_min, &s_fill, &s_nan, list, scratch_cap,
                     &q0, &q1);
     if (threadIdx.x == 0) {
         const T ta = val_of(q0), tb = val_of(q1);
@@ -789,44 +1007,55 @@ __global__ __launch_bounds__(M1_THREADS) void k_m1_fallback(const T *__restrict_
 }
 
 // ---------------------------------------------------------------- host side
-template <typename T>
-static int64_t m1_cap(int64_t max_frames, double frac) {
-    // a block no longer than the sample is gathered whole; longer ones hold `frac` of their keys in the bracket
-    const int64_t want = (int64_t)((double)max_frames * frac) + 1024;
-    const int64_t whole = max_frames < M1<T>::S ? max_frames : M1<T>::S;
+template <typename T, typename Src>
+static int64_t m1_cap(int64_t max_count, double frac) {
+    // a block with no more coefficients than the sample is gathered whole; longer ones hold `frac` of their keys in the bracket
+    const int64_t want = (int64_t)((double)max_count * frac) + 1024;
+    const int64_t whole = max_count < Src::S ? max_count : Src::S;
     return want > whole ? want : whole;
 }
-// Which batches take the single-pass route.  Its sampling and its list selections run one workgroup
-// per block: with lists that fit LDS (blocks up to ~299 K frames in binary32, ~145 K in binary64) that is
-// fast for any number of blocks; longer lists (blocks up to about a million frames) are selected in memory,
-// which pays only when there are enough blocks to fill the GPU (measured: 704 blocks of 864 K frames 4.4 ms
-// against 13.4 ms of the plain route, 80 blocks of 2.9 M frames 3.2 against 1.8 ms).
+// Which batches take the single-pass route (max_count: coefficients of the longest block).  Its sampling
+// and its list selections run one workgroup per block: with lists that fit LDS (stereo blocks up to ~299 K
+// frames in binary32, ~145 K in binary64) that is fast for any number of blocks; longer lists (blocks up to
+// about a million frames) are selected in memory, which pays only when there are enough blocks to fill the
+// GPU (measured: 704 blocks of 864 K frames 4.4 ms against 13.4 ms of the plain route, 80 blocks of 2.9 M
+// frames 3.2 against 1.8 ms).
+template <typename T, typename Src>
+static bool m1_src_applicable(const Ctx *c, int64_t n_blocks, int64_t max_count) {
+    const size_t kb = sizeof(typename KeyT<T>::type);
+    const size_t cap = (size_t)m1_cap<T, Src>(max_count, Src::FRAC_A);
+    return !c->force_generic && max_count < (int64_t(1) << 30) &&
+           (cap <= select_subset_lds_keys(kb) || (n_blocks >= c->num_cus && cap <= select_subset_max_keys(kb)));
+}
+template <typename T, typename Src>
+static size_t m1_src_ws_bytes(int64_t n_blocks, int64_t max_count) {
+    const size_t nb = (size_t)n_blocks;
+    return ws_need(nb, sizeof(M1State)) + ws_need(nb * (size_t)m1_cap<T, Src>(max_count, Src::FRAC_M), sizeof(T)) +
+           ws_need(nb * (size_t)m1_cap<T, Src>(max_count, Src::FRAC_A), sizeof(T)) + 5 * ws_need(nb, 8) + 3 * ws_need(nb, 4) +
+           3 * ws_need(nb, 8) + ws_need(2 * nb, 8);
+}
 template <typename T>
 static bool m1_applicable(const Ctx *c, int64_t n_blocks, int64_t max_frames) {
-    const size_t kb = sizeof(typename KeyT<T>::type);
-    const size_t cap = (size_t)m1_cap<T>(max_frames, M1<T>::FRAC_A);
-    return !c->force_generic && max_frames < (int64_t(1) << 31) &&
-           (cap <= select_subset_lds_keys(kb) || (n_blocks >= c->num_cus && cap <= select_subset_max_keys(kb)));
+    return m1_src_applicable<T, SrcStereo<T>>(c, n_blocks, max_frames);
 }
 template <typename T>
 static size_t m1_ws_bytes(int64_t n_blocks, int64_t max_frames) {
-    const size_t nb = (size_t)n_blocks;
-    return ws_need(nb, sizeof(M1State)) + ws_need(nb * (size_t)m1_cap<T>(max_frames, M1<T>::FRAC_M), sizeof(T)) +
-           ws_need(nb * (size_t)m1_cap<T>(max_frames, M1<T>::FRAC_A), sizeof(T)) + 4 * ws_need(nb, 8) + 3 * ws_need(nb, 4) +
-           3 * ws_need(nb, 8) + ws_need(2 * nb, 8);
+    return m1_src_ws_bytes<T, SrcStereo<T>>(n_blocks, max_frames);
 }
 
-// Median absolute deviation (sigma) and universal threshold of every stereo block; *thresh_ws
-// receives the per-block thresholds (device, binary64).
-template <typename T>
-static int stereo_mad_single_pass(Ctx *c, const T *d_in, const BlockGeom &g, int64_t max_frames, T w0, T w1,
-                                  double *d_sigma_out, double *d_thresh_out, double **thresh_ws) {
+// Median absolute deviation (sigma) and universal threshold of every block from coefficients formed
+// on the fly by `src`; gather(st, cand_m, cap_m, cand_a, cap_a) enqueues the source's gather pass.
+// *thresh_ws receives the per-block thresholds (device, binary64).
+template <typename T, typename Src, typename Gather>
+static int mad_single_pass(Ctx *c, const T *d_in, const BlockGeom &g, int64_t max_count, const Src &src,
+                           const char *sample_name, Gather gather, double *d_sigma_out, double *d_thresh_out,
+                           double **thresh_ws) {
     const size_t nb = (size_t)g.n_blocks;
-    const int64_t cap_m = m1_cap<T>(max_frames, M1<T>::FRAC_M), cap_a = m1_cap<T>(max_frames, M1<T>::FRAC_A);
+    const int64_t cap_m = m1_cap<T, Src>(max_count, Src::FRAC_M), cap_a = m1_cap<T, Src>(max_count, Src::FRAC_A);
     M1State *st = ws_take<M1State>(c, nb);
     T *cand_m = ws_take<T>(c, nb * (size_t)cap_m);
     T *cand_a = ws_take<T>(c, nb * (size_t)cap_a);
-    int64_t *len_m = ws_take<int64_t>(c, nb), *len_a = ws_take<int64_t>(c, nb);
+    int64_t *len_m = ws_take<int64_t>(c, nb), *len_a = ws_take<int64_t>(c, nb), *counts = ws_take<int64_t>(c, nb);
     unsigned long long *below_m = ws_take<unsigned long long>(c, nb), *below_a = ws_take<unsigned long long>(c, nb);
     int *valid_m = ws_take<int>(c, nb), *valid_a = ws_take<int>(c, nb), *resolved = ws_take<int>(c, nb);
     double *med = ws_take<double>(c, nb), *mad = ws_take<double>(c, nb), *thresh = ws_take<double>(c, nb);
@@ -837,26 +1066,20 @@ static int stereo_mad_single_pass(Ctx *c, const T *d_in, const BlockGeom &g, int
     }
     const unsigned nbk = (unsigned)ceil_div(g.n_blocks, 256);
     {
-        auto kern = k_m1_sample<T>;
-        const size_t dyn = (size_t)M1<T>::S * sizeof(typename KeyT<T>::type);
+        auto kern = k_m1_sample<T, Src>;
+        const size_t dyn = (size_t)Src::S * sizeof(typename KeyT<T>::type);
         ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-        ADN_LAUNCH_NAMED("k_m1_sample", kern, dim3((unsigned)g.n_blocks), dim3(M1_THREADS), dyn, c->stream, d_in, g, w0, w1, st);
+        ADN_LAUNCH_NAMED(sample_name, kern, dim3((unsigned)g.n_blocks), dim3(Src::SAMPLE_THREADS), dyn, c->stream, d_in, g, src, st, counts);
     }
-    const int64_t tiles = max_frames / M1_TILE;            // whole tiles of the longest block
-    ADN_REQUIRE(g.n_blocks * (tiles + 1) < (int64_t)0x7FFFFFFF, "wavelet batch too large for one launch");
-    if (tiles > 0)
-        ADN_LAUNCH((k_m1_gather<T, true>), dim3((unsigned)(g.n_blocks * tiles)), dim3(256), 0, c->stream, d_in, g,
-                           w0, w1, st, cand_m, cap_m, cand_a, cap_a, tiles);
-    ADN_LAUNCH((k_m1_gather<T, false>), dim3((unsigned)g.n_blocks), dim3(256), 0, c->stream, d_in, g, w0, w1, st,
-                       cand_m, cap_m, cand_a, cap_a, (int64_t)1);
-    ADN_LAUNCH(k_m1_check, dim3(nbk), dim3(256), 0, c->stream, st, g.frames, g.n_blocks, cap_m, cap_a, len_m, len_a,
+    ADN_TRY(gather(st, cand_m, cap_m, cand_a, cap_a));
+    ADN_LAUNCH(k_m1_check, dim3(nbk), dim3(256), 0, c->stream, st, counts, g.n_blocks, cap_m, cap_a, len_m, len_a,
                        below_m, below_a, valid_m, valid_a, resolved, med, mad, c->force_fallback ? 1 : 0);
     ADN_HIP(hipGetLastError());
     SubsetSelect sm;
     sm.n_seg = g.n_blocks;
     sm.cap = cap_m;
     sm.d_len = len_m;
-    sm.d_orig_len = g.frames;
+    sm.d_orig_len = counts;
     sm.d_below = below_m;
     sm.d_valid = valid_m;
     sm.d_out = med;
@@ -865,7 +1088,7 @@ static int stereo_mad_single_pass(Ctx *c, const T *d_in, const BlockGeom &g, int
     sa.n_seg = g.n_blocks;
     sa.cap = cap_a;
     sa.d_len = len_a;
-    sa.d_orig_len = g.frames;
+    sa.d_orig_len = counts;
     sa.d_below = below_a;
     sa.d_valid = valid_a;
     sa.xform = XF_ABSDEV;
@@ -873,9 +1096,56 @@ static int stereo_mad_single_pass(Ctx *c, const T *d_in, const BlockGeom &g, int
     sa.d_out = mad;
     sa.d_pair = pair_a;
     ADN_TRY(launch_select_subset<T>(c, cand_a, sa));
-    ADN_LAUNCH((k_m1_fallback<T>), dim3((unsigned)g.n_blocks), dim3(M1_THREADS), 0, c->stream, d_in, g, w0, w1, st,
+    ADN_LAUNCH((k_m1_fallback<T, Src>), dim3((unsigned)g.n_blocks), dim3(M1_THREADS), 0, c->stream, d_in, g, src, st,
                        resolved, valid_a, pair_a, med, mad, thresh, d_sigma_out, d_thresh_out, cand_a, cap_a);
     ADN_HIP(hipGetLastError());
     *thresh_ws = thresh;
     return ADN_OK;
+}
+
+template <typename T>
+static int stereo_mad_single_pass(Ctx *c, const T *d_in, const BlockGeom &g, int64_t max_frames, T w0, T w1,
+                                  double *d_sigma_out, double *d_thresh_out, double **thresh_ws) {
+    const int64_t tiles = max_frames / M1_TILE;            // whole tiles of the longest block
+    ADN_REQUIRE(g.n_blocks * (tiles + 1) < (int64_t)0x7FFFFFFF, "wavelet batch too large for one launch");
+    SrcStereo<T> src;
+    src.w0 = w0;
+    src.w1 = w1;
+    auto gather = [&](M1State *st, T *cand_m, int64_t cap_m, T *cand_a, int64_t cap_a) -> int {
+        if (tiles > 0)
+            ADN_LAUNCH((k_m1_gather<T, true>), dim3((unsigned)(g.n_blocks * tiles)), dim3(256), 0, c->stream, d_in, g,
+                               w0, w1, st, cand_m, cap_m, cand_a, cap_a, tiles);
+        ADN_LAUNCH((k_m1_gather<T, false>), dim3((unsigned)g.n_blocks), dim3(256), 0, c->stream, d_in, g, w0, w1, st,
+                           cand_m, cap_m, cand_a, cap_a, (int64_t)1);
+        return ADN_OK;
+    };
+    return mad_single_pass<T>(c, d_in, g, max_frames, src, "k_m1_sample", gather, d_sigma_out, d_thresh_out, thresh_ws);
+}
+
+// The same statistics for the finest detail band of mono blocks (periodization), taps g[0..F) of the
+// decomposition high-pass filter: no coefficient array, one pass over the samples.
+template <typename T, int F, int S>
+static bool mono_single_pass_applicable(const Ctx *c, int64_t n_blocks, int64_t max_frames) {
+    return m1_src_applicable<T, SrcMono<T, F, S>>(c, n_blocks, (max_frames + 1) / 2);
+}
+template <typename T, int F, int S>
+static size_t mono_single_pass_ws_bytes(int64_t n_blocks, int64_t max_frames) {
+    return m1_src_ws_bytes<T, SrcMono<T, F, S>>(n_blocks, (max_frames + 1) / 2);
+}
+template <typename T, int F, int S>
+static int mono_mad_single_pass(Ctx *c, const T *d_in, const BlockGeom &g, int64_t max_frames, const T *taps_g,
+                                double *d_sigma_out, double *d_thresh_out, double **thresh_ws) {
+    const int64_t max_count = (max_frames + 1) / 2;
+    const int64_t tiles = ceil_div(max_count, (int64_t)M1_TILE);
+    ADN_REQUIRE(g.n_blocks * tiles < (int64_t)0x7FFFFFFF, "wavelet batch too large for one launch");
+    SrcMono<T, F, S> src;
+    SrcMono<T, F, 0> gsrc;
+    for (int j = 0; j < F; ++j) src.g[j] = gsrc.g[j] = taps_g[j];
+    auto gather = [&](M1State *st, T *cand_m, int64_t cap_m, T *cand_a, int64_t cap_a) -> int {
+        if (tiles > 0)
+            ADN_LAUNCH((k_d1_gather<T, F>), dim3((unsigned)(g.n_blocks * tiles)), dim3(256), 0, c->stream, d_in, g, gsrc, st,
+                               cand_m, cap_m, cand_a, cap_a, tiles);
+        return ADN_OK;
+    };
+    return mad_single_pass<T>(c, d_in, g, max_count, src, "k_d1_sample", gather, d_sigma_out, d_thresh_out, thresh_ws);
 }

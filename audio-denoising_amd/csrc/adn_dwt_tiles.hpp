@@ -597,6 +597,29 @@ static int denoise_f(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_f
     for (int l = 0; l < TL; ++l) top_stride = (top_stride + 1) / 2;
     top_stride += 1;
     g.d_stride = d1_stride;
+    double *thresh = const_cast<double *>(d_thresh_given);
+    // Blocks whose levels all live in the tiles: the threshold statistics come from one pass over the samples
+    // (finest-band coefficients formed on the fly, bracket candidates gathered), no coefficient array.  The
+    // small bracket sample keeps the per-block sampling cheap; its longer candidate lists must fit LDS.
+    constexpr int S_SMALL = 4096, S_LARGE = 16384;
+    const bool want_single = !deep && !d_thresh_given && !(c->ablate & 16);
+    const bool single_small = want_single && mono_single_pass_applicable<T, F, S_SMALL>(c, 0, max_frames);
+    const bool single_large = want_single && !single_small && mono_single_pass_applicable<T, F, S_LARGE>(c, g.n_blocks, max_frames);
+    if (single_small || single_large) {
+        const TapsF<T, F> tp = make_taps_f<T, F>(wavelet);
+        if (single_small) {
+            ADN_TRY(ws_reserve(c, mono_single_pass_ws_bytes<T, F, S_SMALL>(g.n_blocks, max_frames)));
+            ADN_TRY((mono_mad_single_pass<T, F, S_SMALL>(c, d_in, g, max_frames, tp.g, d_sigma, d_thresh, &thresh)));
+        } else {
+            ADN_TRY(ws_reserve(c, mono_single_pass_ws_bytes<T, F, S_LARGE>(g.n_blocks, max_frames)));
+            ADN_TRY((mono_mad_single_pass<T, F, S_LARGE>(c, d_in, g, max_frames, tp.g, d_sigma, d_thresh, &thresh)));
+        }
+        launch_tile_tl<T, F, MODE_APPLY>(c, TL, d_in, d_out, g, max_frames, wavelet, thresh, thr_mode, d_zeroed,
+                                         (T *)nullptr, 0, (T *)nullptr, 0, 0);
+        ADN_HIP(hipGetLastError());
+        *handled = true;
+        return ADN_OK;
+    }
     const size_t nD = (size_t)g.n_blocks * d1_stride, nT = deep ? (size_t)g.n_blocks * top_stride : 0;
     ADN_TRY(ws_reserve(c, ws_need(nD, sizeof(T)) + ws_need(nT, sizeof(T)) +
                               mad_ws_bytes(g.n_blocks, (max_frames + 1) / 2)));
@@ -610,7 +633,6 @@ static int denoise_f(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_f
     else if (!d_thresh_given)
         launch_tile_tl<T, F, MODE_STATS>(c, 1, d_in, (T *)nullptr, g, max_frames, wavelet, nullptr, thr_mode,
                                          nullptr, D1, d1_stride, (T *)nullptr, 0, 0);
-    double *thresh = const_cast<double *>(d_thresh_given);
     if (!d_thresh_given)
         ADN_TRY(mad_threshold<T>(c, D1, g, F, ADN_EXT_PERIODIZATION, 0, (max_frames + 1) / 2, d_sigma, d_thresh,
                                  &thresh));

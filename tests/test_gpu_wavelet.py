@@ -409,3 +409,77 @@ def test_stereo_single_pass_edge_lengths(dt):
         for n, y, g, f in zip(lens, ys, yg, yf):
             assert np.array_equal(y, g, equal_nan=True), n
             assert np.array_equal(y, f, equal_nan=True), n
+
+
+@pytest.mark.parametrize("dt,wavelet,level,longest", [(torch.float32, "db4", 2, 144000), (torch.float32, "db8", 3, 400001),
+                                                      (torch.float64, "db4", 2, 120001), (torch.float64, "db8", 4, 200000)])
+def test_mono_single_pass_statistics_exact(dt, wavelet, level, longest):
+    """Mono blocks whose levels all live in the tile kernels take their threshold statistics from one
+    pass over the samples (finest-band coefficients formed on the fly: sample -> brackets -> gather ->
+    exact selection among the gathered keys, verified, exact fallback).  Sigma, threshold and zero
+    counts must EQUAL those of the level-by-level route (coefficient arrays + two full selections)
+    and of the exact per-block fallback, for Gaussian, heavy-tailed, quantised, autocorrelated,
+    half-silent, constant, silent, NaN-carrying, odd, short and one-sample blocks, with lengths round
+    the route's internal sizes (bracket sample 4096 / 16384 coefficients, gather tile 4096
+    coefficients = 8192 samples); sigma must match the oracle."""
+    e = engine()
+    rng = np.random.default_rng(99)
+    npdt = np.float32 if dt == torch.float32 else np.float64
+
+    def st(n, kind):
+        if kind == "gauss":
+            x = 0.1 * rng.standard_normal(n)
+        elif kind == "laplace":
+            x = 0.05 * rng.laplace(size=n)
+        elif kind == "pcm":
+            x = np.round(0.2 * rng.standard_normal(n) * 512) / 512
+        elif kind == "ar":
+            w = 0.05 * rng.standard_normal(n)
+            x = np.empty(n)
+            acc = 0.0
+            for i in range(n):
+                acc = 0.9 * acc + w[i]
+                x[i] = acc
+        elif kind == "halfsilent":
+            x = 0.1 * rng.standard_normal(n)
+            x[: n // 2 + 7] = 0.0
+        elif kind == "const":
+            x = np.full(n, 0.25)
+        elif kind == "zero":
+            x = np.zeros(n)
+        elif kind == "nan":
+            x = 0.1 * rng.standard_normal(n)
+            x[n // 3] = np.nan
+        elif kind == "speech":
+            x = synth.noisy_speech(n, 48000, 42, n % 97)
+        return x.astype(npdt)
+
+    spec = [(longest, "gauss"), (longest - 1, "speech"), (100001, "laplace"), (40000, "ar"), (32768, "gauss"),
+            (8192, "gauss"), (8193, "gauss"), (8191, "laplace"), (8194, "gauss"), (16384, "speech"), (16385, "gauss"),
+            (5, "gauss"), (1, "gauss"), (2, "gauss"), (longest - 3, "zero"), (110000, "nan"), (90001, "const"),
+            (longest - 5, "halfsilent"), (65001, "pcm"), (24577, "gauss"), (9, "zero")]
+    blocks = [st(n, k) for n, k in spec]
+    for thr_mode in ("soft", "hard"):
+        ys, s1 = _batch_denoise(e, blocks, dt, wavelet, level, thr_mode)
+        e.force_generic(True)
+        try:
+            yg, s2 = _batch_denoise(e, blocks, dt, wavelet, level, thr_mode)
+        finally:
+            e.force_generic(False)
+        e.force_exact_fallback(True)                 # every block through the exact per-block fallback
+        try:
+            yf, s3 = _batch_denoise(e, blocks, dt, wavelet, level, thr_mode)
+        finally:
+            e.force_exact_fallback(False)
+        for name, a, b, f in zip(("sigma", "thresh", "zeroed"), s1, s2, s3):
+            assert np.array_equal(a, b, equal_nan=True), (name, thr_mode, a, b)
+            assert np.array_equal(a, f, equal_nan=True), (name, thr_mode, a, f)
+        for (n, k), y, f in zip(spec, ys, yf):
+            assert np.array_equal(y, f, equal_nan=True), (n, k)
+    for (n, k), blk, sg in zip(spec, blocks, s1[0]):
+        _, s_or, _ = orc.denoise_block(blk.astype(np.float64), wavelet, level, "soft")
+        if np.isnan(s_or):
+            assert np.isnan(sg), (n, k)
+        else:
+            scale = max(float(np.max(np.abs(blk))), 1e-3)
+            assert abs(sg - s_or) <= (2e-6 if dt == torch.float32 else 1e-14) * scale, (n, k, sg, s_or)
