@@ -102,12 +102,19 @@ struct SrcMono {
     // the F samples under the taps of coefficient k (v[j] meets tap j): independent loads
     __device__ __forceinline__ void window(const T *__restrict__ in, int64_t frames, int64_t k, T (&v)[F_]) const {
         const int n = (int)frames, M = n + (n & 1);
-        const int idx0 = (int)((2 * k + F / 2) % M);
+        int idx0 = 2 * (int)k + F / 2;               // k < M / 2: one subtraction wraps it unless the block is tiny
+        while (idx0 >= M) idx0 -= M;
+        if (idx0 >= F - 1 && idx0 < n) {             // the window neither wraps nor touches the repeated sample
+            const T *w = in + idx0;
 #pragma unroll
-        for (int j = 0; j < F; ++j) {
-            int idx = idx0 - j;
-            while (idx < 0) idx += M;                // F/2 / M + 1 rounds at most
-            v[j] = in[idx < n ? idx : n - 1];
+            for (int j = 0; j < F; ++j) v[j] = w[-j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < F; ++j) {
+                int idx = idx0 - j;
+                while (idx < 0) idx += M;            // F / M + 1 rounds at most
+                v[j] = in[idx < n ? idx : n - 1];
+            }
         }
     }
     __device__ __forceinline__ T eval(const T (&v)[F_]) const {
@@ -418,8 +425,8 @@ __global__ __launch_bounds__(Src::SAMPLE_THREADS) void k_m1_sample(const T *__re
 // keys inside appended to the workgroup's LDS stages (positions from wave ballots, eight keys at a
 // time so that the ballots stay in scalar registers).  FULL: every coefficient exists (a tile inside
 // its block), no per-key bounds.
-template <typename T, bool FULL>
-__device__ __forceinline__ void m1_classify(const T (&d)[16], const bool (&live_in)[16], typename KeyT<T>::type lo,
+template <typename T, bool FULL, int BATCH = 16>
+__device__ __forceinline__ void m1_classify(const T (&d)[BATCH], const bool (&live_in)[BATCH], typename KeyT<T>::type lo,
                                             typename KeyT<T>::type hi, T mhat, T alo, T ahi, T *stage_m, T *stage_a,
                                             unsigned int *s_fill_m, unsigned int *s_fill_a, unsigned int &below_m,
                                             unsigned int &below_a, bool &saw_nan, bool tie_m, bool tie_a) {
@@ -428,7 +435,7 @@ __device__ __forceinline__ void m1_classify(const T (&d)[16], const bool (&live_
     const int lane = threadIdx.x & 63;
     const K span = hi - lo;
 #pragma unroll
-    for (int h = 0; h < 16; h += SUB) {
+    for (int h = 0; h < BATCH; h += SUB) {
         // ---- median bracket (keys)
         {
             bool keep[SUB];
@@ -488,11 +495,11 @@ __device__ __forceinline__ void m1_classify(const T (&d)[16], const bool (&live_
     }
 }
 
-// Second half of a gather workgroup: the 16 coefficients of every thread (coefficient u * 256 + tid of the
+// Second half of a gather workgroup: the BATCH coefficients of every thread (coefficient u * NT + tid of the
 // tile that starts at coefficient f0 of block b, which has n of them) are classified, the counts and
 // the staged keys go to the block's state and lists.
-template <typename T, bool FULL>
-__device__ __forceinline__ void m1_gather_finish(const T (&d)[16], const bool (&live)[16], int64_t b, int64_t f0, int64_t n,
+template <typename T, bool FULL, int BATCH = 16, int NT = 256>
+__device__ __forceinline__ void m1_gather_finish(const T (&d)[BATCH], const bool (&live)[BATCH], int64_t b, int64_t f0, int64_t n,
                                                  typename KeyT<T>::type lo, typename KeyT<T>::type hi, T mhat, T alo, T ahi,
                                                  M1State *__restrict__ st, T *__restrict__ cand_m, int64_t cap_m,
                                                  T *__restrict__ cand_a, int64_t cap_a, T *stage_m, T *stage_a,
@@ -500,7 +507,7 @@ __device__ __forceinline__ void m1_gather_finish(const T (&d)[16], const bool (&
                                                  unsigned int *s_fill_m, unsigned int *s_fill_a, unsigned int *s_base_m,
                                                  unsigned int *s_base_a, int *s_nan) {
     using K = typename KeyT<T>::type;
-    constexpr int BATCH = 16;
+    static_assert(BATCH * NT == M1_TILE, "a workgroup takes one tile");
     const int tid = threadIdx.x, lane = tid & 63;
     unsigned int below_m = 0, below_a = 0;
     bool saw_nan = false;
@@ -509,7 +516,7 @@ __device__ __forceinline__ void m1_gather_finish(const T (&d)[16], const bool (&
         T *dm = cand_m + b * cap_m + f0, *da = cand_a + b * cap_a + f0;
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            const int64_t f = (int64_t)u * 256 + tid;
+            const int64_t f = (int64_t)u * NT + tid;
             if (live[u]) {
                 dm[f] = d[u];
                 da[f] = d[u];
@@ -525,7 +532,7 @@ __device__ __forceinline__ void m1_gather_finish(const T (&d)[16], const bool (&
         return;
     }
     const bool tie_m = st[b].tie_m != 0, tie_a = st[b].tie_a != 0;
-    m1_classify<T, FULL>(d, live, lo, hi, mhat, alo, ahi, stage_m, stage_a, s_fill_m, s_fill_a, below_m, below_a, saw_nan,
+    m1_classify<T, FULL, BATCH>(d, live, lo, hi, mhat, alo, ahi, stage_m, stage_a, s_fill_m, s_fill_a, below_m, below_a, saw_nan,
                          tie_m, tie_a);
     for (int dd = 32; dd >= 1; dd >>= 1) {
         below_m += __shfl_xor(below_m, dd);
@@ -553,13 +560,13 @@ __device__ __forceinline__ void m1_gather_finish(const T (&d)[16], const bool (&
     {
         const int64_t base = *s_base_m;
         T *dst = cand_m + b * cap_m;
-        for (unsigned int p = tid; p < cm; p += 256)
+        for (unsigned int p = tid; p < cm; p += NT)
             if (base + p < cap_m) dst[base + p] = stage_m[p];      // beyond the capacity: seen by n_m > cap_m
     }
     {
         const int64_t base = *s_base_a;
         T *dst = cand_a + b * cap_a;
-        for (unsigned int p = tid; p < ca; p += 256)
+        for (unsigned int p = tid; p < ca; p += NT)
             if (base + p < cap_a) dst[base + p] = stage_a[p];
     }
 }

@@ -536,19 +536,28 @@ __global__ __launch_bounds__(512) void k_deep(T *__restrict__ top, int64_t top_s
     for (int i = tid; i < NN[TL]; i += NT) tp_io[i] = lds[offA[TL] + i];
 }
 
-// Samples and threads of a tile.  Up to two levels in the tile: one wave per tile of 1024 (binary32) samples, so
-// that the barriers between the levels cost nothing and a CU holds a dozen independent tiles; the halo a tile
-// recomputes grows with 2^levels, so deeper tiles stay large (4096 samples, four waves).
-template <typename T, int TL> struct TileS {
-    static constexpr int S = (TL <= TILE_SMALL_TL ? 1024 : 4096) / (int)(sizeof(T) / 4);
-    static constexpr int THREADS = TL <= TILE_SMALL_TL ? 64 : 256;
+// Samples and threads of a tile.  Up to two levels in the tile: one wave per tile of about 1024 (binary32) samples,
+// so that the barriers between the levels cost nothing and a CU holds a dozen independent tiles; the halo a tile
+// recomputes grows with 2^levels, so deeper tiles stay large (about 4096 samples, four waves).
+// Four-wave APPLY tiles: every per-level loop hands its outputs (the owned ones plus the halo) to the threads in
+// whole rounds, so a count just above a multiple of a round costs a nearly empty round: 4096 samples at four
+// levels and sixteen taps take 22 rounds of the workgroup, 3584 samples 17.  Their sizes are those for which the
+// rounds of all levels are (nearly) full.  (One-wave tiles were measured at 960 and 1472 samples as well, with
+// fewer rounds per sample in both cases, and ran 12 % and 20 % slower than at 1024.)
+template <typename T, int F, int TL, int MODE> struct TileS {
+    static constexpr bool SMALL = TL <= TILE_SMALL_TL;
+    static constexpr int THREADS = SMALL ? 64 : 256;
+    static constexpr int S32 = SMALL || MODE != MODE_APPLY ? (SMALL ? 1024 : 4096) : F == 8 ? (TL == 3 ? 3904 : 3776) : (TL == 3 ? 3840 : 3584);
+    static constexpr int S64 = SMALL || MODE != MODE_APPLY ? (SMALL ? 512 : 2048) : F == 8 ? (TL == 3 ? 1888 : 1728) : (TL == 3 ? 1792 : 2016);
+    static constexpr int S = sizeof(T) == 4 ? S32 : S64;
 };
+static constexpr int TILE_MIN_S = 512;      // the smallest of the sizes above
 
 template <typename T, int F, int TL, int MODE>
 static void launch_tile(Ctx *c, const T *x, T *y, const BlockGeom &g, int64_t max_frames, int wavelet,
                         const double *thresh, int thr_mode, int64_t *zeroed, T *d1, int64_t d1_stride,
                         T *top, int64_t top_stride, int use_top) {
-    constexpr int S = TileS<T, TL>::S, THREADS = TileS<T, TL>::THREADS;
+    constexpr int S = TileS<T, F, TL, MODE>::S, THREADS = TileS<T, F, TL, MODE>::THREADS;
     const int tiles = (int)ceil_div(max_frames + 1, S);
     const TapsF<T, F> tp = make_taps_f<T, F>(wavelet);
     ADN_LAUNCH((k_tile<T, F, TL, S, THREADS, MODE>), dim3((unsigned)(tiles * g.n_blocks)), dim3(THREADS),
@@ -662,7 +671,7 @@ static int wavelet_denoise_fused(Ctx *c, const T *d_in, T *d_out, BlockGeom g, i
                                  double *d_thresh, int64_t *d_zeroed, const double *d_thresh_given, bool *handled) {
     *handled = false;
     if (c->force_generic || max_frames >= (int64_t(1) << 30)) return ADN_OK;
-    const int64_t tiles = ceil_div(max_frames + 1, tiles::TileS<T, 1>::S);       // the smallest tile
+    const int64_t tiles = ceil_div(max_frames + 1, (int64_t)tiles::TILE_MIN_S);       // the smallest tile
     if (tiles * g.n_blocks >= (int64_t)0x7FFFFFFF) return ADN_OK;
     if (filter_bank(wavelet).F == 8)
         return tiles::denoise_f<T, 8>(c, d_in, d_out, g, max_frames, wavelet, level, thr_mode, d_sigma,
