@@ -495,10 +495,11 @@ __device__ __forceinline__ void m1_classify(const T (&d)[BATCH], const bool (&li
     }
 }
 
-// Second half of a gather workgroup: the BATCH coefficients of every thread (coefficient u * NT + tid of the
+// Second half of a gather workgroup: the BATCH coefficients of every thread (runs of ADJ neighbouring ones:
+// coefficient ADJ ((u / ADJ) NT + tid) + u % ADJ of the
 // tile that starts at coefficient f0 of block b, which has n of them) are classified, the counts and
 // the staged keys go to the block's state and lists.
-template <typename T, bool FULL, int BATCH = 16, int NT = 256>
+template <typename T, bool FULL, int BATCH = 16, int NT = 256, int ADJ = 1>
 __device__ __forceinline__ void m1_gather_finish(const T (&d)[BATCH], const bool (&live)[BATCH], int64_t b, int64_t f0, int64_t n,
                                                  typename KeyT<T>::type lo, typename KeyT<T>::type hi, T mhat, T alo, T ahi,
                                                  M1State *__restrict__ st, T *__restrict__ cand_m, int64_t cap_m,
@@ -516,7 +517,8 @@ __device__ __forceinline__ void m1_gather_finish(const T (&d)[BATCH], const bool
         T *dm = cand_m + b * cap_m + f0, *da = cand_a + b * cap_a + f0;
 #pragma unroll
         for (int u = 0; u < BATCH; ++u) {
-            const int64_t f = (int64_t)u * NT + tid;
+            // a thread holds ADJ neighbouring coefficients in d[ADJ q .. ADJ q + ADJ - 1]
+            const int64_t f = ADJ * ((int64_t)(u / ADJ) * NT + tid) + u % ADJ;
             if (live[u]) {
                 dm[f] = d[u];
                 da[f] = d[u];
@@ -641,24 +643,27 @@ __global__ __launch_bounds__(256) void k_m1_gather(const T *__restrict__ x, Bloc
                               &s_below_m, &s_below_a, &s_fill_m, &s_fill_a, &s_base_m, &s_base_a, &s_nan);
 }
 
-// The same pass for the finest detail band of mono blocks.  A workgroup takes the tile of M1_TILE
-// coefficients that starts at coefficient k0 = tile * M1_TILE of block b: the 2 M1_TILE + F samples
-// xe[(2 k0 - F/2 + i) mod M] they are formed from are staged in LDS (16-byte loads when the tile
-// neither wraps nor touches the repeated last sample of an odd block, element by element with the
-// periodization index otherwise), thread tid forms coefficients k0 + u * 256 + tid from F/2 + 1
-// eight-byte LDS reads each (consecutive lanes read consecutive pairs: no bank conflicts).
-template <typename T, int F>
-__global__ __launch_bounds__(256) void k_d1_gather(const T *__restrict__ x, BlockGeom g, SrcMono<T, F, 0> src,
-                                                   M1State *__restrict__ st, T *__restrict__ cand_m, int64_t cap_m,
-                                                   T *__restrict__ cand_a, int64_t cap_a, int64_t tiles_per_block) {
+// The same pass for the finest detail band of mono blocks.  A workgroup takes the tile of M1_TILE coefficients
+// that starts at coefficient k0 = tile * M1_TILE of block b; a thread forms runs of ADJ neighbouring coefficients
+// from the (F + 2 ADJ) / VW aligned 16-byte pieces that hold their F + 2 ADJ - 2 samples (VW samples a piece),
+// straight from memory - neighbouring threads' pieces overlap in the cache (plain loads: with the streaming hint
+// the overlapping pieces miss it, +12 %).  Measured alternatives on 2560 blocks of 144 000 samples, eight taps:
+// samples staged in LDS and coefficients from 8-byte LDS reads 0.56 ms (the 33 KB stage leaves four workgroups on
+// a CU), runs of two 0.41 ms, of four 0.38 ms, of eight 0.42 ms.  Tiles that wrap, touch the repeated last sample of
+// an odd block or start at an unaligned address form their coefficients one by one with the periodization index.
+static constexpr int D1_ADJ = 4;           // neighbouring coefficients a thread of the direct gather forms from one set of pieces
+template <typename T, int F, int ADJ>
+__global__ __launch_bounds__(256) void k_d1_gather_direct(const T *__restrict__ x, BlockGeom g, SrcMono<T, F, 0> src,
+                                                          M1State *__restrict__ st, T *__restrict__ cand_m, int64_t cap_m,
+                                                          T *__restrict__ cand_a, int64_t cap_a, int64_t tiles_per_block) {
     using K = typename KeyT<T>::type;
-    using V2 = T __attribute__((ext_vector_type(2)));
-    using V4 = T __attribute__((ext_vector_type(4)));
-    constexpr int BATCH = 16, NS = 2 * M1_TILE + F;         // coefficients per thread, staged samples (a multiple of 4)
-    __shared__ __attribute__((aligned(16))) T xs[NS];
-    // the samples are dead once every thread holds its coefficients: the stages of the bracket keys take their place
-    static_assert(M1_STAGE_M + M1_STAGE_A <= NS, "stages fit the sample buffer");
-    T *stage_m = xs, *stage_a = xs + M1_STAGE_M;
+    constexpr int VW = 16 / (int)sizeof(T), NCH = (F + 2 * ADJ) / VW;   // samples per piece, pieces per run
+    using VQ = T __attribute__((ext_vector_type(VW)));
+    constexpr int BATCH = 16, NU = BATCH / ADJ;                       // coefficients, runs per thread
+    constexpr int REGS = NCH * VW * (int)sizeof(T) / 4;               // registers the pieces of a run take
+    constexpr int G = REGS <= 12 ? 4 : (REGS <= 24 && NU >= 2 ? 2 : 1);   // runs whose pieces are in flight together
+    static_assert(NU % G == 0 && (F + 2 * ADJ) % VW == 0, "runs per thread");
+    __shared__ T stage_m[M1_STAGE_M], stage_a[M1_STAGE_A];
     __shared__ unsigned long long s_below_m, s_below_a;
     __shared__ unsigned int s_fill_m, s_fill_a, s_base_m, s_base_a;
     __shared__ int s_nan;
@@ -678,63 +683,61 @@ __global__ __launch_bounds__(256) void k_d1_gather(const T *__restrict__ x, Bloc
         s_fill_a = 0;
         s_nan = 0;
     }
-    const T *in = x + g.in_off[b];
-    const int64_t base = 2 * k0 - F / 2;                    // unwrapped sample index of xs[0]
-    if (base >= 0 && base + NS <= frames && (reinterpret_cast<uintptr_t>(in + base) & (sizeof(V4) - 1)) == 0) {
-        const V4 *v4 = reinterpret_cast<const V4 *>(in + base);
-        V4 *d4 = reinterpret_cast<V4 *>(xs);
-        V4 q[NS / 4 / 256 + 1];
-#pragma unroll
-        for (int u = 0; u < NS / 4 / 256 + 1; ++u) {
-            const int i = u * 256 + tid;
-            if (i < NS / 4) q[u] = __builtin_nontemporal_load(v4 + i);
-        }
-#pragma unroll
-        for (int u = 0; u < NS / 4 / 256 + 1; ++u) {
-            const int i = u * 256 + tid;
-            if (i < NS / 4) d4[i] = q[u];
-        }
-    } else {
-        // block lengths fit 32 bits; one division, then the index walks upwards with wrap
-        const int n_fr = (int)frames, M = n_fr + (n_fr & 1);
-        int s0 = (int)(base % M);
-        if (s0 < 0) s0 += M;
-        int idx = (int)(((int64_t)s0 + tid) % M);
-        const int step = 256 % M;
-        for (int i = tid; i < NS; i += 256) {
-            xs[i] = in[idx < n_fr ? idx : n_fr - 1];
-            idx += step;
-            idx = idx >= M ? idx - M : idx;
-        }
-    }
     __syncthreads();
+    const T *in = x + g.in_off[b];
+    const int64_t base = 2 * k0 - F / 2;                    // unwrapped index of the sample before the first window
     T d[BATCH];
     bool live[BATCH];
-    const V2 *xs2 = reinterpret_cast<const V2 *>(xs);
+    const bool direct = base >= 0 && base + 2 * M1_TILE + F <= frames &&
+                        (reinterpret_cast<uintptr_t>(in + base) & (sizeof(VQ) - 1)) == 0;
+    if (direct) {
+        const VQ *vq = reinterpret_cast<const VQ *>(in + base);
 #pragma unroll
-    for (int u = 0; u < BATCH; ++u) {
-        const int kk = u * 256 + tid;
-        live[u] = k0 + kk < n;
-        // tap j meets the sample at unwrapped index 2 k + F/2 - j = xs[2 kk + F - j]
-        T v[F + 2];
+        for (int q0 = 0; q0 < NU; q0 += G) {
+            VQ w[G][NCH];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < F / 2 + 1; ++t) {
-            const V2 q = xs2[kk + t];
-            v[2 * t] = q.x;
-            v[2 * t + 1] = q.y;
+            for (int q = 0; q < G; ++q) {
+                // run rr = (q0 + q) * 256 + tid: coefficients k0 + ADJ rr + a, samples base + 2 ADJ rr + [1, F + 2 ADJ - 2]
+                const VQ *pc = vq + (int64_t)((q0 + q) * 256 + tid) * (2 * ADJ / VW);
+#pragma unroll
+                for (int t = 0; t < NCH; ++t) w[q][t] = pc[t];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+                T v[NCH * VW];
+#pragma unroll
+                for (int t = 0; t < NCH; ++t)
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) v[t * VW + e] = w[q][t][e];
+                // tap j of the run's coefficient a meets sample base + 2 ADJ rr + F + 2 a - j
+#pragma unroll
+                for (int a = 0; a < ADJ; ++a) {
+                    T sd = 0;
+#pragma unroll
+                    for (int j = 0; j < F; ++j) sd = fma(src.g[j], v[F + 2 * a - j], sd);
+                    d[ADJ * (q0 + q) + a] = sd;
+                    live[ADJ * (q0 + q) + a] = true;
+                }
+            }
         }
-        T sd = 0;
+    } else {
 #pragma unroll
-        for (int j = 0; j < F; ++j) sd = fma(src.g[j], v[F - j], sd);
-        d[u] = sd;
+        for (int u = 0; u < BATCH; ++u) {
+            const int64_t k = k0 + ADJ * ((int64_t)(u / ADJ) * 256 + tid) + u % ADJ;
+            live[u] = k < n;
+            d[u] = live[u] ? src.at(in, frames, k) : (T)0;
+        }
     }
-    __syncthreads();
     if (k0 + M1_TILE <= n)
-        m1_gather_finish<T, true>(d, live, b, k0, n, lo, hi, mhat, alo, ahi, st, cand_m, cap_m, cand_a, cap_a, stage_m, stage_a,
-                                  &s_below_m, &s_below_a, &s_fill_m, &s_fill_a, &s_base_m, &s_base_a, &s_nan);
+        m1_gather_finish<T, true, BATCH, 256, ADJ>(d, live, b, k0, n, lo, hi, mhat, alo, ahi, st, cand_m, cap_m, cand_a, cap_a,
+                                                   stage_m, stage_a, &s_below_m, &s_below_a, &s_fill_m, &s_fill_a, &s_base_m,
+                                                   &s_base_a, &s_nan);
     else
-        m1_gather_finish<T, false>(d, live, b, k0, n, lo, hi, mhat, alo, ahi, st, cand_m, cap_m, cand_a, cap_a, stage_m, stage_a,
-                                   &s_below_m, &s_below_a, &s_fill_m, &s_fill_a, &s_base_m, &s_base_a, &s_nan);
+        m1_gather_finish<T, false, BATCH, 256, ADJ>(d, live, b, k0, n, lo, hi, mhat, alo, ahi, st, cand_m, cap_m, cand_a, cap_a,
+                                                    stage_m, stage_a, &s_below_m, &s_below_a, &s_fill_m, &s_fill_a, &s_base_m,
+                                                    &s_base_a, &s_nan);
 }
 
 // Per block: are the wanted ranks inside the gathered lists?  Descriptors for the two selections.
@@ -1150,7 +1153,7 @@ static int mono_mad_single_pass(Ctx *c, const T *d_in, const BlockGeom &g, int64
     for (int j = 0; j < F; ++j) src.g[j] = gsrc.g[j] = taps_g[j];
     auto gather = [&](M1State *st, T *cand_m, int64_t cap_m, T *cand_a, int64_t cap_a) -> int {
         if (tiles > 0)
-            ADN_LAUNCH((k_d1_gather<T, F>), dim3((unsigned)(g.n_blocks * tiles)), dim3(256), 0, c->stream, d_in, g, gsrc, st,
+            ADN_LAUNCH((k_d1_gather_direct<T, F, D1_ADJ>), dim3((unsigned)(g.n_blocks * tiles)), dim3(256), 0, c->stream, d_in, g, gsrc, st,
                                cand_m, cap_m, cand_a, cap_a, tiles);
         return ADN_OK;
     };
