@@ -145,8 +145,9 @@ int adn_wavelet_denoise_f64(adn_ctx *ctx, const double *d_in, double *d_out, int
 
 /* adn_wavelet_denoise_f32 for callers that cannot allocate device memory (code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the
- * reference.  Same arguments, same kernels, same results; the kernels' workspace (finest-band
- * coefficients, candidate lists and counters of the threshold statistics) lives in a static
+ * reference.  Same arguments, same kernels, same results; the kernels' workspace (candidate
+ * lists and counters of the threshold statistics, finest-band coefficients of transforms deeper
+ * than four levels) lives in a static
  * device array of ADN_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the
  * process ends.  The call makes no hipMalloc / hipFree and no other allocating call; a batch whose
  * kernels need more scratch than that is rejected with ADN_ERR_NOMEM (the message states both
