@@ -448,29 +448,42 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
 
 // Levels TL+1 .. L of one block on the level-TL approximation (whole arrays in LDS, exact
 // modular indexing): analysis, shrink + zero count, synthesis back to level TL, in place in `top`.
+static constexpr int DEEP_THREADS = 1024;   // one workgroup per block and CU: all the waves a CU takes
 template <typename T, int F>
-__global__ __launch_bounds__(512) void k_deep(T *__restrict__ top, int64_t top_stride, BlockGeom g,
+__global__ __launch_bounds__(DEEP_THREADS) void k_deep(T *__restrict__ top, int64_t top_stride, BlockGeom g,
                                               int TL, int L, TapsF<T, F> tp,
                                               const double *__restrict__ thresh, int thr_mode,
                                               int64_t *__restrict__ zeroed) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     T *lds = reinterpret_cast<T *>(smem_raw);
     __shared__ int offA[34], offD[34], NN[34];
-    const int tid = threadIdx.x, NT = 512;
+    const int tid = threadIdx.x, NT = DEEP_THREADS;
     const int64_t b = blockIdx.x;
     if (tid == 0) {
         int n = (int)g.frames[b];
         for (int l = 0; l < TL; ++l) n = (n + 1) >> 1;
-        int off = 0;
-        for (int l = TL; l <= L; ++l) {
-            NN[l] = n;
+        // A_TL at 0, then A and D of level TL + 1.  A_TL is dead from the analysis of level TL + 2 until the last
+        // synthesis step writes it again, and the arrays of all levels beyond TL + 1 together are no longer than it
+        // (unless the block is tiny): they take its place, so that two workgroups share a CU.
+        const int n1 = (n + 1) >> 1;
+        int deeper = 0;
+        for (int l = TL + 2, m = n1; l <= L; ++l) {
+            m = (m + 1) >> 1;
+            deeper += 2 * m;
+        }
+        NN[TL] = n;
+        offA[TL] = 0;
+        NN[TL + 1] = n1;
+        offA[TL + 1] = n;
+        offD[TL + 1] = n + n1;
+        int off = deeper <= n ? 0 : n + 2 * n1;
+        for (int l = TL + 2, m = n1; l <= L; ++l) {
+            m = (m + 1) >> 1;
+            NN[l] = m;
             offA[l] = off;
-            off += n;
-            if (l > TL) {
-                offD[l] = off;
-                off += n;
-            }
-            n = (n + 1) >> 1;
+            off += m;
+            offD[l] = off;
+            off += m;
         }
     }
     __syncthreads();
@@ -577,16 +590,20 @@ static void launch_tile_tl(Ctx *c, int TL, const T *x, T *y, const BlockGeom &g,
     }
 }
 
-// LDS bytes k_deep needs for the longest block
+// LDS bytes k_deep needs for the longest block (its layout, see the kernel; tiny blocks do not fold the deeper
+// levels into the level-TL array and may need more than a longer block: a floor covers them)
 template <typename T>
 static size_t deep_lds_bytes(int64_t max_frames, int TL, int L) {
     int64_t n = max_frames;
     for (int l = 0; l < TL; ++l) n = (n + 1) / 2;
-    size_t total = 0;
-    for (int l = TL; l <= L; ++l) {
-        total += (size_t)n * (l > TL ? 2 : 1);
-        n = (n + 1) / 2;
+    const int64_t n1 = (n + 1) / 2;
+    int64_t deeper = 0;
+    for (int64_t l = TL + 2, m = n1; l <= L; ++l) {
+        m = (m + 1) / 2;
+        deeper += 2 * m;
     }
+    size_t total = (size_t)(n + 2 * n1 + (deeper <= n ? 0 : deeper));
+    if (total < 512) total = 512;
     return total * sizeof(T) + 16;
 }
 
@@ -650,7 +667,7 @@ static int denoise_f(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_f
         if (deep_lds > 48 * 1024)
             ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_deep<T, F>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)deep_lds));
-        ADN_LAUNCH((k_deep<T, F>), dim3((unsigned)g.n_blocks), dim3(512), deep_lds, c->stream, top,
+        ADN_LAUNCH((k_deep<T, F>), dim3((unsigned)g.n_blocks), dim3(DEEP_THREADS), deep_lds, c->stream, top,
                            top_stride, g, TL, level, tp, thresh, thr_mode, d_zeroed);
     }
     launch_tile_tl<T, F, MODE_APPLY>(c, TL, d_in, d_out, g, max_frames, wavelet, thresh, thr_mode, d_zeroed,
