@@ -3,15 +3,16 @@ import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "audio-denoising_amd"))
 from adn_hip import get_engine
 wavelet, level = (sys.argv[1], int(sys.argv[2])) if len(sys.argv) > 2 else ("db4", 2)
+dt = torch.float64 if len(sys.argv) > 3 and sys.argv[3] == "f64" else torch.float32
 e = get_engine(0)
 if os.environ.get("ADN_ABLATE"):              # diagnostics: alternative routes of the mono statistics (16: two passes with the finest band in memory)
     e._check(e.lib.adn_set_option(e._h, 2, int(os.environ["ADN_ABLATE"])))
 clips, SR, n = 256, 48000, 30 * 48000
-x = torch.empty(clips * n, dtype=torch.float32, device="cuda")
+x = torch.empty(clips * n, dtype=dt, device="cuda")
 tmp = torch.empty(n, dtype=torch.float64, device="cuda")
 for c in range(16):
     e.synth_noisy_speech(n, SR, stream=c, out=tmp)
-    x[c * n:(c + 1) * n] = tmp.float()
+    x[c * n:(c + 1) * n] = tmp.to(dt)
 for c in range(16, clips):
     x[c * n:(c + 1) * n] = x[(c % 16) * n:(c % 16 + 1) * n]
 bs = e.denoise_block_frames(SR, n)
