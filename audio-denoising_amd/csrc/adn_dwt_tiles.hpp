@@ -555,8 +555,9 @@ __global__ __launch_bounds__(DEEP_THREADS) void k_deep(T *__restrict__ top, int6
 // Four-wave APPLY tiles: every per-level loop hands its outputs (the owned ones plus the halo) to the threads in
 // whole rounds, so a count just above a multiple of a round costs a nearly empty round: 4096 samples at four
 // levels and sixteen taps take 22 rounds of the workgroup, 3584 samples 17.  Their sizes are those for which the
-// rounds of all levels are (nearly) full.  (One-wave tiles were measured at 960 and 1472 samples as well, with
-// fewer rounds per sample in both cases, and ran 12 % and 20 % slower than at 1024.)
+// rounds of all levels are (nearly) full.  (One-wave tiles were measured at 448, 960 and 1472 samples as well, with
+// fewer rounds per sample in every case, and ran 15 %, 12 % and 20 % slower than at 1024; two-wave tiles of 1920
+// samples 25 % slower.)
 template <typename T, int F, int TL, int MODE> struct TileS {
     static constexpr bool SMALL = TL <= TILE_SMALL_TL;
     static constexpr int THREADS = SMALL ? 64 : 256;
