@@ -578,6 +578,19 @@ __global__ __launch_bounds__(256) void k_masked_mean(const T *__restrict__ S, in
 // gain[k] of the reference Wiener stage from the per-bin statistics (src/wiener_filter.py:84-86,
 // 108-115, 35-39): three zero-padded running medians around the SNR arithmetic.
 __device__ inline double medfilt_at(const double *v, int F, int k, int ksz) {
+    if (ksz == 5) {
+        // the reference's kernel size: five values in registers, a nine-comparator sorting network
+        double w0 = k >= 2 ? v[k - 2] : 0.0, w1 = k >= 1 ? v[k - 1] : 0.0, w2 = v[k];
+        double w3 = k + 1 < F ? v[k + 1] : 0.0, w4 = k + 2 < F ? v[k + 2] : 0.0;
+        auto cx = [](double &x, double &y) {
+            const bool sw = y < x;
+            const double lo = sw ? y : x, hi = sw ? x : y;
+            x = lo;
+            y = hi;
+        };
+        cx(w0, w1); cx(w3, w4); cx(w2, w4); cx(w2, w3); cx(w0, w3); cx(w0, w2); cx(w1, w4); cx(w1, w3); cx(w1, w2);
+        return w2;
+    }
     double w[31];
     const int h = ksz / 2;
     for (int i = 0; i < ksz; ++i) {
@@ -596,27 +609,29 @@ __device__ inline double medfilt_at(const double *v, int F, int k, int ksz) {
     return w[h];
 }
 
+// (a bin per thread for n_fft = 2048: the three running medians are short serial loops, and a signal is one workgroup)
+static constexpr int GAIN_THREADS = 1024;
 template <typename T>
-__global__ __launch_bounds__(256) void k_wiener_gain(const double *__restrict__ p10,
+__global__ __launch_bounds__(GAIN_THREADS) void k_wiener_gain(const double *__restrict__ p10,
                                                      const double *__restrict__ speech_raw, int F,
                                                      int ksz, T *__restrict__ gain) {
     extern __shared__ __align__(16) unsigned char smem[];
     double *a = reinterpret_cast<double *>(smem), *b = a + F, *g = b + F;
     const int64_t sig = blockIdx.x;
-    for (int k = threadIdx.x; k < F; k += 256) {
+    for (int k = threadIdx.x; k < F; k += GAIN_THREADS) {
         a[k] = (double)(T)p10[sig * F + k];
         b[k] = (double)(T)speech_raw[sig * F + k];
     }
     __syncthreads();
     double nz[9], sp[9];
     int cnt = 0;
-    for (int k = threadIdx.x; k < F; k += 256, ++cnt) {
+    for (int k = threadIdx.x; k < F; k += GAIN_THREADS, ++cnt) {
         nz[cnt] = (double)(T)fmax(medfilt_at(a, F, k, ksz), 1e-12);
         sp[cnt] = medfilt_at(b, F, k, ksz);
     }
     __syncthreads();
     cnt = 0;
-    for (int k = threadIdx.x; k < F; k += 256, ++cnt) {
+    for (int k = threadIdx.x; k < F; k += GAIN_THREADS, ++cnt) {
         const T noise = (T)nz[cnt];
         T speech = (T)sp[cnt];
         speech = speech > noise ? speech : noise;
@@ -626,7 +641,7 @@ __global__ __launch_bounds__(256) void k_wiener_gain(const double *__restrict__ 
         g[k] = (double)gv;
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < F; k += 256) gain[sig * F + k] = (T)medfilt_at(g, F, k, ksz);
+    for (int k = threadIdx.x; k < F; k += GAIN_THREADS) gain[sig * F + k] = (T)medfilt_at(g, F, k, ksz);
 }
 
 // 1 / sqrt(x) for x > 0 to within a few ulp: hardware estimate (about 2^-26 relative) refined by
@@ -1186,7 +1201,7 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
         sa.d_out = sraw;
         ADN_TRY(launch_select<T>(c, S, sa));
     }
-    ADN_LAUNCH((k_wiener_gain<T>), dim3((unsigned)n_sig), dim3(256), 3 * F * sizeof(double), c->stream, p10,
+    ADN_LAUNCH((k_wiener_gain<T>), dim3((unsigned)n_sig), dim3(GAIN_THREADS), 3 * F * sizeof(double), c->stream, p10,
                        sraw, F, kernel_bins, gain);
     ADN_HIP(hipGetLastError());
     ApplyArgs<T> a{};
@@ -1351,7 +1366,7 @@ int wiener_gain(Ctx *c, const double *d_noise_psd, const double *d_speech_psd, i
     ADN_REQUIRE(n_bins >= 1 && n_bins <= 9 * 256, "bin count out of range");
     if (n_sig <= 0) return ADN_OK;
     DeviceGuard dg(c->device);
-    ADN_LAUNCH((k_wiener_gain<T>), dim3((unsigned)n_sig), dim3(256), 3 * n_bins * sizeof(double), c->stream, d_noise_psd,
+    ADN_LAUNCH((k_wiener_gain<T>), dim3((unsigned)n_sig), dim3(GAIN_THREADS), 3 * n_bins * sizeof(double), c->stream, d_noise_psd,
                d_speech_psd, n_bins, kernel_bins, d_gain);
     ADN_HIP(hipGetLastError());
     return ADN_OK;
