@@ -66,6 +66,20 @@ __device__ __forceinline__ float shrink_fast(float d, float t, int thr_mode) {
 }
 __device__ __forceinline__ double shrink_fast(double d, double t, int thr_mode) { return shrink(d, t, thr_mode); }
 
+// acc + coef * (q.x, q.x) (HALF = 0) or coef * (q.y, q.y) (HALF = 1): the two-wide fused multiply-add with one half
+// of its second operand selected for both results
+// (half is a constant after unrolling: the branch folds away)
+__device__ __forceinline__ Pk<float>::type pk_fma_half(int half, Pk<float>::type coef, Pk<float>::type q, Pk<float>::type acc) {
+    Pk<float>::type r;
+    if (half == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "s"(coef), "v"(q), "v"(acc));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(r) : "s"(coef), "v"(q), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ Pk<double>::type pk_fma_half(int half, Pk<double>::type coef, Pk<double>::type q, Pk<double>::type acc) {
+    const double x = half ? q.y : q.x;
+    return __builtin_elementwise_fma(coef, Pk<double>::type{x, x}, acc);
+}
+
 // canonical contiguous range: indices (s + i) mod N for i < c
 struct Rg {
     int s, c, N;
@@ -296,12 +310,25 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
                     v[2 * t + 1] = q.y;
                 }
                 P acc0 = {(T)0, (T)0}, acc1 = {(T)0, (T)0};
+                if constexpr (sizeof(T) == 4) {
+                    // window element e is one half of the pair it was read in: the instruction's operand select
+                    // feeds that half to both filters, no register moves
+                    P qp[F / 2 + 1];
 #pragma unroll
-                for (int j = 0; j < F; ++j) {
-                    const P v0 = {v[F - 1 - j], v[F - 1 - j]};
-                    const P v1 = {v[F + 1 - j], v[F + 1 - j]};
-                    acc0 = __builtin_elementwise_fma(tp.hg[j], v0, acc0);
-                    acc1 = __builtin_elementwise_fma(tp.hg[j], v1, acc1);
+                    for (int t = 0; t < F / 2 + 1; ++t) qp[t] = P{v[2 * t], v[2 * t + 1]};
+#pragma unroll
+                    for (int j = 0; j < F; ++j) {
+                        acc0 = pk_fma_half((F - 1 - j) & 1, tp.hg[j], qp[(F - 1 - j) >> 1], acc0);
+                        acc1 = pk_fma_half((F + 1 - j) & 1, tp.hg[j], qp[(F + 1 - j) >> 1], acc1);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < F; ++j) {
+                        const P v0 = {v[F - 1 - j], v[F - 1 - j]};
+                        const P v1 = {v[F + 1 - j], v[F + 1 - j]};
+                        acc0 = __builtin_elementwise_fma(tp.hg[j], v0, acc0);
+                        acc1 = __builtin_elementwise_fma(tp.hg[j], v1, acc1);
+                    }
                 }
                 put(i, acc0.x, acc0.y);
                 if (i + 1 < dr.c) put(i + 1, acc1.x, acc1.y);
