@@ -44,3 +44,25 @@ def test_interior_tiles_exist_and_plan_is_in_bounds():
                 assert I[l].c <= ic[l]
         kinds.add(any(G[l].wraps() for l in range(TL + 1)))
     assert kinds == {True, False}
+
+
+@pytest.mark.parametrize("wavelet,n,off,vw", [
+    ("db4", 30000, 0, 4), ("db4", 30001, 4, 4), ("db4", 24577, 3, 4), ("db8", 30000, 8, 4), ("db8", 16401, 0, 4),
+    ("db4", 30000, 2, 2), ("db8", 30000, 1, 2), ("db4", 9, 0, 4), ("db4", 1, 0, 4), ("db8", 2, 5, 4), ("db4", 8200, 0, 4)])
+def test_one_pass_statistics_gather_model(wavelet, n, off, vw):
+    """Index model of the gather pass of the one-pass threshold statistics (oracle/d1_gather_model.py): every
+    finest-band coefficient of a mono block is formed exactly once, through the aligned-piece path in interior
+    tiles and the periodization index elsewhere, and equals the oracle's cD1 - for odd and tiny blocks, both
+    filter lengths, aligned and unaligned block offsets, four and two samples per 16-byte piece."""
+    import d1_gather_model as gm
+    rng = np.random.default_rng(n + 7 * off)
+    buf = rng.standard_normal(off + n + 8)
+    g = orc.filters(wavelet)[1]
+    d, n_direct, n_edge = gm.gather_all(buf, off, n, g, adj=4, vw=vw)
+    want = gm.reference_detail(buf[off:off + n], wavelet)
+    assert d.shape == want.shape and not np.any(np.isnan(d))
+    assert np.max(np.abs(d - want)) <= 1e-12
+    if n >= 3 * 8192 and off % vw == 0:
+        assert n_direct >= 1 and n_edge >= 2            # first and last tile wrap, the middle ones are direct
+    if off % vw:
+        assert n_direct == 0
