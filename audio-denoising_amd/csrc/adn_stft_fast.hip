@@ -1791,14 +1791,31 @@ static int apply_wave(Ctx *c, ApplyArgs<R> a, int64_t n_sig, int64_t Tmax) {
     constexpr int WAVES_PER_CU = sizeof(R) == 8 ? W : (MODE == APPLY_SUBTRACT ? 8 : 12);
     const int64_t out_hops = Tmax - 1;
     if (out_hops <= 0) return ADN_OK;
-    // one round of runs over the waves a full chip holds (measured against two: -3 %); a run pays three warm-up frames (and two
-    // analysis-only frames in SUBTRACT mode), so it is not made shorter than 16 hops
-    int64_t run = ceil_div(n_sig * out_hops, (int64_t)c->num_cus * WAVES_PER_CU * 1);
-    run = run < 16 ? 16 : (run > 1024 ? 1024 : run);
+    // Runs per signal and hops per run.  The waves of a workgroup share one signal's noise / gain row, so a signal
+    // takes a multiple of W runs (runs beyond the signal's end exit at once), and a run pays three warm-up frames
+    // (and two analysis-only frames in SUBTRACT mode), so it is not made shorter than 16 hops.  A batch whose runs
+    // fill the chip's wave slots exactly once is the best case (64 signals of 5624 hops: 32 runs of 176 hops; two
+    // rounds measured 3 % slower); for other batch sizes the rounding to W runs per signal would leave a second,
+    // nearly empty round (96 signals: 24 runs of 264 hops = 2304 waves for 2048 slots, twice the time), so the
+    // number of rounds is chosen with the runs sized to fill them: the fewest hop-steps per wave slot win.
+    const int64_t slots = (int64_t)c->num_cus * WAVES_PER_CU;
+    const int64_t warm = MODE == APPLY_SUBTRACT ? 5 : 3;
+    int64_t run = 0, segs = 0, best = -1;
+    for (int64_t r = 1; r <= 8; ++r) {
+        int64_t sg_try = slots * r / n_sig / W * W;                     // runs per signal that fit r rounds
+        sg_try = sg_try < W ? W : sg_try;
+        int64_t run_try = ceil_div(out_hops, sg_try);
+        run_try = run_try < 16 ? 16 : (run_try > 1024 ? 1024 : run_try);
+        sg_try = ceil_div(ceil_div(out_hops, run_try), (int64_t)W) * W;
+        const int64_t cost = ceil_div(n_sig * sg_try, slots) * (run_try + warm);
+        if (best < 0 || cost < best) {
+            best = cost;
+            run = run_try;
+            segs = sg_try;
+        }
+    }
     a.seg_hops = (int)run;
-    a.segs_per_sig = ceil_div(out_hops, run);
-    // the waves of a workgroup share one signal's noise / gain row (runs beyond the signal's end exit at once)
-    a.segs_per_sig = ceil_div(a.segs_per_sig, (int64_t)W) * W;
+    a.segs_per_sig = segs;
     a.n_sig = n_sig;
     // one 2 KB line that takes the stores of hops which are not stored by the kernel's fast path
     if (c->ws_used + APPLY_WS_BYTES > c->ws_bytes) {
