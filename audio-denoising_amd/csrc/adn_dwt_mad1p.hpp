@@ -5,7 +5,7 @@
 // every frame has one such coefficient, d = w0 * left + w1 * right.  The two medians are nested, so
 // the plain route materialises d and selects twice (three passes over it).  Here:
 //
-//   1. k_m1_sample: a stratified sample of S coefficients per block (runs of 16 consecutive frames)
+//   1. k_m1_sample: a stratified sample of S coefficients per block (runs of 8 consecutive coefficients)
 //      gives (a) a key bracket [lo_m, hi_m] that holds the block's median ranks with probability
 //      ~ 1 - 1e-5 and (b), with m^ = the bracket's midpoint, a value bracket [alo, ahi] for
 //      |d - m^| that holds the ranks of the absolute deviation, widened by the largest possible
@@ -21,7 +21,7 @@
 //      that sample ranks lo and hi hold the same key) gathers nothing: the keys equal to it are
 //      counted, and the counts alone prove the median (and, with the median pinned, the deviation).
 //   6. k_m1_fallback: blocks that fail any check (bracket missed, list or stage overflow, non-finite
-//      data, strongly autocorrelated coefficients for which a run of 16 frames is worth few samples)
+//      data, strongly autocorrelated coefficients for which a run of consecutive coefficients is worth few samples)
 //      are selected exactly by one workgroup streaming the block: one sweep histograms the leading
 //      11 bits of the on-the-fly keys, a second gathers the rank's bin into the block's (now useless)
 //      candidate list, the remaining digits are found there.  Resolved blocks cost it one early exit;
@@ -40,7 +40,8 @@ struct M1 {
     static constexpr double FRAC_A = 0.13;         // ~3.5 % and ~9 % of a Gaussian block
 };
 static constexpr int M1_THREADS = 1024;     // sample / fallback workgroups
-static constexpr int M1_RUN = 16;           // consecutive frames per sample run
+static constexpr int M1_RUN = 8;            // consecutive coefficients per sample run (a 128-byte line holds 16 stereo binary32 frames: shorter runs cost
+                                            // more lines, longer ones are worth fewer samples when the coefficients are autocorrelated)
 static constexpr int M1_BINS = 2048;        // 11-bit digits
 static constexpr int M1_TILE = 4096;        // frames per gather workgroup (256 threads x 16)
 static constexpr int M1_STAGE_M = 1024;     // bracket keys a tile can stage: median list (~3.5 % expected),

@@ -93,7 +93,7 @@ class Workload:
     def __init__(self, eng, clips, dtype, rank):
         self.e, self.B, self.dtype = eng, clips, dtype
         dev = eng.torch_device
-        n, nn = CLIP_S * SR, NOISE_S * SR
+        n, nn = int(round(CLIP_S * SR)), NOISE_S * SR
         self.n, self.nn = n, nn
         # stereo clips, interleaved (frames, 2); generated in fp64 and rounded once
         x = torch.empty((clips, n, 2), dtype=dtype, device=dev)
