@@ -656,7 +656,7 @@ static int denoise_f(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_f
     // (finest-band coefficients formed on the fly, bracket candidates gathered), no coefficient array.  The
     // small bracket sample keeps the per-block sampling cheap; its longer candidate lists must fit LDS.
     constexpr int S_SMALL = 4096, S_LARGE = 16384;
-    const bool want_single = !deep && !d_thresh_given && !(c->ablate & 16);
+    const bool want_single = !deep && !d_thresh_given && !(c->ablate & 512);
     const bool single_small = want_single && mono_single_pass_applicable<T, F, S_SMALL>(c, 0, max_frames);
     const bool single_large = want_single && !single_small && mono_single_pass_applicable<T, F, S_LARGE>(c, g.n_blocks, max_frames);
     if (single_small || single_large) {

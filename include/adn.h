@@ -73,7 +73,7 @@ int adn_synchronize(adn_ctx *ctx);
  *   per-block fallback (independent of ADN_OPT_FORCE_GENERIC).
  * ADN_OPT_ABLATE (diagnostics, results become WRONG): bit mask of stages the fused binary32
  *   STFT kernel skips - 1 analysis, 2 synthesis, 4 overlap-add - so that the cost of each stage
- *   can be timed (the mono tile kernels read bits 1, 2, 4, 8 the same way).  Bit 16 changes no
+ *   can be timed (the mono tile kernels read bits 1, 2, 4, 8 the same way).  Bit 512 changes no
  *   result: mono blocks take their threshold statistics in two passes (finest band written to
  *   memory, two selections on it) instead of one pass over the samples.
  * ADN_OPT_KERNEL_TIMING: record a HIP event pair on the context's stream around every kernel

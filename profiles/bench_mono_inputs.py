@@ -52,7 +52,7 @@ for kind in kinds:
     x = make(kind)
     y = torch.empty_like(x)
     res = {"input": kind, "dtype": str(DT).split(".")[-1], "wavelet": WAVELET, "level": LEVEL}
-    for label, ablate in (("one_pass_ms", 0), ("two_pass_ms", 16)):
+    for label, ablate in (("one_pass_ms", 0), ("two_pass_ms", 512)):
         e._check(e.lib.adn_set_option(e._h, 2, ablate))
         def run():
             e.wavelet_denoise(x, d_off, d_len, y, d_off, n_ch=1, wavelet=WAVELET, level=LEVEL, max_frames=int(lens.max()))

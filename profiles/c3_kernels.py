@@ -5,7 +5,7 @@ from adn_hip import get_engine
 wavelet, level = (sys.argv[1], int(sys.argv[2])) if len(sys.argv) > 2 else ("db4", 2)
 dt = torch.float64 if len(sys.argv) > 3 and sys.argv[3] == "f64" else torch.float32
 e = get_engine(0)
-if os.environ.get("ADN_ABLATE"):              # diagnostics: alternative routes of the mono statistics (16: two passes with the finest band in memory)
+if os.environ.get("ADN_ABLATE"):              # diagnostics: alternative routes of the mono statistics (512: two passes with the finest band in memory)
     e._check(e.lib.adn_set_option(e._h, 2, int(os.environ["ADN_ABLATE"])))
 clips, SR, n = 256, 48000, 30 * 48000
 x = torch.empty(clips * n, dtype=dt, device="cuda")
