@@ -1857,7 +1857,7 @@ static int launch_select_wave(Ctx *c, const T *d_vals, const SelectArgs &a) {
     return ADN_OK;
 }
 
-int64_t select_grouped_limit() { return 96 * 64; }
+int64_t select_grouped_limit() { return 128 * 64; }
 
 template <typename T>
 int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {

@@ -308,3 +308,30 @@ def test_statistics_paths_agree():
                     assert torch.equal(a, b), (str(dt), name)
                 else:
                     assert float((a - b).abs().max()) <= tol, (str(dt), name)
+
+
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
+def test_wiener_and_noise_profile_rows_of_7000_frames(dt):
+    """Files of 65 to 87 s at 48 kHz have 6145 ... 8192 STFT frames: their power rows still take the grouped layout
+    and the register-resident row select (128 keys per lane).  One 75 s mono signal (7030 frames) through the Wiener
+    stage, with and without voice-activity guidance, and as a noise sample through the noise profile, against the
+    oracle; the gain row to 1e-12 in binary64."""
+    e = engine()
+    n = 75 * SR
+    x = synth.noisy_speech(n, SR, 42, 31)
+    npdt = np.float64 if dt == torch.float64 else np.float32
+    xin = x.astype(npdt)
+    for vad in (True, False):
+        y, _, gain = e.wiener(dev(xin, dt), [n], SR, vad_guided=vad, want_gain=True)
+        want, gain_or = orc.wiener(xin.astype(np.float64), SR, vad_guided=vad)
+        if dt == torch.float64:
+            check64(host(y), want)
+            check64(host(gain)[0], gain_or, 1e-12)
+        else:
+            check32(host(y), want)
+    base = host(e.noise_psd(dev(xin, dt), [n]))[0]
+    base_or = orc.noise_profile(xin.astype(np.float64))[0]
+    if dt == torch.float64:
+        check64(base, base_or, 1e-12)
+    else:
+        assert np.max(np.abs(base - base_or)) <= 2e-6 * max(1.0, float(np.max(np.abs(base_or))))
