@@ -1197,10 +1197,28 @@ void k_apply_wave(ApplyArgs<R> a) {
     // the wave index as a scalar: the run's bounds, pointers and counters then live in scalar registers
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane0 = threadIdx.x & 63, tid = threadIdx.x;
     // the waves of a workgroup work on one signal (segs_per_sig is a multiple of W) and share its noise / gain row
-    const int64_t gid = (int64_t)blockIdx.x * W + wave;
-    const int64_t sig = gid / a.segs_per_sig;
-    const int run = (int)(gid % a.segs_per_sig);
-    const bool have_sig = sig < a.n_sig;
+    int64_t sig;
+    int run;
+    bool have_sig;
+    if (a.wg_start != nullptr) {
+        // signals of different lengths: signal s owns workgroups wg_start[s] .. wg_start[s + 1] - 1 (as many as its own
+        // frames need); the grid is sized for the longest signal and the workgroups past the last one do nothing
+        const int b = (int)blockIdx.x, ns = (int)a.n_sig;
+        have_sig = b < a.wg_start[ns];
+        int lo = 0, hi = ns;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (a.wg_start[mid] <= b) lo = mid;
+            else hi = mid;
+        }
+        sig = lo;
+        run = (b - a.wg_start[lo]) * W + wave;
+    } else {
+        const int64_t gid = (int64_t)blockIdx.x * W + wave;
+        sig = gid / a.segs_per_sig;
+        run = (int)(gid % a.segs_per_sig);
+        have_sig = sig < a.n_sig;
+    }
     const R *row = a.row + (have_sig ? sig : 0) * a.row_stride;
     fill_tw_table(twtab, tb.fast_tw, tid, W * 64);
     for (int i = tid; i < 1024; i += W * 64) wtab[i] = tb.window[i];
@@ -1225,9 +1243,10 @@ void k_apply_wave(ApplyArgs<R> a) {
     const int Tn = (int)stft_frames(n, 2048, H, 1);        // frame / hop indices of one signal fit 32 bits
     // output hops are the padded hops j = 2 .. Tn (istft drops n_fft/2 at both ends); hop j is
     // complete once frame min(j, Tn - 1) has been added
-    const int ja = 2 + run * a.seg_hops;
+    const int seg_hops = a.wg_start != nullptr ? a.wg_start[a.n_sig + 1] : a.seg_hops;
+    const int ja = 2 + run * seg_hops;
     if (Tn < 2 || ja > Tn) return;
-    const int jb = (ja + a.seg_hops < Tn + 1) ? ja + a.seg_hops : Tn + 1;            // exclusive
+    const int jb = (ja + seg_hops < Tn + 1) ? ja + seg_hops : Tn + 1;            // exclusive
     const int ta = ja - 3 < 0 ? 0 : ja - 3;                // first frame synthesised (fills the partial hops)
     const int tb_ = jb - 1 < Tn - 1 ? jb - 1 : Tn - 1;     // last frame synthesised
     const R *xs = a.x + a.sg.off[sig];
@@ -1783,6 +1802,122 @@ static size_t apply_lds(int W, int mode, int hop) {
 }  // namespace fast
 
 // hop 512: one wave per run of hops
+// Run length and first workgroup of every signal for the one-wave-per-run kernels.  A signal of h output hops has
+// ceil(h / run) runs (run r starts at output hop 2 + r * run) and takes ceil(runs / W) workgroups.  The host knows
+// only the longest signal; with the lengths at hand the run is sized here so that the runs of all signals together
+// fill whole rounds of the chip's wave slots (the fewest hop-steps per slot win; host_run, sized as if every signal
+// were the longest, is the first candidate and is kept on ties), within the max_wgs workgroups of the launch.
+// wg_start[0 .. n_sig]: first workgroup per signal and their total; wg_start[n_sig + 1]: hops per run.
+// One workgroup, up to APPLY_MAP_MAX signals: signal q * 1024 + tid is thread tid's q-th.
+// Workgroups of a signal of h hops (h < 2^24, exact in binary32), W = 1 << lw, inv ~ 1 / run:
+__device__ __forceinline__ int wg_map_count(int h, int run, float inv, int lw) {
+    int q = (int)((float)h * inv);                  // floor(h / run), off by one at most
+    int r = h - q * run;
+    if (r < 0) { --q; r += run; }
+    if (r >= run) { ++q; r -= run; }
+    q += r > 0;                                     // runs
+    return (q + (1 << lw) - 1) >> lw;               // workgroups
+}
+__global__ __launch_bounds__(1024) void k_apply_wg_map(Signals sg, int n_sig, int host_run, int lw, int slots, int warm,
+                                                       int max_wgs, int *__restrict__ wg_start) {
+    constexpr int PER = APPLY_MAP_MAX / 1024, NC = 25;
+    __shared__ long long part[16][NC + 1];
+    __shared__ long long s_cost[NC];
+    __shared__ int s_cand[NC];
+    __shared__ int wtot[16];
+    __shared__ int s_run;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool wave_has = wave * 64 < n_sig;        // waves past the last signal only take part in the barriers
+    int hops[PER];
+    long long tot = 0;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int s = q * 1024 + tid;
+        hops[q] = 0;
+        if (s < n_sig) {
+            const int64_t Tn = stft_frames(sg.len[s], sg.n_fft, sg.hop, 1);
+            hops[q] = Tn >= 2 ? (int)(Tn - 1) : 0;
+        }
+        tot += hops[q];
+    }
+    if (wave_has) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
+    }
+    if (lane == 0) part[wave][NC] = wave_has ? tot : 0;
+    __syncthreads();
+    long long H = 0;
+    for (int w = 0; w < 16; ++w) H += part[w][NC];
+    if (tid < NC) {                                 // candidate tid: r rounds, with no, half or all of the rounding to W
+        int run = host_run;                         // runs per signal allowed for
+        if (tid > 0) {
+            const int r = 1 + (tid - 1) / 3, v = (tid - 1) % 3;
+            const long long den = (long long)slots * r - (((long long)n_sig << lw) * v >> 1);
+            long long t = den > 0 ? (H + den - 1) / den : 1024;
+            run = (int)(t < 16 ? 16 : (t > 1024 ? 1024 : t));
+        }
+        s_cand[tid] = run;
+    }
+    __syncthreads();
+    if (wave_has) {
+        for (int i = 0; i < NC; ++i) {
+            const int run = s_cand[i];
+            const float inv = __builtin_amdgcn_rcpf((float)run);
+            int g = 0;
+#pragma unroll
+            for (int q = 0; q < PER; ++q)
+                if (q * 1024 < n_sig) g += wg_map_count(hops[q], run, inv, lw);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) g += __shfl_xor(g, d);
+            if (lane == 0) part[wave][i] = g;
+        }
+    } else if (lane == 0) {
+        for (int i = 0; i < NC; ++i) part[wave][i] = 0;
+    }
+    __syncthreads();
+    if (tid < NC) {
+        long long G = 0;
+        for (int w = 0; w < 16; ++w) G += part[w][tid];
+        s_cost[tid] = G > max_wgs ? -1 : (((G << lw) + slots - 1) / slots) * (s_cand[tid] + warm);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        long long best = -1;
+        int run = host_run;
+        for (int i = 0; i < NC; ++i)
+            if (s_cost[i] >= 0 && (best < 0 || s_cost[i] < best)) {
+                best = s_cost[i];
+                run = s_cand[i];
+            }
+        s_run = run;
+    }
+    __syncthreads();
+    const int run = s_run;
+    const float inv = __builtin_amdgcn_rcpf((float)run);
+    int base = 0;
+    for (int q = 0; q < PER && q * 1024 < n_sig; ++q) {
+        const int cnt = wg_map_count(hops[q], run, inv, lw);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        int excl = base + incl - cnt;
+        for (int w = 0; w < wave; ++w) excl += wtot[w];
+        const int s = q * 1024 + tid;
+        if (s < n_sig) wg_start[s] = excl;
+        for (int w = 0; w < 16; ++w) base += wtot[w];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        wg_start[n_sig] = base;
+        wg_start[n_sig + 1] = run;
+    }
+}
+
 template <typename R, int MODE>
 static int apply_wave(Ctx *c, ApplyArgs<R> a, int64_t n_sig, int64_t Tmax) {
     // binary32: eight waves (SUBTRACT, two per SIMD) / four (GAIN, three workgroups per CU); binary64: a wave's
@@ -1822,7 +1957,19 @@ static int apply_wave(Ctx *c, ApplyArgs<R> a, int64_t n_sig, int64_t Tmax) {
         set_error("internal: the caller of the fused STFT kernel did not reserve its scratch line");
         return ADN_ERR_NOMEM;
     }
-    a.dummy = ws_take<R>(c, APPLY_WS_BYTES / sizeof(R));
+    a.dummy = ws_take<R>(c, 4096 / sizeof(R));
+    // signals of different lengths: the runs are sized and handed out on the device, where the lengths are; the launch
+    // is sized for the host's choice (every signal as long as the longest) plus the rounding of one workgroup a signal
+    int *wg_start = ws_take<int>(c, APPLY_MAP_MAX + 2);
+    a.wg_start = nullptr;
+    int64_t wgs = ceil_div(n_sig * a.segs_per_sig, (int64_t)W);
+    if (n_sig > 1 && n_sig <= APPLY_MAP_MAX && wgs + n_sig < (int64_t)0x7FFFFFFF && Tmax < (1 << 24)) {
+        wgs += n_sig;
+        static_assert(W == 4 || W == 8, "the map kernel takes log2(W)");
+        ADN_LAUNCH(k_apply_wg_map, dim3(1), dim3(1024), 0, c->stream, a.sg, (int)n_sig, a.seg_hops, W == 8 ? 3 : 2, (int)slots,
+                   (int)warm, (int)wgs, wg_start);
+        a.wg_start = wg_start;
+    }
     const size_t lds = fast::apply_wave_lds(W, MODE, sizeof(R));
     a.dbg = nullptr;
     if (c->ablate & 16) {       // diagnostics: per-phase cycle totals, printed after the launch
@@ -1832,7 +1979,6 @@ static int apply_wave(Ctx *c, ApplyArgs<R> a, int64_t n_sig, int64_t Tmax) {
     auto kern = a.sg.n_ch == 2 ? (a.dbg ? fast::k_apply_wave<R, W, MODE, 2, true> : fast::k_apply_wave<R, W, MODE, 2, false>)
                                : (a.dbg ? fast::k_apply_wave<R, W, MODE, 1, true> : fast::k_apply_wave<R, W, MODE, 1, false>);
     ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t wgs = ceil_div(n_sig * a.segs_per_sig, (int64_t)W);
     ADN_REQUIRE(wgs < (int64_t)0x7FFFFFFF, "batch too large for one launch");
     ADN_LAUNCH_NAMED((MODE == APPLY_SUBTRACT ? "k_apply_wave<SUBTRACT>" : "k_apply_wave<GAIN>"), kern, dim3((unsigned)wgs),
                      dim3(W * 64), lds, c->stream, a);

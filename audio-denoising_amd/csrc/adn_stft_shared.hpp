@@ -98,12 +98,15 @@ struct ApplyArgs {
     int ablate;          // diagnostics: bit 0 skips the analysis, 1 the synthesis, 2 the overlap-add
     T *dummy;            // 512 writable elements nobody reads (target of stores a kernel issues unconditionally)
     unsigned long long *dbg;   // diagnostics (ablate bit 4): per-phase shader-clock totals of wave 0
+    const int *wg_start;       // one-wave-per-run kernels, optional: first workgroup of every signal, their total, hops per run (n_sig + 2):
+                               // signals then take the workgroups their own length needs instead of segs_per_sig / W each
 };
 
 
 // Workspace the fused apply kernels take beyond what their callers carve out themselves; callers
 // add it to their ws_reserve request.
-static constexpr size_t APPLY_WS_BYTES = 4096;
+static constexpr int APPLY_MAP_MAX = 4096;                 // signals of a batch whose workgroups are mapped by their own lengths
+static constexpr size_t APPLY_WS_BYTES = 4096 + (((size_t)(APPLY_MAP_MAX + 2) * sizeof(int) + 255) & ~(size_t)255);
 
 // register-resident path (binary32, n_fft = 2048)
 bool apply_fast_ok(int n_fft, int hop, int st, int sf);

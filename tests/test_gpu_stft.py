@@ -172,6 +172,41 @@ def test_large_batch_properties():
     assert torch.equal(y1, y[L:2 * L])
 
 
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
+def test_batch_of_mixed_lengths_equals_single_calls(golden, dt):
+    """Signals of different lengths in one call: the fused kernels size the runs of hops from all lengths together and
+    hand every signal the workgroups its own length needs.  Every signal's output must equal, bit for bit, what a call
+    with that signal alone gives (other run boundaries, same arithmetic per hop), for 2b and 2c, and the oracle's
+    for a sample of them - shortest signals (no output hop, one hop), lengths around hop multiples, long ones."""
+    e = engine()
+    nm = _noise_mag(golden)
+    rng = np.random.default_rng(77)
+    lens_in = [2048, 2100, 2559, 2560, 2561, 3072, 4095, 4096, 300000, 2048 + 512 * 177, 2047 + 512 * 178]
+    lens_in += [int(v) for v in rng.integers(2048, 200000, size=29)]
+    order = rng.permutation(len(lens_in))
+    lens_in = [lens_in[i] for i in order]
+    xs = [synth.noisy_speech(n, SR, 42, 100 + i) for i, n in enumerate(lens_in)]
+    flat = dev(np.concatenate(xs), dt)
+    nmd = dev(nm, dt)
+    yb, lb = e.spectral_subtract(flat, lens_in, nmd)
+    yc, lc = e.wiener(flat, lens_in, SR)
+    assert list(lb) == list(lc) == [(e.stft_num_frames(n, 2048, 512) - 1) * 512 for n in lens_in]
+    pos_in = pos = 0
+    for i, n in enumerate(lens_in):
+        xi = flat[pos_in:pos_in + n].clone()
+        L = int(lb[i])
+        y1, _ = e.spectral_subtract(xi, [n], nmd)
+        assert torch.equal(y1, yb[pos:pos + L]), (i, n)
+        w1, _ = e.wiener(xi, [n], SR)
+        assert torch.equal(w1, yc[pos:pos + L]), (i, n)
+        if dt == torch.float64 and i % 8 == 0:
+            check64(host(yb[pos:pos + L]), orc.spectral_subtract(xs[i], nm))
+            check64(host(yc[pos:pos + L]), orc.wiener(xs[i], SR)[0])
+        pos_in += n
+        pos += L
+    assert pos == yb.numel() == yc.numel()
+
+
 def test_generic_fp32_kernels_match_specialised(golden):
     """binary32 / n_fft 2048 normally runs the register-resident kernels; the shape-generic
     LDS kernels must agree with them (and with the oracle) on the same input."""
