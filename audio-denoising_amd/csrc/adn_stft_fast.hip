@@ -1622,7 +1622,8 @@ template <typename R, int W, int NCH, bool VADE>
 __global__ __launch_bounds__(W * 64) __attribute__((amdgpu_waves_per_eu(sizeof(R) == 8 ? 1 : 3, sizeof(R) == 8 ? 1 : 3)))
 void k_rows_wave(const R *__restrict__ x, Signals sg, Tables<R> tb, int64_t n_sig, int64_t runs_per_sig,
                  int groups_per_run, int64_t sig_stride, int power, R *__restrict__ S, R *__restrict__ dummy,
-                 double *__restrict__ vad_e, int64_t frame_len, int64_t nv_max, unsigned long long *__restrict__ sig_max) {
+                 double *__restrict__ vad_e, int64_t frame_len, int64_t nv_max, unsigned long long *__restrict__ sig_max,
+                 const int *__restrict__ wave_start) {
     typedef typename CxOf<R>::type C;
     typedef typename QuadOf<R>::type Q;                    // the four frames of a bin: one store
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1631,13 +1632,32 @@ void k_rows_wave(const R *__restrict__ x, Signals sg, Tables<R> tb, int64_t n_si
     C *twtab = bufs + (size_t)W * WBUF;
     R *wtab = reinterpret_cast<R *>(twtab + TWTAB);                           // [1024] first half of the window
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane0 = threadIdx.x & 63, tid = threadIdx.x;
+    if (wave_start != nullptr && (int64_t)blockIdx.x * W >= wave_start[n_sig]) return;     // the whole workgroup: no run left
     fill_tw_table(twtab, tb.fast_tw, tid, W * 64);
     for (int i = tid; i < 1024; i += W * 64) wtab[i] = tb.window[i];
     __syncthreads();                                       // the only workgroup barrier: every wave reaches it
     const int64_t gid = (int64_t)blockIdx.x * W + wave;
-    const int64_t sig = gid / runs_per_sig;
-    if (sig >= n_sig) return;
-    const int run = (int)(gid % runs_per_sig);
+    int64_t sig;
+    int run;
+    if (wave_start != nullptr) {
+        // signals of different lengths: signal s owns the waves wave_start[s] .. wave_start[s + 1] - 1, one per run of
+        // wave_start[n_sig + 1] groups (both sized on the device from all lengths, see k_apply_wg_map)
+        const int ns = (int)n_sig;
+        if (gid >= wave_start[ns]) return;
+        int lo = 0, hi = ns;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (wave_start[mid] <= (int)gid) lo = mid;
+            else hi = mid;
+        }
+        sig = lo;
+        run = (int)gid - wave_start[lo];
+        groups_per_run = wave_start[ns + 1];
+    } else {
+        sig = gid / runs_per_sig;
+        if (sig >= n_sig) return;
+        run = (int)(gid % runs_per_sig);
+    }
     const int64_t n = sg.len[sig];
     const int Tn = (int)stft_frames(n, 2048, H, sg.padded);
     const int g0 = run * groups_per_run;
@@ -1818,11 +1838,14 @@ __device__ __forceinline__ int wg_map_count(int h, int run, float inv, int lw) {
     q += r > 0;                                     // runs
     return (q + (1 << lw) - 1) >> lw;               // workgroups
 }
+// rows: the statistics kernel's variant - the unit is a group of four frames, W = 1 (a wave per run), and the run is
+// what the host's rule gives for the real total (about two rounds of the wave slots, run_min .. run_max groups);
+// host_run if that does not fit the launch.
 __global__ __launch_bounds__(1024) void k_apply_wg_map(Signals sg, int n_sig, int host_run, int lw, int slots, int warm,
-                                                       int max_wgs, int *__restrict__ wg_start) {
+                                                       int max_wgs, int *__restrict__ wg_start, int rows, int run_min,
+                                                       int run_max) {
     constexpr int PER = APPLY_MAP_MAX / 1024, NC = 25;
     __shared__ long long part[16][NC + 1];
-    __shared__ long long s_cost[NC];
     __shared__ int s_cand[NC];
     __shared__ int wtot[16];
     __shared__ int s_run;
@@ -1835,8 +1858,11 @@ __global__ __launch_bounds__(1024) void k_apply_wg_map(Signals sg, int n_sig, in
         const int s = q * 1024 + tid;
         hops[q] = 0;
         if (s < n_sig) {
-            const int64_t Tn = stft_frames(sg.len[s], sg.n_fft, sg.hop, 1);
-            hops[q] = Tn >= 2 ? (int)(Tn - 1) : 0;
+            // stft_frames() for n_fft 2048 and hop 512, the only shape of the one-wave-per-run kernels, without divisions
+            const int64_t n = sg.len[s];
+            const int64_t nadd = (rows ? sg.padded : 1) ? ((512 - ((n - 2048) & 511)) & 511) : 0;
+            const int64_t Tn = n < 2048 ? 0 : 1 + ((n + nadd - 2048) >> 9);
+            hops[q] = rows ? (int)((Tn + 3) >> 2) : (Tn >= 2 ? (int)(Tn - 1) : 0);
         }
         tot += hops[q];
     }
@@ -1852,44 +1878,58 @@ __global__ __launch_bounds__(1024) void k_apply_wg_map(Signals sg, int n_sig, in
         int run = host_run;                         // runs per signal allowed for
         if (tid > 0) {
             const int r = 1 + (tid - 1) / 3, v = (tid - 1) % 3;
-            const long long den = (long long)slots * r - (((long long)n_sig << lw) * v >> 1);
-            long long t = den > 0 ? (H + den - 1) / den : 1024;
-            run = (int)(t < 16 ? 16 : (t > 1024 ? 1024 : t));
+            const long long den = rows ? 2LL * slots : (long long)slots * r - (((long long)n_sig << lw) * v >> 1);
+            // (binary64 division: exact for these magnitudes up to the rounding of a candidate, and much shorter)
+            long long t = den > 0 ? (long long)ceil((double)H / (double)den) : run_max;
+            run = (int)(t < run_min ? run_min : (t > run_max ? run_max : t));
         }
         s_cand[tid] = run;
     }
     __syncthreads();
+    const int nc = rows ? 2 : NC;
     if (wave_has) {
+        // all candidates side by side: their wave sums are independent chains of cross-lane moves
+        int g[NC];
+#pragma unroll
         for (int i = 0; i < NC; ++i) {
-            const int run = s_cand[i];
-            const float inv = __builtin_amdgcn_rcpf((float)run);
-            int g = 0;
+            g[i] = 0;
+            if (i < nc) {
+                const int run = s_cand[i];
+                const float inv = __builtin_amdgcn_rcpf((float)run);
 #pragma unroll
-            for (int q = 0; q < PER; ++q)
-                if (q * 1024 < n_sig) g += wg_map_count(hops[q], run, inv, lw);
+                for (int q = 0; q < PER; ++q)
+                    if (q * 1024 < n_sig) g[i] += wg_map_count(hops[q], run, inv, lw);
+            }
+        }
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) g += __shfl_xor(g, d);
-            if (lane == 0) part[wave][i] = g;
+        for (int d = 32; d >= 1; d >>= 1)
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+                if (i < nc) g[i] += __shfl_xor(g[i], d);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+                if (i < nc) part[wave][i] = g[i];
         }
     } else if (lane == 0) {
-        for (int i = 0; i < NC; ++i) part[wave][i] = 0;
+        for (int i = 0; i < nc; ++i) part[wave][i] = 0;
     }
     __syncthreads();
-    if (tid < NC) {
-        long long G = 0;
-        for (int w = 0; w < 16; ++w) G += part[w][tid];
-        s_cost[tid] = G > max_wgs ? -1 : (((G << lw) + slots - 1) / slots) * (s_cand[tid] + warm);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        long long best = -1;
-        int run = host_run;
-        for (int i = 0; i < NC; ++i)
-            if (s_cost[i] >= 0 && (best < 0 || s_cost[i] < best)) {
-                best = s_cost[i];
-                run = s_cand[i];
-            }
-        s_run = run;
+    if (wave == 0) {                                // lane i: candidate i; the cheapest wins, the lower index on ties
+        long long key = 0x7FFFFFFFFFFFFFFFLL;
+        if (lane < nc) {
+            long long G = 0;
+            for (int w = 0; w < 16; ++w) G += part[w][lane];
+            const long long rounds = (long long)ceil((double)(G << lw) / (double)slots);
+            const long long cost = rows ? (lane == 0) : rounds * (s_cand[lane] + warm);
+            if (G <= max_wgs) key = (cost << 8) | lane;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const long long o = __shfl_xor(key, d);
+            key = o < key ? o : key;
+        }
+        if (lane == 0) s_run = key == 0x7FFFFFFFFFFFFFFFLL ? host_run : s_cand[(int)(key & 255)];
     }
     __syncthreads();
     const int run = s_run;
@@ -1967,7 +2007,7 @@ static int apply_wave(Ctx *c, ApplyArgs<R> a, int64_t n_sig, int64_t Tmax) {
         wgs += n_sig;
         static_assert(W == 4 || W == 8, "the map kernel takes log2(W)");
         ADN_LAUNCH(k_apply_wg_map, dim3(1), dim3(1024), 0, c->stream, a.sg, (int)n_sig, a.seg_hops, W == 8 ? 3 : 2, (int)slots,
-                   (int)warm, (int)wgs, wg_start);
+                   (int)warm, (int)wgs, wg_start, 0, 16, 1024);
         a.wg_start = wg_start;
     }
     const size_t lds = fast::apply_wave_lds(W, MODE, sizeof(R));
@@ -2073,14 +2113,26 @@ int rows_wave(Ctx *c, const R *d_x, const Signals &sg, const Tables<R> &tb, int6
         set_error("internal: the caller of the rows kernel did not reserve its scratch line");
         return ADN_ERR_NOMEM;
     }
-    R *dummy = ws_take<R>(c, APPLY_WS_BYTES / sizeof(R));
+    R *dummy = ws_take<R>(c, 4096 / sizeof(R));
+    int *wave_start = ws_take<int>(c, APPLY_MAP_MAX + 2);
     const int64_t groups = ceil_div(Tmax, (int64_t)4);
     // about two rounds of runs over the waves a full chip holds
-    int64_t gpr = ceil_div(n_sig * groups, (int64_t)c->num_cus * (sizeof(R) == 8 ? 4 : 12) * 2);
+    const int64_t slots = (int64_t)c->num_cus * (sizeof(R) == 8 ? 4 : 12);
+    int64_t gpr = ceil_div(n_sig * groups, slots * 2);
     gpr = gpr < 4 ? 4 : (gpr > 64 ? 64 : gpr);
     const int64_t runs_per_sig = ceil_div(groups, gpr);
-    const int64_t wgs = ceil_div(n_sig * runs_per_sig, (int64_t)W);
-    ADN_REQUIRE(wgs < (int64_t)0x7FFFFFFF, "batch too large for one launch");
+    int64_t waves = n_sig * runs_per_sig;
+    // signals of different lengths: the run is sized on the device by the same rule from the sum of the lengths
+    // (shorter runs than the longest signal alone suggests), which takes at most this many waves
+    const int64_t waves_dev = (2 * slots > n_sig * ceil_div(groups, (int64_t)64) ? 2 * slots : n_sig * ceil_div(groups, (int64_t)64)) + n_sig;
+    const bool mapped = n_sig > 1 && n_sig <= APPLY_MAP_MAX && Tmax < (1 << 24) && (waves > waves_dev ? waves : waves_dev) < (int64_t)0x7FFFFFFF;
+    if (mapped) {
+        waves = waves > waves_dev ? waves : waves_dev;
+        ADN_LAUNCH(k_apply_wg_map, dim3(1), dim3(1024), 0, c->stream, sg, (int)n_sig, (int)gpr, 0, (int)slots, 0, (int)waves,
+                   wave_start, 1, 4, 64);
+    }
+    const int64_t wgs = ceil_div(waves, (int64_t)W);
+    ADN_REQUIRE(wgs < (int64_t)0x7FFFFFFF / W, "batch too large for one launch");
     const size_t lds = fast::rows_wave_lds(W, sizeof(R));
     // voice-activity energies on the way (vad_e: n_sig x nv_max sums, zero on entry): a voice-activity frame must
     // not be longer than a run, so that at most two runs hold parts of it
@@ -2089,7 +2141,8 @@ int rows_wave(Ctx *c, const R *d_x, const Signals &sg, const Tables<R> &tb, int6
                       : (sg.n_ch == 2 ? fast::k_rows_wave<R, W, 2, false> : fast::k_rows_wave<R, W, 1, false>);
     ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     ADN_LAUNCH_NAMED("k_rows_wave", kern, dim3((unsigned)wgs), dim3(W * 64), lds, c->stream, d_x, sg, tb, n_sig, runs_per_sig,
-                     (int)gpr, sig_stride, power, S, dummy, vad_e, frame_len, nv_max, sig_max);
+                     (int)gpr, sig_stride, power, S, dummy, vad_e, frame_len, nv_max, sig_max,
+                     mapped ? (const int *)wave_start : (const int *)nullptr);
     ADN_HIP(hipGetLastError());
     return ADN_OK;
 }

@@ -202,11 +202,9 @@ int adn_waverec_f32(adn_ctx *ctx, const float *d_coeffs, const int64_t *h_band_l
  * slower element-wise one (spectral subtraction of files packed back to back at
  * odd offsets: 1.7 times the time).  The same holds for the blocks of
  * adn_wavelet_denoise_* (d_in_off / d_out_off).  Files of different lengths
- * may share a call: the fused apply kernels (n_fft 2048, hop 512, up to 4096
- * signals) size their runs on the device from all lengths; the row kernels of
- * the statistics work by max_len, so files of similar lengths remain the best
- * case (20 ... 60 s files in one call: about 1.13 times the time of equal files
- * with the same total audio).
+ * may share a call: the fused kernels (n_fft 2048, hop 512, up to 4096 signals)
+ * size their runs on the device from all lengths (20 ... 60 s files in one
+ * call: about 1.05 times the time of equal files with the same total audio).
  */
 
 /* Phase 1 (src/noise_profile.py:11-14, 57-63): |STFT| with a periodic Hann

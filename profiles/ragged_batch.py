@@ -1,6 +1,6 @@
 """Spectral subtraction and Wiener stage on a batch of mono files of DIFFERENT lengths (uniform in 20 ... 60 s) against a
-batch of equal files with the same total audio (the apply kernels size their runs on the device from all lengths;
-the row kernels of the statistics work by the longest file) - and with files whose start offsets are 16-byte aligned
+batch of equal files with the same total audio (the one-wave-per-run kernels size their runs on the device from all
+lengths, k_apply_wg_map) - and with files whose start offsets are 16-byte aligned
 against files packed back to back (the kernels' 16-byte loads and 8-byte stores need aligned starts)."""
 import os, sys, time
 import numpy as np

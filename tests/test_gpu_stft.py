@@ -176,7 +176,7 @@ def test_large_batch_properties():
 def test_batch_of_mixed_lengths_equals_single_calls(golden, dt):
     """Signals of different lengths in one call: the fused kernels size the runs of hops from all lengths together and
     hand every signal the workgroups its own length needs.  Every signal's output must equal, bit for bit, what a call
-    with that signal alone gives (other run boundaries, same arithmetic per hop), for 2b and 2c, and the oracle's
+    with that signal alone gives (other run boundaries, same arithmetic per hop), for 1, 2b and 2c, and the oracle's
     for a sample of them - shortest signals (no output hop, one hop), lengths around hop multiples, long ones."""
     e = engine()
     nm = _noise_mag(golden)
@@ -190,6 +190,8 @@ def test_batch_of_mixed_lengths_equals_single_calls(golden, dt):
     nmd = dev(nm, dt)
     yb, lb = e.spectral_subtract(flat, lens_in, nmd)
     yc, lc = e.wiener(flat, lens_in, SR)
+    pb = e.noise_psd(flat, lens_in)                 # the statistics rows alone (phase 1), padded and unpadded frames
+    pu = e.noise_psd(flat, lens_in, padded=False)
     assert list(lb) == list(lc) == [(e.stft_num_frames(n, 2048, 512) - 1) * 512 for n in lens_in]
     pos_in = pos = 0
     for i, n in enumerate(lens_in):
@@ -199,6 +201,8 @@ def test_batch_of_mixed_lengths_equals_single_calls(golden, dt):
         assert torch.equal(y1, yb[pos:pos + L]), (i, n)
         w1, _ = e.wiener(xi, [n], SR)
         assert torch.equal(w1, yc[pos:pos + L]), (i, n)
+        assert torch.equal(e.noise_psd(xi, [n])[0], pb[i]), (i, n)
+        assert torch.equal(e.noise_psd(xi, [n], padded=False)[0], pu[i]), (i, n)
         if dt == torch.float64 and i % 8 == 0:
             check64(host(yb[pos:pos + L]), orc.spectral_subtract(xs[i], nm))
             check64(host(yc[pos:pos + L]), orc.wiener(xs[i], SR)[0])
