@@ -211,6 +211,31 @@ def test_batch_of_mixed_lengths_equals_single_calls(golden, dt):
     assert pos == yb.numel() == yc.numel()
 
 
+def test_batch_of_1500_short_files_equals_its_halves(golden):
+    """More than 1024 signals in one call (the device-side run map walks them in blocks of 1024): the outputs equal,
+    bit for bit, those of the two halves of the batch processed on their own, and a sample equals single calls."""
+    e = engine()
+    nmd = dev(_noise_mag(golden), torch.float32)
+    rng = np.random.default_rng(5)
+    lens_in = [int(v) for v in rng.integers(2048, 9000, size=1500)]
+    flat = e.synth_noisy_speech(sum(lens_in), SR, stream=61).to(torch.float32)
+    half = 750
+    n_half = sum(lens_in[:half])
+    yb, lb = e.spectral_subtract(flat, lens_in, nmd)
+    yc, lc = e.wiener(flat, lens_in, SR)
+    pb = e.noise_psd(flat, lens_in)
+    parts = [(flat[:n_half].clone(), lens_in[:half]), (flat[n_half:].clone(), lens_in[half:])]
+    assert torch.equal(yb, torch.cat([e.spectral_subtract(x, l, nmd)[0] for x, l in parts]))
+    assert torch.equal(yc, torch.cat([e.wiener(x, l, SR)[0] for x, l in parts]))
+    assert torch.equal(pb, torch.cat([e.noise_psd(x, l) for x, l in parts]))
+    off_in = np.concatenate([[0], np.cumsum(lens_in)])
+    off_out = np.concatenate([[0], np.cumsum(lb)])
+    for i in (0, 1023, 1024, 1025, 1499):
+        xi = flat[off_in[i]:off_in[i + 1]].clone()
+        assert torch.equal(e.spectral_subtract(xi, [lens_in[i]], nmd)[0], yb[off_out[i]:off_out[i + 1]]), i
+        assert torch.equal(e.wiener(xi, [lens_in[i]], SR)[0], yc[off_out[i]:off_out[i + 1]]), i
+
+
 def test_generic_fp32_kernels_match_specialised(golden):
     """binary32 / n_fft 2048 normally runs the register-resident kernels; the shape-generic
     LDS kernels must agree with them (and with the oracle) on the same input."""
