@@ -1845,12 +1845,12 @@ __global__ __launch_bounds__(1024) void k_apply_wg_map(Signals sg, int n_sig, in
                                                        int max_wgs, int *__restrict__ wg_start, int rows, int run_min,
                                                        int run_max) {
     constexpr int PER = APPLY_MAP_MAX / 1024, NC = 25;
-    __shared__ long long part[16][NC + 1];
+    __shared__ int s_hops[APPLY_MAP_MAX];
+    __shared__ long long s_tot[16], s_G[NC];
     __shared__ int s_cand[NC];
     __shared__ int wtot[16];
     __shared__ int s_run;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool wave_has = wave * 64 < n_sig;        // waves past the last signal only take part in the barriers
     int hops[PER];
     long long tot = 0;
 #pragma unroll
@@ -1863,19 +1863,20 @@ __global__ __launch_bounds__(1024) void k_apply_wg_map(Signals sg, int n_sig, in
             const int64_t nadd = (rows ? sg.padded : 1) ? ((512 - ((n - 2048) & 511)) & 511) : 0;
             const int64_t Tn = n < 2048 ? 0 : 1 + ((n + nadd - 2048) >> 9);
             hops[q] = rows ? (int)((Tn + 3) >> 2) : (Tn >= 2 ? (int)(Tn - 1) : 0);
+            s_hops[s] = hops[q];
         }
         tot += hops[q];
     }
-    if (wave_has) {
+    if (wave * 64 < n_sig) {                        // (waves past the last signal hold zeros)
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
     }
-    if (lane == 0) part[wave][NC] = wave_has ? tot : 0;
+    if (lane == 0) s_tot[wave] = tot;
     __syncthreads();
-    long long H = 0;
-    for (int w = 0; w < 16; ++w) H += part[w][NC];
     if (tid < NC) {                                 // candidate tid: r rounds, with no, half or all of the rounding to W
-        int run = host_run;                         // runs per signal allowed for
+        long long H = 0;                            // runs per signal allowed for
+        for (int w = 0; w < 16; ++w) H += s_tot[w];
+        int run = host_run;
         if (tid > 0) {
             const int r = 1 + (tid - 1) / 3, v = (tid - 1) % 3;
             const long long den = rows ? 2LL * slots : (long long)slots * r - (((long long)n_sig << lw) * v >> 1);
@@ -1886,40 +1887,22 @@ __global__ __launch_bounds__(1024) void k_apply_wg_map(Signals sg, int n_sig, in
         s_cand[tid] = run;
     }
     __syncthreads();
+    // the workgroup total of every candidate: the waves share the candidates, a wave's lanes the signals
     const int nc = rows ? 2 : NC;
-    if (wave_has) {
-        // all candidates side by side: their wave sums are independent chains of cross-lane moves
-        int g[NC];
+    for (int i = wave; i < nc; i += 16) {
+        const int run = s_cand[i];
+        const float inv = __builtin_amdgcn_rcpf((float)run);
+        long long g = 0;
+        for (int s = lane; s < n_sig; s += 64) g += wg_map_count(s_hops[s], run, inv, lw);
 #pragma unroll
-        for (int i = 0; i < NC; ++i) {
-            g[i] = 0;
-            if (i < nc) {
-                const int run = s_cand[i];
-                const float inv = __builtin_amdgcn_rcpf((float)run);
-#pragma unroll
-                for (int q = 0; q < PER; ++q)
-                    if (q * 1024 < n_sig) g[i] += wg_map_count(hops[q], run, inv, lw);
-            }
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1)
-#pragma unroll
-            for (int i = 0; i < NC; ++i)
-                if (i < nc) g[i] += __shfl_xor(g[i], d);
-        if (lane == 0) {
-#pragma unroll
-            for (int i = 0; i < NC; ++i)
-                if (i < nc) part[wave][i] = g[i];
-        }
-    } else if (lane == 0) {
-        for (int i = 0; i < nc; ++i) part[wave][i] = 0;
+        for (int d = 32; d >= 1; d >>= 1) g += __shfl_xor(g, d);
+        if (lane == 0) s_G[i] = g;
     }
     __syncthreads();
     if (wave == 0) {                                // lane i: candidate i; the cheapest wins, the lower index on ties
         long long key = 0x7FFFFFFFFFFFFFFFLL;
         if (lane < nc) {
-            long long G = 0;
-            for (int w = 0; w < 16; ++w) G += part[w][lane];
+            const long long G = s_G[lane];
             const long long rounds = (long long)ceil((double)(G << lw) / (double)slots);
             const long long cost = rows ? (lane == 0) : rounds * (s_cand[lane] + warm);
             if (G <= max_wgs) key = (cost << 8) | lane;
