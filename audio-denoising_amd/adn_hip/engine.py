@@ -218,6 +218,26 @@ class Engine:
         return y[:n_out.value].clone()
 
     # ------------------------------------------------------------ STFT stages
+    @staticmethod
+    def pack_signals(signals, n_ch=1, device=None):
+        """Put files of any lengths into one flat buffer for a batched call, every file starting at a 16-byte
+        aligned address (the fused kernels' 16-byte loads need that; files packed back to back at odd offsets take
+        an element-wise path that costs 1.7 times the time).  signals: tensors of the same dtype, (frames,) or
+        (frames, n_ch) each.  Returns (flat, lens, offsets): pass `lens` (frames per file) and `offsets=offsets`
+        (element offsets) to the stage methods.  The gaps between files are zero."""
+        dtype = signals[0].dtype
+        device = signals[0].device if device is None else device
+        per = 16 // signals[0].element_size()
+        lens = np.array([int(s.shape[0]) for s in signals], dtype=np.int64)
+        sizes = (lens * n_ch + per - 1) // per * per
+        offsets = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        flat = torch.zeros(int(sizes.sum()), dtype=dtype, device=device)
+        for s, off in zip(signals, offsets):
+            if s.dtype != dtype or s.numel() != s.shape[0] * n_ch:
+                raise ValueError("signals must share a dtype and hold n_ch values per frame")
+            flat[int(off):int(off) + s.numel()] = s.reshape(-1).to(device)
+        return flat, lens, offsets
+
     def _signals(self, lens, n_ch, n_fft):
         lens = np.asarray(lens, dtype=np.int64)
         if (lens < n_fft).any():
