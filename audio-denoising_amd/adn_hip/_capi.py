@@ -15,6 +15,7 @@ EXT = {"per": 0, "periodization": 0, "sym": 1, "symmetric": 1}
 THR = {"soft": 0, "hard": 1}
 AXIS = {"reference": 0, "time": 1}
 NOALLOC_SCRATCH_BYTES = 32 << 20
+ABI_VERSION = 3            # ADN_ABI_VERSION of the include/adn.h this binding was written against
 MASK = {"soft": 0, "hard": 1, "binary": 2}
 
 _vp, _i, _i64, _d, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_uint64
@@ -23,6 +24,7 @@ _vp, _i, _i64, _d, _u64 = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_uint64
 _PLAIN = {
     "adn_last_error": (C.c_char_p, []),
     "adn_version": (_i, []),
+    "adn_abi_version": (_i, []),
     "adn_create": (_i, [C.POINTER(_vp), _i]),
     "adn_destroy": (_i, [_vp]),
     "adn_set_stream": (_i, [_vp, _vp]),
@@ -88,6 +90,9 @@ def load(path=LIB_PATH):
         for suf in ("_f32", "_f64"):
             fn = getattr(lib, base + suf)
             fn.restype, fn.argtypes = _i, args
+    if lib.adn_abi_version() != ABI_VERSION:
+        raise ImportError("%s has ABI version %d, this binding expects %d: rebuild the library"
+                          % (path, lib.adn_abi_version(), ABI_VERSION))
     return lib
 
 

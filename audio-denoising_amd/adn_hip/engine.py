@@ -86,6 +86,9 @@ class Engine:
         (synchronises the stream)."""
         buf = C.create_string_buffer(1 << 16)
         n = int(self.lib.adn_kernel_times(self._h, buf, len(buf)))
+        if n < -1:                                   # too small: the library kept the records, -n bytes hold them
+            buf = C.create_string_buffer(-n)
+            n = int(self.lib.adn_kernel_times(self._h, buf, len(buf)))
         if n < 0:
             raise AdnError(n, "adn_kernel_times failed")
         out = {}

@@ -201,13 +201,19 @@ class SpreadPipeline:
     def spectral_subtract(self, x_local, ranges, noise_mag, **kw):
         """x_local: this rank's range of the stage's input (ranges: every rank's).  Returns (y_local, ranges_out)."""
         e = self.e
+        if kw.get("n_fft", NFFT) != NFFT or kw.get("hop", HOP) != HOP:
+            raise ValueError("a recording spread over ranks is cut at multiples of hop %d for n_fft %d: other STFT "
+                             "shapes are not supported here" % (HOP, NFFT))
+        # frames on either side that the time smoothing of a frame reads (src/spectral_subtract.py:39-43:
+        # uniform_filter over smooth_time frames): the sub-call's halo must hold them
+        reach = (int(kw.get("smooth_time", 3)) - 1) // 2
         n_in = ranges[-1][1]
         out_ranges, frames, _ = self._out_ranges(ranges, n_in)
         sig = SpreadSignal(x_local, ranges, self.rank, self.group)
 
         def win(r):
             a, b = out_ranges[r]
-            return ck.stft_chunk_window(a // HOP, b // HOP, frames, n_in) if b > a else None
+            return ck.stft_chunk_window(a // HOP, b // HOP, frames, n_in, reach=reach) if b > a else None
 
         (sub,) = sig.fetch(lambda r: [win(r)[:2]] if win(r) else []) or (None,)
         a, b = out_ranges[self.rank]

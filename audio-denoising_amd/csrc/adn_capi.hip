@@ -112,6 +112,8 @@ extern "C" {
 
 const char *adn_last_error(void) { return adn::g_err; }
 
+int adn_abi_version(void) { return ADN_ABI_VERSION; }
+
 int adn_version(void) { return 100; }
 
 int adn_create(adn_ctx **out, int device) {
@@ -197,14 +199,14 @@ int64_t adn_kernel_times(adn_ctx *c, char *buf, int64_t cap) {
         total[i] += ms;
         count[i] += 1;
     }
-    adn::drop_kernel_records(c);
     std::string out;
     char line[384];
     for (size_t i = 0; i < names.size(); ++i) {
         snprintf(line, sizeof(line), "%s\t%lld\t%.6f\n", names[i], count[i], total[i]);
         out += line;
     }
-    if ((int64_t)out.size() + 1 > cap) return -(int64_t)(out.size() + 1);
+    if ((int64_t)out.size() + 1 > cap) return -(int64_t)(out.size() + 1);     // the records stay: call again with room
+    adn::drop_kernel_records(c);
     memcpy(buf, out.c_str(), out.size() + 1);
     return (int64_t)out.size();
 }

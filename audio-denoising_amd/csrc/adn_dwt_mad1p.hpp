@@ -1025,25 +1025,23 @@ static int64_t m1_cap(int64_t max_count, double frac) {
     const int64_t whole = max_count < Src::S ? max_count : Src::S;
     return want > whole ? want : whole;
 }
-// Which batches take the single-pass route (max_count: coefficients of the longest block).  Its sampling
-// and its list selections run one workgroup per block: with lists that fit LDS (stereo blocks up to ~299 K
-// frames in binary32, ~145 K in binary64) that is fast for any number of blocks; longer lists (blocks up to
-// about a million frames) are selected in memory, which pays only when there are enough blocks to fill the
-// GPU (measured: 704 blocks of 864 K frames 4.4 ms against 13.4 ms of the plain route, 80 blocks of 2.9 M
-// frames 3.2 against 1.8 ms).
+// Which batches take the single-pass route (max_count: coefficients of the longest block).  Its sampling runs one
+// workgroup per block; lists that fit LDS (stereo blocks up to ~299 K frames in binary32, ~145 K in binary64) are
+// selected there, longer lists are bracketed again first (select_subset_ws_bytes).
 template <typename T, typename Src>
 static bool m1_src_applicable(const Ctx *c, int64_t n_blocks, int64_t max_count) {
     const size_t kb = sizeof(typename KeyT<T>::type);
     const size_t cap = (size_t)m1_cap<T, Src>(max_count, Src::FRAC_A);
-    return !c->force_generic && max_count < (int64_t(1) << 30) &&
-           (cap <= select_subset_lds_keys(kb) || (n_blocks >= c->num_cus && cap <= select_subset_max_keys(kb)));
+    return !c->force_generic && max_count < (int64_t(1) << 30) && cap <= select_subset_max_keys(kb);
 }
 template <typename T, typename Src>
 static size_t m1_src_ws_bytes(int64_t n_blocks, int64_t max_count) {
     const size_t nb = (size_t)n_blocks;
     return ws_need(nb, sizeof(M1State)) + ws_need(nb * (size_t)m1_cap<T, Src>(max_count, Src::FRAC_M), sizeof(T)) +
            ws_need(nb * (size_t)m1_cap<T, Src>(max_count, Src::FRAC_A), sizeof(T)) + 5 * ws_need(nb, 8) + 3 * ws_need(nb, 4) +
-           3 * ws_need(nb, 8) + ws_need(2 * nb, 8);
+           3 * ws_need(nb, 8) + ws_need(2 * nb, 8) +
+           select_subset_ws_bytes(n_blocks, m1_cap<T, Src>(max_count, Src::FRAC_M), sizeof(typename KeyT<T>::type)) +
+           select_subset_ws_bytes(n_blocks, m1_cap<T, Src>(max_count, Src::FRAC_A), sizeof(typename KeyT<T>::type));
 }
 template <typename T>
 static bool m1_applicable(const Ctx *c, int64_t n_blocks, int64_t max_frames) {
@@ -1110,6 +1108,36 @@ static int mad_single_pass(Ctx *c, const T *d_in, const BlockGeom &g, int64_t ma
     ADN_LAUNCH((k_m1_fallback<T, Src>), dim3((unsigned)g.n_blocks), dim3(M1_THREADS), 0, c->stream, d_in, g, src, st,
                        resolved, valid_a, pair_a, med, mad, thresh, d_sigma_out, d_thresh_out, cand_a, cap_a);
     ADN_HIP(hipGetLastError());
+    if (c->ablate & 2048) {      // diagnostics: which blocks went to the exact fallback, and why (synchronises)
+        ADN_HIP(hipStreamSynchronize(c->stream));
+        std::vector<M1State> hs(nb);
+        std::vector<int> hvm(nb), hva(nb), hres(nb);
+        std::vector<double> hmed(nb), hpair(2 * nb);
+        std::vector<int64_t> hcnt(nb);
+        ADN_HIP(hipMemcpy(hs.data(), st, nb * sizeof(M1State), hipMemcpyDeviceToHost));
+        ADN_HIP(hipMemcpy(hvm.data(), valid_m, nb * sizeof(int), hipMemcpyDeviceToHost));
+        ADN_HIP(hipMemcpy(hva.data(), valid_a, nb * sizeof(int), hipMemcpyDeviceToHost));
+        ADN_HIP(hipMemcpy(hres.data(), resolved, nb * sizeof(int), hipMemcpyDeviceToHost));
+        ADN_HIP(hipMemcpy(hmed.data(), med, nb * sizeof(double), hipMemcpyDeviceToHost));
+        ADN_HIP(hipMemcpy(hpair.data(), pair_a, 2 * nb * sizeof(double), hipMemcpyDeviceToHost));
+        ADN_HIP(hipMemcpy(hcnt.data(), counts, nb * sizeof(int64_t), hipMemcpyDeviceToHost));
+        size_t shown = 0;
+        for (size_t b = 0; b < nb && shown < 24; ++b) {
+            const M1State &m = hs[b];
+            const double eps_t = sizeof(T) == 4 ? 1.1920929e-7 : 2.220446049250313e-16;
+            const double cc = (double)(T)hmed[b];
+            const double span = fabs(hpair[2 * b + 1]) + fabs(cc) + fabs(m.mhat) + (m.ahi <= 1.7e308 ? fabs(m.ahi) : 0.0);
+            const double e = fabs(cc - m.mhat) * (1.0 + 4.0 * eps_t) + 8.0 * eps_t * span + 1e-300;
+            const bool ver = (m.alo < 0.0 || hpair[2 * b] > m.alo + e) && (!(m.ahi <= 1.7e308) || hpair[2 * b + 1] < m.ahi - e) &&
+                             hpair[2 * b] == hpair[2 * b] && hpair[2 * b + 1] == hpair[2 * b + 1];
+            if (hres[b] || (hva[b] && ver)) continue;
+            ++shown;
+            fprintf(stderr, "m1 block %zu: n %lld usable %d nan %d spill %d tie %d/%d n_m %u (cap %lld) below_m %llu n_a %u (cap %lld) below_a %llu "
+                            "valid %d/%d med %.9g mhat %.9g alo %.9g ahi %.9g pair %.9g %.9g\n", b, (long long)hcnt[b], m.usable,
+                    m.has_nan, m.spill, m.tie_m, m.tie_a, m.n_m, (long long)cap_m, m.below_m, m.n_a, (long long)cap_a, m.below_a,
+                    hvm[b], hva[b], hmed[b], m.mhat, m.alo, m.ahi, hpair[2 * b], hpair[2 * b + 1]);
+        }
+    }
     *thresh_ws = thresh;
     return ADN_OK;
 }

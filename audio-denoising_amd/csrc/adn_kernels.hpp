@@ -45,8 +45,8 @@ struct SelectArgs {
     // quad_stride == 1: plain contiguous segments (the fields above)
     int64_t quad_stride = 1, blk_rows = 1, blk_sig_stride = 0;
 };
-// longest row of the grouped layout launch_select takes
-int64_t select_grouped_limit();
+// longest row of the grouped layout launch_select takes (values of value_bytes bytes)
+int64_t select_grouped_limit(size_t value_bytes);
 // longest segment launch_select handles inside one workgroup (longer ones take the
 // multi-workgroup path, which has no fused masked mean)
 int64_t select_short_limit();
@@ -62,7 +62,8 @@ size_t select_ws_bytes(int64_t n_seg, int64_t max_len);
 // Median of segments of which only a gathered SUBSET is at hand (the keys inside a value bracket): list s holds
 // d_len[s] keys at d_cand + s * cap; the ranks are those of the original segment (d_orig_len[s] keys) minus
 // d_below[s], the number of its keys below the bracket.  Lists with d_valid[s] == 0 are skipped (d_out untouched).
-// cap <= select_subset_max_keys(sizeof key); lists that fit LDS are staged there whole.
+// cap <= select_subset_max_keys(sizeof key); lists that fit LDS are staged there whole, longer ones are bracketed
+// again until they do (the caller reserves select_subset_ws_bytes of workspace per call for that).
 struct SubsetSelect {
     int64_t n_seg = 0, cap = 0;
     const int64_t *d_len = nullptr, *d_orig_len = nullptr;
@@ -77,6 +78,7 @@ template <typename T>
 int launch_select_subset(Ctx *c, const T *d_cand, const SubsetSelect &a);
 size_t select_subset_max_keys(size_t key_bytes);
 size_t select_subset_lds_keys(size_t key_bytes);   // lists up to this length are staged in LDS
+size_t select_subset_ws_bytes(int64_t n_seg, int64_t cap, size_t key_bytes);
 
 // -------------------------------------------------------------- wavelets
 template <typename T>

@@ -1089,6 +1089,23 @@ __global__ __launch_bounds__(256) void k_big_gather(const T *__restrict__ vals, 
     const T *v = vals + (seg_off ? seg_off[seg] : seg * seg_stride);
     const T c = XF == XF_ABSDEV ? (T)center[seg] : (T)0;
     T *dst = cand + seg * cap;
+    if (lo == 0 && hi == ~(K)0) {
+        // a short list that passes through this level whole (k_big_sample): copied in place, no staging (a tile of
+        // such a list holds more keys than the stage)
+        const int64_t i1 = i0 + GATHER_TILE < n ? i0 + GATHER_TILE : n;
+        bool nan_here = false, over = false;
+        for (int64_t i = i0 + tid; i < i1; i += 256) {
+            T x = v[i];
+            if (XF == XF_ABSDEV) x = fabs(x - c);
+            nan_here |= x != x;
+            if (i < cap) dst[i] = x;
+            else over = true;
+        }
+        if (nan_here) st[seg].has_nan = 1;
+        if (over) st[seg].overflow = 1;
+        if (tid == 0) atomicAdd(&st[seg].n_cand, (unsigned int)(i1 - i0));
+        return;
+    }
     unsigned int below = 0;
     bool saw_nan = false, spilled = false;
     // batches of BATCH elements per thread: all loads of a batch are in flight together, the
@@ -1585,8 +1602,13 @@ template <> struct Quad4<float> { typedef float4 type; };
 template <> struct Quad4<double> { typedef double4 type; };
 
 // T: binary32 (keys of 32 bits, three waves per SIMD up to 96 keys per lane) or binary64 (64-bit keys: twice the registers)
-template <typename T, int XF, bool MASKED, int KPL>
-__global__ __launch_bounds__(256)
+//
+// NW > 1: a row longer than one wave's registers is shared by the NW waves of a workgroup (one row per workgroup).
+// Wave w holds quads w * KPL / 4 * 64 ... of the row; every count of the search is the sum of the waves' counts,
+// exchanged through LDS with one barrier per decided bit (all waves take the same decisions); once the candidates
+// fit SEL_CK registers per lane every wave holds all of them and finishes the search alone.
+template <typename T, int XF, bool MASKED, int KPL, int NW = 1>
+__global__ __launch_bounds__(NW <= 4 ? 256 : NW * 64)
 __attribute__((amdgpu_waves_per_eu(sizeof(T) == 8 ? (KPL <= 96 ? 2 : 1) : (KPL <= 88 ? 4 : (KPL <= 96 ? 3 : 2)))))
 void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_off,
                                                      int64_t seg_stride, const int64_t *__restrict__ seg_len,
@@ -1604,9 +1626,56 @@ void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_o
     // must meet in one L2, and consecutive workgroups go to different XCDs: workgroup b (XCD b mod 8) takes the
     // rows of logical workgroup ((b / 16) * 8 + b mod 8) * 2 + (b / 8) mod 2.
     int64_t wg = blockIdx.x;
-    if (quad_stride != 1 && (int64_t)gridDim.x % 16 == 0) wg = ((wg >> 4) * 8 + (wg & 7)) * 2 + ((wg >> 3) & 1);
-    const int64_t seg = wg * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int64_t seg;
+    if (NW == 1) {
+        if (quad_stride != 1 && (int64_t)gridDim.x % 16 == 0) wg = ((wg >> 4) * 8 + (wg & 7)) * 2 + ((wg >> 3) & 1);
+        seg = wg * 4 + wave;
+    } else {
+        // one row per workgroup: the eight rows that share 128-byte lines go to workgroups b, b + 8, ..., b + 56
+        // (one XCD) of a block of 64 workgroups
+        if (quad_stride != 1 && (int64_t)gridDim.x % 64 == 0) wg = ((wg >> 6) << 6) + ((wg & 7) << 3) + ((wg >> 3) & 7);
+        seg = wg;
+    }
+    const int wv = NW == 1 ? 0 : wave;                      // this wave's slice of the row
     if (seg >= n_seg) return;
+    // exchange between the waves of a row (NW > 1).  Sums and minima: every wave adds to / lowers one LDS word, a
+    // barrier, every wave reads the word; three words used in turn, the next one cleared by the call before, so that
+    // one barrier per exchange is enough (a wave can be at most one exchange ahead of the slowest).
+    __shared__ unsigned long long sh_min[3], sh_a[NW], sh_b[NW], sh_m[NW];
+    __shared__ uint32_t sh_sum[3], sh_c[NW], sh_d[NW];
+    __shared__ uint32_t sh_ctr;
+    __shared__ K cbuf_all[NW == 1 ? 4 : 1][SEL_CK * 64];
+    int turn = 0;
+    if (NW > 1 && threadIdx.x == 0) {
+        sh_ctr = 0;
+        sh_sum[0] = 0;
+        sh_min[0] = ~0ull;
+    }
+    auto next_turn = [&]() {
+        const int nxt = turn == 2 ? 0 : turn + 1;
+        if (threadIdx.x == 0) {
+            sh_sum[nxt] = 0;
+            sh_min[nxt] = ~0ull;
+        }
+        return nxt;
+    };
+    auto wg_sum = [&](uint32_t v) -> uint32_t {             // v: one value per wave
+        const int nxt = next_turn();
+        if (lane == 0) atomicAdd(&sh_sum[turn], v);
+        __syncthreads();
+        const uint32_t sum = sh_sum[turn];
+        turn = nxt;
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)sum);
+    };
+    auto wg_min = [&](K v) -> K {
+        const int nxt = next_turn();
+        if (lane == 0) atomicMin(&sh_min[turn], (unsigned long long)v);
+        __syncthreads();
+        const K m = (K)sh_min[turn];
+        turn = nxt;
+        return m;
+    };
     const int n = (int)(seg_len ? seg_len[seg / len_div] : uniform_len);
     if (n <= 0) {
         if (lane == 0) {
@@ -1662,7 +1731,7 @@ void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_o
         const Q4 *vv = reinterpret_cast<const Q4 *>(vrow);
         const uint32_t *mv = reinterpret_cast<const uint32_t *>(mrow);
         const int jt = 4 * nq + lane;                       // tail element of lanes 0..2
-        const bool tail = lane < 3 && jt < n;
+        const bool tail = wv == 0 && lane < 3 && jt < n;
         const T xt = vrow[tail ? (size_t)nq * 4 * qs + lane : 0];
         const unsigned mt = MASKED ? mrow[tail ? jt : 0] : 0u;
 #pragma unroll
@@ -1672,7 +1741,7 @@ void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_o
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < QB; ++i) {
-                const uint32_t j = (uint32_t)lane + 64u * (uint32_t)(b0 + i);
+                const uint32_t j = (uint32_t)lane + 64u * (uint32_t)(b0 + i + wv * (KPL / 4));
                 const uint32_t js = j < (uint32_t)nq ? j : (uint32_t)nq - 1u;
                 xq[i] = vv[js * qs];
                 mq[i] = MASKED ? mv[js] : 0u;
@@ -1680,7 +1749,7 @@ void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_o
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < QB; ++i) {
-                const bool valid = lane + 64 * (b0 + i) < nq;
+                const bool valid = lane + 64 * (b0 + i + wv * (KPL / 4)) < nq;
                 take(4 * (b0 + i) + 0, xq[i].x, mq[i] & 0xFF, valid);
                 take(4 * (b0 + i) + 1, xq[i].y, (mq[i] >> 8) & 0xFF, valid);
                 take(4 * (b0 + i) + 2, xq[i].z, (mq[i] >> 16) & 0xFF, valid);
@@ -1696,14 +1765,14 @@ void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_o
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < SB; ++i) {
-                const uint32_t j = (uint32_t)lane + 64u * (uint32_t)(b0 + i);
+                const uint32_t j = (uint32_t)lane + 64u * (uint32_t)(b0 + i + wv * KPL);
                 const uint32_t js = j < (uint32_t)n ? j : (uint32_t)n - 1u;
                 xs[i] = vrow[js];
                 ms[i] = MASKED ? mrow[js] : 0u;
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < SB; ++i) take(b0 + i, xs[i], ms[i], lane + 64 * (b0 + i) < n);
+            for (int i = 0; i < SB; ++i) take(b0 + i, xs[i], ms[i], lane + 64 * (b0 + i + wv * KPL) < n);
         }
         key[KPL] = KEY_MAX;
     }
@@ -1717,10 +1786,46 @@ void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_o
             mcnt += __shfl_xor(mcnt, d);
         }
     }
-    const bool any_nan = __ballot(saw_nan) != 0;
-    if (MASKED && lane == 0) mm.out[seg] = (double)(msum / (T)(mcnt > 1 ? mcnt : 1));
+    bool any_nan = __ballot(saw_nan) != 0;
+    if (NW > 1) {
+        // every wave leaves its partial results in its own slot; lane w of every wave then takes wave w's and the
+        // lanes combine them in a fixed order (the masked sum must not depend on which wave arrives first)
+        if (lane == 0) {
+            sh_a[wv] = (unsigned long long)kmin;
+            sh_b[wv] = (unsigned long long)kmax;
+            sh_c[wv] = any_nan ? 1u : 0u;
+            if (MASKED) {
+                sh_d[wv] = (uint32_t)mcnt;
+                sh_m[wv] = sizeof(T) == 8 ? (unsigned long long)__double_as_longlong((double)msum)
+                                          : (unsigned long long)__float_as_uint((float)msum);
+            }
+        }
+        __syncthreads();
+        const bool has = lane < NW;
+        kmin = has ? (K)sh_a[has ? lane : 0] : KEY_MAX;
+        kmax = has ? (K)sh_b[has ? lane : 0] : (K)0;
+        uint32_t nan_w = has ? sh_c[has ? lane : 0] : 0u;
+        if (MASKED) {
+            mcnt = has ? (int)sh_d[has ? lane : 0] : 0;
+            const unsigned long long mb = sh_m[has ? lane : 0];
+            msum = has ? (sizeof(T) == 8 ? (T)__longlong_as_double((long long)mb) : (T)__uint_as_float((uint32_t)mb)) : (T)0;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const K a = __shfl_xor(kmin, d), b = __shfl_xor(kmax, d);
+            kmin = a < kmin ? a : kmin;
+            kmax = b > kmax ? b : kmax;
+            nan_w |= __shfl_xor(nan_w, d);
+            if (MASKED) {
+                msum += __shfl_xor(msum, d);
+                mcnt += __shfl_xor(mcnt, d);
+            }
+        }
+        any_nan = nan_w != 0;
+    }
+    if (MASKED && lane == 0 && wv == 0) mm.out[seg] = (double)(msum / (T)(mcnt > 1 ? mcnt : 1));
     if (any_nan) {
-        if (lane == 0) out[seg] = __longlong_as_double(0x7FF8000000000000ll);
+        if (lane == 0 && wv == 0) out[seg] = __longlong_as_double(0x7FF8000000000000ll);
         return;
     }
     // ---- selection on key - kmin (the padding keys stay above every trial value that can be accepted)
@@ -1733,13 +1838,17 @@ void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_o
     // compacted (through the wave's LDS slot) and the remaining bits are decided on them alone: a row of some
     // thousand spread-out keys needs a handful of full sweeps, not one per bit.
     K res = 0;
-    uint32_t lo_cnt = 0, hi_cnt = (uint32_t)n;
+    // (the padding keys, KEY_MAX - kmin now, lie below 2^bits only when the row spans half the key space: they
+    // then count as keys of the top interval, so that a compaction never meets more candidates than it counted)
+    const bool pad_low = bits >= (int)(8 * sizeof(K)) || ((K)(KEY_MAX - kmin) >> bits) == 0;
+    uint32_t lo_cnt = 0, hi_cnt = pad_low ? (uint32_t)(NW * (KPL + 1) * 64) : (uint32_t)n;
     K ck[SEL_CK];
     bool compact = false, unique = false;
     int b = bits - 1;
     for (; b >= 0; --b) {
         const K trial = res | ((K)1 << b);
-        const uint32_t cnt = count_below<K, KPL + 1>(key, trial);
+        uint32_t cnt = count_below<K, KPL + 1>(key, trial);
+        if (NW > 1) cnt = wg_sum(cnt);
         if (cnt <= r0) {                                    // the r0-th key (0-based) is >= trial
             res = trial;
             lo_cnt = cnt;
@@ -1765,25 +1874,43 @@ void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_o
             const K o = __shfl_xor(mn, d);
             mn = o < mn ? o : mn;
         }
+        if (NW > 1) mn = wg_min(mn);
         res = mn;
     }
     if (compact) {
-        __shared__ K cbuf_all[4][SEL_CK * 64];
-        K *cbuf = cbuf_all[threadIdx.x >> 6];
+        K *cbuf = cbuf_all[NW == 1 ? wave : 0];
         const K span = (K)1 << b;                      // candidates: res <= key < res + span
         uint32_t base = 0;
+        if (NW == 1) {
 #pragma unroll
-        for (int i = 0; i <= KPL; ++i) {
-            const bool in = key[i] - res < span;
-            const unsigned long long m = __ballot(in);
-            const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (in) cbuf[pos] = key[i];
-            base += (uint32_t)__builtin_popcountll(m);
-            if ((i & 7) == 7) asm volatile("" : "+s"(base));
+            for (int i = 0; i <= KPL; ++i) {
+                const bool in = key[i] - res < span;
+                const unsigned long long m = __ballot(in);
+                const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (in) cbuf[pos] = key[i];
+                base += (uint32_t)__builtin_popcountll(m);
+                if ((i & 7) == 7) asm volatile("" : "+s"(base));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            // the waves append to one list; a wave reserves the places of a register's candidates with one LDS atomic
+#pragma unroll
+            for (int i = 0; i <= KPL; ++i) {
+                const bool in = key[i] - res < span;
+                const unsigned long long m = __ballot(in);
+                if (m != 0) {
+                    uint32_t at = 0;
+                    if (lane == 0) at = atomicAdd(&sh_ctr, (uint32_t)__builtin_popcountll(m));
+                    at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+                    const uint32_t pos = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (in) cbuf[pos] = key[i];
+                }
+            }
+            __syncthreads();
+            base = sh_ctr;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int i = 0; i < SEL_CK; ++i) ck[i] = lane + 64 * i < (int)base ? cbuf[lane + 64 * i] : KEY_MAX;
         uint32_t lo2 = lo_cnt;
@@ -1822,19 +1949,28 @@ void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_o
             if ((i & 7) == 7) asm volatile("" : "+s"(cnt_le));
             above = (key[i] > res && key[i] < above) ? key[i] : above;
         }
+        if (NW > 1) cnt_le = wg_sum(cnt_le);
         if (cnt_le <= r1) {
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) {
                 const K o = __shfl_xor(above, d);
                 above = o < above ? o : above;
             }
+            if (NW > 1) above = wg_min(above);
             k1 = above;
         }
     }
-    if (lane == 0) out[seg] = select_result<T>(val_of((K)(k0 + kmin)), val_of((K)(k1 + kmin)), r0 == r1, frac, mode);
+    if (lane == 0 && wv == 0) out[seg] = select_result<T>(val_of((K)(k0 + kmin)), val_of((K)(k1 + kmin)), r0 == r1, frac, mode);
 }
 
-static constexpr int64_t SEL_WAVE_MAX = 128 * 64;       // longest row the register-resident kernel takes
+static constexpr int64_t SEL_WAVE_MAX = 128 * 64;       // longest row ONE wave holds in registers
+
+// Rows of the grouped layout beyond that (binary32: beyond 88 keys per lane, the longest row four waves per SIMD hold):
+// NW waves per row, KPL keys per lane each.  binary32: 64 or 88 keys, four waves per SIMD, so that a workgroup of
+// sixteen waves fits a CU; binary64: 96 keys of two registers, two waves per SIMD, eight waves per workgroup.
+template <typename T> struct SelWg;
+template <> struct SelWg<float> { static constexpr int64_t ONE_WAVE = 88 * 64, LIMIT = 16 * 88 * 64; };
+template <> struct SelWg<double> { static constexpr int64_t ONE_WAVE = 128 * 64, LIMIT = 8 * 96 * 64; };
 
 template <typename T, int XF, bool MASKED>
 static int launch_select_wave(Ctx *c, const T *d_vals, const SelectArgs &a) {
@@ -1846,6 +1982,34 @@ static int launch_select_wave(Ctx *c, const T *d_vals, const SelectArgs &a) {
     ADN_LAUNCH_NAMED("k_select_wave<" #KPLV ">", (k_select_wave<T, XF, MASKED, KPLV>), grid, block, 0, c->stream, d_vals,  \
                      a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len, a.n_seg, a.mode, a.q, a.d_center, \
                      a.d_out, mm, (c->ablate & 32) ? 0 : 64, a.quad_stride, a.blk_rows, a.blk_sig_stride)
+#define ADN_SEL_WG(NWV, KPLV)                                                                                        \
+    ADN_LAUNCH_NAMED("k_select_wave<" #KPLV ", " #NWV " waves per row>", (k_select_wave<T, XF, MASKED, KPLV, NWV>),   \
+                     dim3((unsigned)(ceil_div(a.n_seg, (int64_t)64) * 64)), dim3(NWV * 64), 0, c->stream, d_vals,   \
+                     a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len, a.n_seg, a.mode, a.q, a.d_center, \
+                     a.d_out, mm, (c->ablate & 32) ? 0 : 64, a.quad_stride, a.blk_rows, a.blk_sig_stride)
+    // (diagnostic option bit 1024: rows that one wave could hold are shared by two waves all the same)
+    const bool share = a.quad_stride != 1 && (a.max_len > SelWg<T>::ONE_WAVE || (c->ablate & 1024));
+    if constexpr (XF == XF_NONE) {
+        if (share) {
+            const int64_t n = a.max_len;
+            if constexpr (sizeof(T) == 4) {
+                if (n <= 2 * 64 * 64) ADN_SEL_WG(2, 64);
+                else if (n <= 2 * 88 * 64) ADN_SEL_WG(2, 88);
+                else if (n <= 4 * 64 * 64) ADN_SEL_WG(4, 64);
+                else if (n <= 4 * 88 * 64) ADN_SEL_WG(4, 88);
+                else if (n <= 8 * 64 * 64) ADN_SEL_WG(8, 64);
+                else if (n <= 8 * 88 * 64) ADN_SEL_WG(8, 88);
+                else if (n <= 16 * 64 * 64) ADN_SEL_WG(16, 64);
+                else ADN_SEL_WG(16, 88);
+            } else {
+                if (n <= 2 * 96 * 64) ADN_SEL_WG(2, 96);
+                else if (n <= 4 * 96 * 64) ADN_SEL_WG(4, 96);
+                else ADN_SEL_WG(8, 96);
+            }
+            ADN_HIP(hipGetLastError());
+            return ADN_OK;
+        }
+    }
     if (a.max_len <= 8 * 64) ADN_SEL_WAVE(8);
     else if (a.max_len <= 24 * 64) ADN_SEL_WAVE(24);
     else if (a.max_len <= 48 * 64) ADN_SEL_WAVE(48);
@@ -1853,23 +2017,24 @@ static int launch_select_wave(Ctx *c, const T *d_vals, const SelectArgs &a) {
     else if (a.max_len <= 96 * 64) ADN_SEL_WAVE(96);
     else ADN_SEL_WAVE(128);
 #undef ADN_SEL_WAVE
+#undef ADN_SEL_WG
     ADN_HIP(hipGetLastError());
     return ADN_OK;
 }
 
-int64_t select_grouped_limit() { return 128 * 64; }
+int64_t select_grouped_limit(size_t value_bytes) { return value_bytes == 8 ? SelWg<double>::LIMIT : SelWg<float>::LIMIT; }
 
 template <typename T>
 int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {
     if (a.n_seg <= 0) return ADN_OK;
     using K = typename KeyT<T>::type;
     if (a.quad_stride != 1) {
-        ADN_REQUIRE(a.max_len > 0 && a.max_len <= select_grouped_limit() &&
+        ADN_REQUIRE(a.max_len > 0 && a.max_len <= select_grouped_limit(sizeof(T)) && a.xform == XF_NONE &&
                         a.mode != SEL_PERCENTILE_DB20 && (reinterpret_cast<uintptr_t>(d_vals) & 31) == 0 &&
                         a.blk_sig_stride % 4 == 0 && (a.quad_stride * (a.max_len / 4 + 1)) < (int64_t(1) << 28),
-                    "internal: grouped rows are rows of at most %lld values", (long long)select_grouped_limit());
+                    "internal: grouped rows are rows of at most %lld values", (long long)select_grouped_limit(sizeof(T)));
     }
-    if (a.max_len > BIG_THRESHOLD) {
+    if (a.max_len > BIG_THRESHOLD && a.quad_stride == 1) {
         if (a.d_masked_mean) {
             set_error("internal: the fused masked mean is only available for LDS-resident segments");
             return ADN_ERR_UNSUPPORTED;
@@ -1879,7 +2044,8 @@ int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {
     }
     // rows of up to a few thousand values: one wave per row, keys in registers (binary64: rows in the grouped
     // layout only, the other binary64 rows keep the LDS kernels)
-    if ((!c->force_generic || a.quad_stride != 1) && a.max_len > 0 && a.max_len <= SEL_WAVE_MAX && a.mode != SEL_PERCENTILE_DB20 &&
+    if ((!c->force_generic || a.quad_stride != 1) && a.max_len > 0 && (a.max_len <= SEL_WAVE_MAX || a.quad_stride != 1) &&
+        a.mode != SEL_PERCENTILE_DB20 &&
         (std::is_same<T, float>::value || a.quad_stride != 1)) {
         const bool masked = a.d_masked_mean != nullptr;
         if (a.xform == XF_ABSDEV) return masked ? launch_select_wave<T, XF_ABSDEV, true>(c, d_vals, a)
@@ -1947,11 +2113,102 @@ int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {
 template int launch_select<float>(Ctx *, const float *, const SelectArgs &);
 template int launch_select<double>(Ctx *, const double *, const SelectArgs &);
 
-// Lists up to this many keys are staged whole in LDS (one workgroup per CU); longer ones, up to
-// select_subset_max_keys, are walked in memory by the general kernel (they sit in L2).
+// Lists up to this many keys are staged whole in LDS (one workgroup per CU).  Longer ones are bracketed again
+// (sample -> count + gather, on the list, with the rank offset) until the keys left fit LDS: the levels of the
+// long-segment select, started on a list instead of a segment.
 static size_t subset_lds_keys(size_t key_bytes) { return SUBSET_LDS_BYTES / key_bytes; }
-size_t select_subset_max_keys(size_t key_bytes) { return (size_t)1 << 17; }
+size_t select_subset_max_keys(size_t key_bytes) { return (size_t)1 << 27; }
 size_t select_subset_lds_keys(size_t key_bytes) { return subset_lds_keys(key_bytes); }
+
+size_t select_subset_ws_bytes(int64_t n_seg, int64_t cap, size_t key_bytes) {
+    if ((size_t)cap <= subset_lds_keys(key_bytes)) return 0;
+    int64_t caps[BIG_MAX_LEVELS];
+    const int nl = big_level_caps(cap, key_bytes, caps);
+    size_t total = 0;
+    for (int l = 0; l < nl; ++l)
+        total += ws_need((size_t)n_seg * caps[l], 8) + ws_need((size_t)n_seg, sizeof(BigState)) + 4 * ws_need((size_t)n_seg, 8) +
+                 ws_need((size_t)n_seg, 4);
+    return total;
+}
+
+// lists that an earlier step had declared usable but a bracket level lost: their results must not look valid
+__global__ void k_subset_invalidate(const int *valid_in, const int *valid_out, int64_t n_seg, double *out, double *pair) {
+    const int64_t seg = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (seg >= n_seg || (valid_in && !valid_in[seg]) || valid_out[seg]) return;
+    const double nan = __longlong_as_double(0x7FF8000000000000ll);
+    out[seg] = nan;
+    if (pair) pair[2 * seg] = pair[2 * seg + 1] = nan;
+}
+
+template <typename T>
+static int launch_select_subset_levels(Ctx *c, const T *d_cand, const SubsetSelect &a) {
+    using K = typename KeyT<T>::type;
+    int64_t caps[BIG_MAX_LEVELS];
+    const int n_levels = big_level_caps(a.cap, sizeof(K), caps);
+    BigState *st_l[BIG_MAX_LEVELS];
+    T *cand_l[BIG_MAX_LEVELS];
+    int64_t *len_l[BIG_MAX_LEVELS];
+    unsigned long long *below_l[BIG_MAX_LEVELS], *lohi_l[BIG_MAX_LEVELS];
+    int *valid_l[BIG_MAX_LEVELS];
+    for (int l = 0; l < n_levels; ++l) {
+        st_l[l] = ws_take<BigState>(c, (size_t)a.n_seg);
+        cand_l[l] = reinterpret_cast<T *>(ws_take<double>(c, (size_t)a.n_seg * caps[l]));
+        len_l[l] = ws_take<int64_t>(c, (size_t)a.n_seg);
+        below_l[l] = ws_take<unsigned long long>(c, (size_t)a.n_seg);
+        valid_l[l] = ws_take<int>(c, (size_t)a.n_seg);
+        lohi_l[l] = ws_take<unsigned long long>(c, 2 * (size_t)a.n_seg);
+    }
+    if (c->ws_used > c->ws_bytes) {
+        set_error("internal: workspace not reserved for the bracket levels of long candidate lists");
+        return ADN_ERR_NOMEM;
+    }
+    const unsigned nb = (unsigned)ceil_div(a.n_seg, 256);
+    const T *src = d_cand;
+    const int64_t *src_len = a.d_len;
+    int64_t src_cap = a.cap;
+    const unsigned long long *src_below = a.d_below;
+    const int *src_valid = a.d_valid;
+    for (int l = 0; l < n_levels; ++l) {
+        const RankSrc rs{a.d_orig_len, 1, 0, src_below, src_valid};
+        const int64_t ltiles = ceil_div(src_cap, GATHER_TILE);
+        ADN_REQUIRE(a.n_seg * ltiles < (int64_t)0x7FFFFFFF, "select batch too large for one launch");
+        ADN_LAUNCH(k_big_init_level, dim3(nb), dim3(256), 0, c->stream, st_l[l], a.n_seg);
+        // the first level sees the list as it was gathered (raw coefficients: |x - centre| is formed on the way and
+        // it is those values that the level gathers); deeper levels see transformed keys
+        if (l == 0 && a.xform == XF_ABSDEV) {
+            ADN_LAUNCH((k_big_sample<T, XF_ABSDEV>), dim3((unsigned)a.n_seg), dim3(SAMPLE_THREADS), 0, c->stream, src,
+                       (const int64_t *)nullptr, src_cap, src_len, (int64_t)1, (int64_t)0, a.d_center, st_l[l], (int)SEL_MEDIAN, 50.0, rs);
+            ADN_LAUNCH((k_big_gather<T, XF_ABSDEV>), dim3((unsigned)(a.n_seg * ltiles)), dim3(256), 0, c->stream, src,
+                       (const int64_t *)nullptr, src_cap, src_len, (int64_t)1, (int64_t)0, a.d_center, st_l[l], cand_l[l], caps[l], ltiles, 0);
+        } else {
+            ADN_LAUNCH((k_big_sample<T, XF_NONE>), dim3((unsigned)a.n_seg), dim3(SAMPLE_THREADS), 0, c->stream, src,
+                       (const int64_t *)nullptr, src_cap, src_len, (int64_t)1, (int64_t)0, (const double *)nullptr, st_l[l], (int)SEL_MEDIAN, 50.0, rs);
+            ADN_LAUNCH((k_big_gather<T, XF_NONE>), dim3((unsigned)(a.n_seg * ltiles)), dim3(256), 0, c->stream, src,
+                       (const int64_t *)nullptr, src_cap, src_len, (int64_t)1, (int64_t)0, (const double *)nullptr, st_l[l], cand_l[l], caps[l], ltiles, 0);
+        }
+        ADN_LAUNCH(k_big_check, dim3(nb), dim3(256), 0, c->stream, st_l[l], src_len, (int64_t)1, (int64_t)0, a.n_seg,
+                   (int)SEL_MEDIAN, 50.0, caps[l], rs, len_l[l], valid_l[l], below_l[l], lohi_l[l]);
+        src = cand_l[l];
+        src_len = len_l[l];
+        src_cap = caps[l];
+        src_below = below_l[l];
+        src_valid = valid_l[l];
+    }
+    const int L = n_levels - 1;
+    ADN_LAUNCH(k_subset_invalidate, dim3(nb), dim3(256), 0, c->stream, a.d_valid, valid_l[L], a.n_seg, a.d_out, a.d_pair);
+    const MaskedMean mm{nullptr, 1, 0, nullptr};
+    SubsetRanks sub{a.d_orig_len, 1, 0, below_l[L], valid_l[L], lohi_l[L]};
+    sub.pair = a.d_pair;
+    const size_t dyn = (size_t)caps[L] * sizeof(K);
+    ADN_REQUIRE(dyn <= SEL_LDS_MAX_BYTES, "internal: the last bracket level left lists of %lld keys", (long long)caps[L]);
+    auto kern = k_select_lds<T, XF_NONE, false>;
+    ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    ADN_LAUNCH_NAMED("k_select_lds<XF_NONE, subset levels>", kern, dim3((unsigned)a.n_seg), dim3(SEL_THREADS), dyn, c->stream,
+                     cand_l[L], (const int64_t *)nullptr, caps[L], len_l[L], (int64_t)1, (int64_t)0, (int)SEL_MEDIAN, 50.0,
+                     (const double *)nullptr, a.d_out, mm, sub);
+    ADN_HIP(hipGetLastError());
+    return ADN_OK;
+}
 
 template <typename T>
 int launch_select_subset(Ctx *c, const T *d_cand, const SubsetSelect &a) {
@@ -1977,19 +2234,7 @@ int launch_select_subset(Ctx *c, const T *d_cand, const SubsetSelect &a) {
                                a.d_len, (int64_t)1, (int64_t)0, (int)SEL_MEDIAN, 50.0, center, a.d_out, mm, sub);
         }
     } else {
-        const int lds_keys = (int)(SEL_LDS_BYTES / sizeof(K));
-        const size_t dyn = 2 * (size_t)lds_keys * sizeof(K);
-        if (a.xform == XF_ABSDEV) {
-            auto kern = k_select<T, XF_ABSDEV>;
-            ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-            ADN_LAUNCH_NAMED("k_select<XF_ABSDEV, subset>", kern, dim3((unsigned)a.n_seg), dim3(SEL_THREADS), dyn, c->stream, d_cand, (const int64_t *)nullptr,
-                               a.cap, a.d_len, (int64_t)1, (int64_t)0, (int)SEL_MEDIAN, 50.0, center, a.d_out, lds_keys, mm, sub);
-        } else {
-            auto kern = k_select<T, XF_NONE>;
-            ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
-            ADN_LAUNCH_NAMED("k_select<XF_NONE, subset>", kern, dim3((unsigned)a.n_seg), dim3(SEL_THREADS), dyn, c->stream, d_cand, (const int64_t *)nullptr,
-                               a.cap, a.d_len, (int64_t)1, (int64_t)0, (int)SEL_MEDIAN, 50.0, center, a.d_out, lds_keys, mm, sub);
-        }
+        return launch_select_subset_levels<T>(c, d_cand, a);
     }
     ADN_HIP(hipGetLastError());
     return ADN_OK;

@@ -1008,6 +1008,9 @@ static int apply_dispatch(Ctx *c, const ApplyArgs<T> &a, int64_t n_sig, int64_t 
             return apply_wave64<MODE>(c, a, n_sig, Tmax);
     }
     if (need(8) <= 160 * 1024) return launch_apply<T, 8, MODE>(c, a, n_sig, Tmax);
+    if constexpr (MODE == APPLY_SUBTRACT) {      // a time smoothing of 5 ... 7 frames needs as many waves
+        if (need(6) <= 160 * 1024 && min_w > 4 && min_w <= 6) return launch_apply<T, 6, MODE>(c, a, n_sig, Tmax);
+    }
     if (need(4) <= 160 * 1024 && min_w <= 4) return launch_apply<T, 4, MODE>(c, a, n_sig, Tmax);
     if (need(3) <= 160 * 1024 && min_w <= 3) return launch_apply<T, 3, MODE>(c, a, n_sig, Tmax);
     if (need(2) <= 160 * 1024 && min_w <= 2) return launch_apply<T, 2, MODE>(c, a, n_sig, Tmax);
@@ -1038,7 +1041,7 @@ int noise_psd(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const i
     Signals sg{d_off, d_len, n_ch, n_fft, hop, padded};
     // rows of up to a few thousand frames take the grouped layout (rows written by waves that work alone, read by
     // the register-resident row select), like the statistics of the Wiener stage
-    const bool grouped = !c->force_generic && (c->ablate & 64) == 0 && rows_wave_ok(sg, n_fft) && Tmax <= select_grouped_limit();
+    const bool grouped = !c->force_generic && (c->ablate & 64) == 0 && rows_wave_ok(sg, n_fft) && Tmax <= select_grouped_limit(sizeof(T));
     const int64_t sig_floats = std::max<int64_t>((int64_t)F * Ts, rows_wave_sig_floats(Tmax));
     const size_t nS = (size_t)n_sig * sig_floats;
     ADN_TRY(ws_reserve(c, ws_need(nS, sizeof(T)) + ws_need(n_sig, 8) * 2 + ws_need((size_t)n_sig * F, 8) +
@@ -1150,7 +1153,7 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     // rows of up to a few thousand frames: power rows in groups of four frames, written by waves that
     // work alone and read by the register-resident row select; the rows kernel adds up the voice-activity
     // frames' energies on the way when those frames are at least a hop long
-    const bool grouped = !c->force_generic && (c->ablate & 64) == 0 && rows_wave_ok(sg, n_fft) && Tmax <= select_grouped_limit();
+    const bool grouped = !c->force_generic && (c->ablate & 64) == 0 && rows_wave_ok(sg, n_fft) && Tmax <= select_grouped_limit(sizeof(T));
     const bool vad_in_rows = grouped && vad_guided && (c->ablate & 128) == 0 && frame_len >= hop &&
                              frame_len <= rows_wave_vad_max_frame();
     if (vad_guided && !vad_in_rows) {

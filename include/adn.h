@@ -57,6 +57,13 @@ enum { ADN_THR_SOFT = 0, ADN_THR_HARD = 1 };
 enum { ADN_AXIS_REFERENCE = 0, ADN_AXIS_TIME = 1 };
 
 /* ---------------------------------------------------------------- context */
+/* ADN_ABI_VERSION counts incompatible changes of the argument lists below; a caller compares the value it was
+ * built with against adn_abi_version() of the library it loaded before it calls anything else.
+ *   2: adn_wavelet_denoise_* gained axis_mode and ext_mode (in the middle of the list: a caller built against the
+ *      older header would pass wavelet / level / thr_mode in the wrong places); ADN_OPT_* renumbered.
+ *   3: adn_kernel_times keeps its records when the buffer is too small. */
+#define ADN_ABI_VERSION 3
+int adn_abi_version(void);
 const char *adn_last_error(void);
 int adn_version(void);
 int adn_create(adn_ctx **ctx, int device);
@@ -71,11 +78,18 @@ int adn_synchronize(adn_ctx *ctx);
  *   tests can cover both.
  * ADN_OPT_FORCE_FALLBACK: the single-pass threshold statistics hand every block to their exact
  *   per-block fallback (independent of ADN_OPT_FORCE_GENERIC).
- * ADN_OPT_ABLATE (diagnostics, results become WRONG): bit mask of stages the fused binary32
- *   STFT kernel skips - 1 analysis, 2 synthesis, 4 overlap-add - so that the cost of each stage
- *   can be timed (the mono tile kernels read bits 1, 2, 4, 8 the same way).  Bit 512 changes no
- *   result: mono blocks take their threshold statistics in two passes (finest band written to
- *   memory, two selections on it) instead of one pass over the samples.
+ * ADN_OPT_ABLATE (diagnostics): a bit mask.
+ *   Bits that make results WRONG (timing only): 1 analysis, 2 synthesis, 4 overlap-add, 8 next-frame prefetch of
+ *   the fused STFT kernels skipped (the mono tile kernels read 1, 2, 4, 8 the same way: levels, shrink, deeper
+ *   levels, synthesis); 32 the row select decides no bit / the generic subtract kernel skips its magnitudes.
+ *   Bit 16: the fused STFT kernels record per-phase shader clocks of wave 0; the launch then ALLOCATES a counter
+ *   buffer (hipMalloc), SYNCHRONISES the stream and prints the totals to stderr.
+ *   Bits that change no result (they pick another route to the same values, for tests): 64 per-bin statistics on
+ *   transposed rows (LDS select, separate voice-activity pass) instead of the grouped rows; 128 voice-activity
+ *   energies in their own pass; 256 binary64 STFT stages on the shape-generic kernels; 512 mono blocks take their
+ *   threshold statistics in two passes (finest band written to memory, two selections on it) instead of one pass
+ *   over the samples; 1024 every grouped row is shared by two waves of the row select (what rows longer than
+ *   8192 frames get by themselves).
  * ADN_OPT_KERNEL_TIMING: record a HIP event pair on the context's stream around every kernel
  *   launch; adn_kernel_times() reports them.  Switching it off drops unreported records. */
 enum { ADN_OPT_FORCE_GENERIC = 1, ADN_OPT_ABLATE = 2, ADN_OPT_FORCE_FALLBACK = 3, ADN_OPT_KERNEL_TIMING = 4 };
@@ -83,7 +97,7 @@ int adn_set_option(adn_ctx *ctx, int option, int value);
 /* Measurement aid (no counterpart in the reference): synchronises the stream, then writes one
  * line per launch site timed since the last report, "name<TAB>launches<TAB>total_ms<NEWLINE>",
  * NUL-terminated, into buf and forgets the records.  Returns the text length, -1 on failure, or
- * minus the capacity needed when cap is too small (records are dropped then too). */
+ * minus the capacity needed when cap is too small (the records are kept: call again with that much room). */
 int64_t adn_kernel_times(adn_ctx *ctx, char *buf, int64_t cap);
 /* Measurement aid (no counterpart in the reference): while kernel timing is on, only launches of the
  * site called `name` (as adn_kernel_times() prints it) get their event pair; NULL or "" = every launch.
@@ -232,7 +246,8 @@ int adn_noise_psd_f64(adn_ctx *ctx, const double *d_x, int64_t n_sig, const int6
  *                                                    20*log10(|Z| + 1e-12) over the same values
  *   d_time_mean[s * T_max + t]                     = mean over all bins of |Z[:, t]|  (NULL: skipped)
  *   d_mag[(s * (n_fft/2+1) + k) * T_max + t]       = |Z[k, t]| itself, for the host-side plots (NULL: skipped)
- * with T_max = adn_stft_num_frames(max_len, n_fft, hop, padded).  At most 16 bands and 16
+ * with T_max = adn_stft_num_frames(max_len, n_fft, hop, padded); entries at frames t beyond a shorter signal's own
+ * frame count are unspecified in d_time_mean and d_mag.  At most 16 bands and 16
  * percentiles per call; an empty band gives NaN.  h_* arrays are host memory. */
 int adn_band_summary_f32(adn_ctx *ctx, const float *d_x, int64_t n_sig, const int64_t *d_off,
                          const int64_t *d_len, int64_t max_len, int n_ch, int sample_rate, int n_fft,

@@ -4,7 +4,9 @@ import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "audio-denoising_amd"))
 from adn_hip import get_engine
 e = get_engine(0)
-B, n, SR = 64, 60 * 48000, 48000
+SR = 48000
+secs = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0          # clip length; about 3840 s of audio per call
+B, n = max(1, int(round(3840 / secs))), int(secs * SR)
 x = torch.randn(B * n, device="cuda", dtype=torch.float32) * 0.1
 for ab in (0, 32):
     e.lib.adn_set_option(e._h, 2, ab)
@@ -14,5 +16,5 @@ for ab in (0, 32):
         e.wiener(x, [n] * B, SR)
     kt = e.kernel_times()
     e.kernel_timing(False)
-    print("ablate", ab, {k: round(v["total_ms"] / v["count"], 4) for k, v in kt.items() if "select" in k or "rows" in k})
+    print("clip %.0f s x %d, ablate" % (secs, B), ab, {k: round(v["total_ms"] / v["count"], 4) for k, v in kt.items() if "select" in k or "rows" in k})
 e.lib.adn_set_option(e._h, 2, 0)

@@ -70,79 +70,27 @@ def test_spectral_subtract_in_chunks(dtype, n_chunks):
         chk(host(y[s - 4096:s + 4096]), want[s - 4096:s + 4096])
 
 
-@pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("vad_guided", [True, False])
-def test_wiener_in_chunks(dtype, vad_guided):
+@pytest.mark.parametrize("dtype,n_fft,hop", [("f32", 2048, 512), ("f64", 1024, 256)])
+def test_spectral_subtract_in_chunks_smooth_time_5(dtype, n_fft, hop):
+    """A time smoothing of five frames (the reference reads the count from its configuration,
+    src/spectral_subtract.py:58-59) reads two frames on either side: the chunks' halo must grow with it
+    (reach = 2), else the hops next to a seam differ from the one-call result.  (binary64 at n_fft 2048 has no
+    room in LDS for five frames of smoothing: that precision runs at n_fft 1024 here.)"""
     e = engine()
     dt = torch.float64 if dtype == "f64" else torch.float32
-    n = 24 * SR + 77
-    x = dev(synth.noisy_speech(n, SR, 42, 920), dt)
-    y1, l1, g1 = e.wiener(x, [n], SR, want_gain=True, vad_guided=vad_guided)
-    n_chunks = 4
-    hops, frames = ck.plan_stft_chunks(n, n_chunks)
-    fl = int(SR * 20 / 1000.0)
-    stats = []
-    for i, (h0, h1) in enumerate(hops):
-        t0, t1 = h0, (frames if i == len(hops) - 1 else h1)       # frames owned for the statistics
-        s0 = t0 * 512
-        s1 = n if t1 == frames else (t1 - 1) * 512 + 2048
-        vb = max((t0 * 512 // fl - 5) * fl, 0)                    # five VAD frames of hangover
-        stats.append(ck.wiener_chunk_stats(e, x[s0:s1].contiguous(), t1 - t0, x[vb:s1].contiguous(), vb, n, t0, SR,
-                                           vad_guided=vad_guided))
-    gain = ck.wiener_gain_from_chunks(e, stats, frames, dt, ck.LocalReducer(), vad_guided=vad_guided)
-    gdiff = float((gain - g1[0]).abs().max())
-    print("%s vad=%s: max |gain chunked - one call| = %.3g" % (dtype, vad_guided, gdiff))
-    if vad_guided:       # the masked mean is summed in another order (and in binary64) than the one-call kernel's
-        assert gdiff <= (1e-12 if dtype == "f64" else 2e-6)
-    elif dtype == "f64":
-        # binary64: the chunks' rows come from the shape-generic transform (adn_stft_rows_f64), the one call's from the
-        # register-resident one: two correctly rounded binary64 computations of the same spectra
-        assert gdiff <= 1e-12
-    else:
-        assert torch.equal(gain, g1[0])
-    pieces = []
+    n = 12 * SR + 333
+    x = dev(synth.noisy_speech(n, SR, 42, 912), dt)
+    prof = e.noise_psd(dev(synth.white_noise(2 * SR, 42, 913), dt), [2 * SR], n_fft=n_fft, hop=hop)[0]
+    kw = dict(smooth_time=5, n_fft=n_fft, hop=hop)
+    y1, l1 = e.spectral_subtract(x, [n], prof, **kw)
+    hops, frames = ck.plan_stft_chunks(n, 3, n_fft, hop)
+    pieces, short = [], []
     for h0, h1 in hops:
-        s0, s1, keep = ck.stft_chunk_window(h0, h1, frames, n, reach=0)
-        pieces.append(ck.wiener_apply_chunk(e, x[s0:s1].contiguous(), keep, (h1 - h0) * 512, g1[0]))
-    y = torch.cat(pieces)
-    assert y.numel() == int(l1[0])
-    assert torch.equal(y, y1)                                     # same gain -> same samples, seams included
-    # chunked end to end (own gain) against the oracle round the seams
-    pieces = []
-    for h0, h1 in hops:
-        s0, s1, keep = ck.stft_chunk_window(h0, h1, frames, n, reach=0)
-        pieces.append(ck.wiener_apply_chunk(e, x[s0:s1].contiguous(), keep, (h1 - h0) * 512, gain))
-    y = torch.cat(pieces)
-    if vad_guided:
-        want, _ = orc.wiener(host(x).astype(np.float64), SR)
-        chk = check64 if dtype == "f64" else check32
-        for h0, _ in hops[1:]:
-            s = h0 * 512
-            chk(host(y[s - 4096:s + 4096]), want[s - 4096:s + 4096])
-
-
-def test_order_statistics_over_ragged_parts():
-    """The distributed selection alone: ragged segments scattered unevenly over 3 holders, ties, negative
-    values, an empty part; every rank of a few segments against numpy's sort."""
-    e = engine()
-    rng = np.random.default_rng(5)
-    for dt, npdt in ((torch.float32, np.float32), (torch.float64, np.float64)):
-        seg_vals = [np.round(rng.standard_normal(m) * 3, 1).astype(npdt) for m in (1, 7, 1000, 4097)]
-        parts = []
-        for h in range(3):
-            cuts = [(len(v) * h // 3, len(v) * (h + 1) // 3) if h < 2 else (len(v) * 2 // 3, len(v)) for v in seg_vals]
-            chunk = [v[a:b] for v, (a, b) in zip(seg_vals, cuts)]
-            lens = np.array([c.size for c in chunk], dtype=np.int64)
-            offs = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
-            flat = np.concatenate(chunk) if lens.sum() else np.zeros(1, npdt)
-            parts.append((dev(flat, dt), e._i64(offs), e._i64(lens)))
-        for q in (0.0, 0.1, 0.5, 1.0):
-            ranks = [int(round(q * (len(v) - 1))) for v in seg_vals]
-            got = host(ck.order_statistics(e, parts, [ranks], dt, ck.LocalReducer())[0])
-            want = np.array([np.sort(v)[r] for v, r in zip(seg_vals, ranks)], dtype=np.float64)
-            assert np.array_equal(got, want), (q, got, want)
-        centers = dev(np.array([0.3, -0.2, 0.1, 0.0]), torch.float64)
-        ranks = [len(v) // 2 for v in seg_vals]
-        got = host(ck.order_statistics(e, parts, [ranks], dt, ck.LocalReducer(), absdev=True, centers=centers)[0])
-        want = np.array([np.sort(np.abs(v - npdt(c)))[r] for v, r, c in zip(seg_vals, ranks, host(centers))], dtype=np.float64)
-        assert np.array_equal(got, want), (got, want)
+        s0, s1, keep = ck.stft_chunk_window(h0, h1, frames, n, n_fft, hop, reach=2)
+        pieces.append(ck.spectral_subtract_chunk(e, x[s0:s1].contiguous(), keep, (h1 - h0) * hop, prof, **kw))
+        s0, s1, keep = ck.stft_chunk_window(h0, h1, frames, n, n_fft, hop, reach=1)
+        short.append(ck.spectral_subtract_chunk(e, x[s0:s1].contiguous(), keep, (h1 - h0) * hop, prof, **kw))
+    assert torch.equal(torch.cat(pieces), y1)
+    assert not torch.equal(torch.cat(short), y1)            # the halo of the 3-frame smoothing is too short
+    want = orc.spectral_subtract(host(x).astype(np.float64), host(prof).astype(np.float64), smooth_time=5, n_fft=n_fft, hop=hop)
+    (check64 if dtype == "f64" else check32)(host(y1), want)

@@ -363,7 +363,8 @@ def test_wiener_long_rows(dt):
 def test_statistics_paths_agree():
     """The Wiener stage and the noise profile on the grouped-rows path (rows written by waves that work alone,
     register-resident select, voice-activity energies added up by the rows kernel) against the transposed-rows
-    path with its separate voice-activity pass (diagnostic option bits 64 / 128 switch the new pieces off):
+    path with its separate voice-activity pass (diagnostic option bits 64 / 128 switch the new pieces off; bit 1024
+    lets two waves share every row):
     binary32 bit for bit (both paths transform a frame with the same arithmetic), binary64 to 1e-12 (the
     transposed binary64 rows come from the shape-generic transform)."""
     e = engine()
@@ -379,7 +380,7 @@ def test_statistics_paths_agree():
             xs = torch.cat([x.reshape(-1), x[: 5 * SR48 + 77].reshape(-1)])
         lens = [n, 5 * SR48 + 77]
         res = {}
-        for name, bits in (("grouped", 0), ("vad_apart", 128), ("transposed", 64)):
+        for name, bits in (("grouped", 0), ("vad_apart", 128), ("transposed", 64), ("shared_rows", 1024)):
             e.lib.adn_set_option(e._h, 2, bits)
             try:
                 y, l, g = e.wiener(xs, lens, SR48, n_ch=n_ch, want_gain=True)
@@ -387,6 +388,12 @@ def test_statistics_paths_agree():
             finally:
                 e.lib.adn_set_option(e._h, 2, 0)
             res[name] = (y.clone(), g.clone(), p.clone())
+        # rows shared by two waves (bit 1024; what rows of more than 8192 frames take by themselves): the order
+        # statistics are the same keys; the voice-activity mean adds its terms in another order
+        y, g, p = res["shared_rows"]
+        assert torch.equal(p, res["grouped"][2]), str(dt)
+        assert float((g - res["grouped"][1]).abs().max()) <= (1e-12 if dt == torch.float64 else 2e-6)
+        assert float((y - res["grouped"][0]).abs().max()) <= (1e-12 if dt == torch.float64 else 2e-6)
         for name in ("vad_apart", "transposed"):
             for a, b in zip(res["grouped"], res[name]):
                 if tol == 0.0 or name == "vad_apart":
@@ -420,3 +427,22 @@ def test_wiener_and_noise_profile_rows_of_7000_frames(dt):
         check64(base, base_or, 1e-12)
     else:
         assert np.max(np.abs(base - base_or)) <= 2e-6 * max(1.0, float(np.max(np.abs(base_or))))
+
+
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
+@pytest.mark.parametrize("kernel_bins,update_ms", [(3, 10), (7, 30), (9, 20), (1, 10)])
+def test_wiener_other_median_kernels_and_vad_frames(dt, kernel_bins, update_ms):
+    """wiener.median_kernel_bins and wiener.update_ms are read from the configuration
+    (src/wiener_filter.py:52-53): running medians of 1, 3, 7 and 9 bins, voice-activity frames of 10 ms
+    (480 samples: shorter than a hop, the energies take their own pass), 20 and 30 ms, against the oracle."""
+    e = engine()
+    n = 6 * SR + 321
+    x = synth.noisy_speech(n, SR, 42, 1200 + kernel_bins)
+    if dt == torch.float32:
+        x = x.astype(np.float32).astype(np.float64)
+    for vad in (True, False):
+        want, g_or = orc.wiener(x, SR, update_ms=update_ms, kernel_bins=kernel_bins, vad_guided=vad)
+        y, _, gain = e.wiener(dev(x, dt), [n], SR, update_ms=update_ms, kernel_bins=kernel_bins, vad_guided=vad,
+                              want_gain=True)
+        (check64 if dt == torch.float64 else check32)(host(y), want)
+        assert np.max(np.abs(host(gain)[0].astype(np.float64) - g_or)) <= (1e-10 if dt == torch.float64 else 2e-4)
