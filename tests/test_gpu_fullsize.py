@@ -258,3 +258,76 @@ def test_config2_end_to_end_fp32_against_fp64_chain():
         print("end to end, binary32 vs binary64 chain, %s: max-abs %.3g, SNR of the difference %.1f dB"
               % (name, float(np.max(np.abs(d))), snr))
     check32(host(y2c), y2c_or)
+
+
+@pytest.mark.timeout(300)
+def test_config3_full_size():
+    """BASELINE.json config 3 at its stated size: 1024 clips of 30 s at 48 kHz, mono, db8 level 8, ten blocks per
+    clip = 10 240 blocks of 144 000 samples (5.9 GB in, 5.9 GB out) in ONE call.  Sixteen distinct blocks, the
+    rest copies: every copy's result equals its original's bit for bit (a block's result does not depend on its
+    place in the batch), every sample is finite, sampled blocks against the oracle, per-block statistics equal."""
+    e = engine()
+    nb, bl, gen = 10240, 144000, 16
+    x = torch.empty(nb * bl, dtype=torch.float32, device="cuda:0")
+    for i in range(gen):
+        x[i * bl:(i + 1) * bl] = e.synth_noisy_speech(bl, SR, stream=900 + i, start=i * bl).float()
+    xv = x.view(nb // gen, gen * bl)
+    xv[1:] = xv[0]
+    off = np.arange(nb, dtype=np.int64) * bl
+    out = torch.empty_like(x)
+    sigma, thresh, zeroed = e.wavelet_denoise(x, e._i64(off), e._i64(np.full(nb, bl)), out, e._i64(off),
+                                              wavelet="db8", level=8, want_stats=True, max_frames=bl)
+    ov = out.view(nb // gen, gen * bl)
+    assert bool(torch.isfinite(out).all())
+    for r in range(1, nb // gen, 37):                       # every 37th repetition of the sixteen blocks ...
+        assert torch.equal(ov[r], ov[0]), r
+    assert torch.equal(ov[nb // gen - 1], ov[0])           # ... and the last one
+    sg = sigma.view(nb // gen, gen)
+    assert bool((sg == sg[0]).all()) and bool((zeroed.view(nb // gen, gen) == zeroed.view(nb // gen, gen)[0]).all())
+    xh = host(x[:gen * bl]).reshape(gen, bl).astype(np.float64)
+    y = host(out[:gen * bl]).reshape(gen, bl)
+    for i in (0, 5, 15):
+        want, s_or, t_or = orc.denoise_block(xh[i], "db8", 8)
+        check32(y[i], want)
+        assert abs(float(sigma[i]) - s_or) <= 2e-6 * s_or
+
+
+@pytest.mark.timeout(300)
+def test_config4_full_size_file_shards():
+    """BASELINE.json config 4 at its stated size on one GPU: 10 h of 48 kHz audio as 1200 mono files of 30 s,
+    sharded round-robin over 8 ranks (here: eight calls on one device, one per rank's shard), one noise profile
+    learnt once and handed to every shard, phase 2b -> 2c.  Thirteen distinct files, the rest copies: every file's
+    result equals that of the file it copies in whatever shard it landed, and the oracle for sampled files."""
+    from adn_hip import dist as adist
+    e = engine()
+    n_files, n, gen, world = 1200, 30 * SR, 13, 8
+    files = torch.empty((gen, n), dtype=torch.float32, device="cuda:0")
+    for i in range(gen):
+        files[i] = e.synth_noisy_speech(n, SR, stream=1300 + i).float()
+    noise = dev(synth.white_noise(5 * SR, 42, 101300).astype(np.float32))
+    prof = e.noise_psd(noise, [5 * SR])[0]
+    first = {}                                              # distinct file -> its first result
+    L = None
+    for rank in range(world):
+        idx = adist.shard_indices(n_files, rank, world)
+        shard_prof = adist.broadcast_profile(prof if rank == 0 else prof.clone(), 1025, src=0)
+        xs = files[torch.as_tensor(idx % gen, device="cuda:0")].reshape(-1)
+        yb, lb = e.spectral_subtract(xs, [n] * len(idx), shard_prof)
+        yc, lc = e.wiener(yb, [int(v) for v in lb], SR)
+        L = int(lc[0])
+        ycv = yc.view(len(idx), L)
+        for j, i in enumerate(idx):
+            k = int(i % gen)
+            if k not in first:
+                first[k] = ycv[j].clone()
+        for k in sorted(set(int(v) for v in idx % gen)):      # all copies of file k in this shard at once
+            rows = torch.as_tensor(np.nonzero(idx % gen == k)[0], device="cuda:0")
+            assert bool((ycv[rows] == first[k]).all()), (rank, k)
+    p64 = host(prof).astype(np.float64)
+    for k in (0, 7):
+        xb = host(files[k]).astype(np.float64)
+        yb_or = orc.spectral_subtract(xb, p64)
+        yb_k, _ = e.spectral_subtract(files[k].contiguous(), [n], prof)
+        check32(host(yb_k), yb_or)
+        want_c, _ = orc.wiener(host(yb_k).astype(np.float64), SR)
+        check32(host(first[k]), want_c)
