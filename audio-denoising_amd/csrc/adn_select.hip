@@ -1895,18 +1895,25 @@ void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_o
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         } else {
-            // the waves append to one list; a wave reserves the places of a register's candidates with one LDS atomic
+            // the waves append to one list: a wave counts its candidates, reserves their places with ONE LDS atomic
+            // and writes them there
+            uint32_t mine = 0;
+#pragma unroll
+            for (int i = 0; i <= KPL; ++i) {
+                mine += (uint32_t)__builtin_popcountll(__ballot(key[i] - res < span));
+                if ((i & 7) == 7) asm volatile("" : "+s"(mine));
+            }
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(&sh_ctr, mine);
+            at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
 #pragma unroll
             for (int i = 0; i <= KPL; ++i) {
                 const bool in = key[i] - res < span;
                 const unsigned long long m = __ballot(in);
-                if (m != 0) {
-                    uint32_t at = 0;
-                    if (lane == 0) at = atomicAdd(&sh_ctr, (uint32_t)__builtin_popcountll(m));
-                    at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-                    const uint32_t pos = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (in) cbuf[pos] = key[i];
-                }
+                const uint32_t pos = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (in) cbuf[pos] = key[i];
+                at += (uint32_t)__builtin_popcountll(m);
+                if ((i & 7) == 7) asm volatile("" : "+s"(at));
             }
             __syncthreads();
             base = sh_ctr;
