@@ -1,15 +1,18 @@
-// Register-resident STFT kernels for the headline shape: binary32, n_fft = 2048.
+// Register-resident STFT kernels for the headline shape: n_fft = 2048, hop 512, both precisions.
 //
-// One wavefront owns one frame.  The 2048 real samples are packed into 1024 complex
-// points, 16 per lane, and transformed as 16 x 16 x 4:
+// One wavefront owns one frame at a time and a run of consecutive frames of one signal.  The 2048 real samples
+// are packed into 1024 complex points, 16 per lane, and transformed as 16 x 16 x 4:
 //   pass 1  16-point DFT in registers over the stride-64 samples of a lane,
 //           twiddle by W1024^(lane*k1), transpose through LDS (padded rows: conflict free);
-//   pass 2  16-point DFT in registers, twiddle by W64^(b*c);
-//   pass 3  radix-4 across the four lanes of a quad with DPP moves (no LDS).
-// The inverse transform is the same network with conjugated twiddles.  Spectra are
-// exchanged between lanes only through a natural-order LDS image with 8 entries of
-// padding per 256 (all accesses of a wave hit distinct banks), twiddles and the
-// real-FFT split factors live in registers for the lifetime of the workgroup.
+//   pass 2  16-point DFT in registers, twiddle by W64^(b*c), second exchange through LDS;
+//   pass 3  four radix-4 butterflies per lane.
+// The inverse transform is the same network with conjugated twiddles.  Spectra are exchanged between lanes only
+// through a natural-order LDS image with 8 entries of padding per 256 (all accesses of a wave hit distinct
+// banks); the inter-pass twiddles are one table per workgroup in LDS, the real-FFT split factors of a lane are
+// one value times compile-time constants.
+// Kernels: k_apply_wave (STFT -> modify -> ISTFT, one wave per run of output hops), k_rows_wave (power / magnitude
+// rows in groups of four frames, one wave per run of frames), k_rows_fast (transposed rows, one workgroup per
+// sixteen frames), k_apply_wg_map (run sizes for batches of signals of different lengths).
 #include "adn_kernels.hpp"
 #include "adn_stft_shared.hpp"
 
@@ -27,7 +30,6 @@ static_assert(sizeof(c2) == sizeof(float2), "c2 is layout-compatible with float2
 static constexpr int NC = 1024;     // complex points per frame
 static constexpr int RS = 68;       // exchange row stride (float2): 64 + 4 keeps quads on distinct banks
 static constexpr int WBUF = 1088;   // float2 per wave buffer: 16 * RS >= padded natural image + 1
-static constexpr int MROW = 1032;   // floats per magnitude row (1025 used)
 static constexpr int FAST_ST = 3;   // time-smoothing frames this specialisation is built for
 static constexpr int ROWS_GPW = 8;  // groups of frames per workgroup of the rows kernel
 static constexpr int PARK = 1026;   // float2 slots of a parked spectrum (1025 used)
@@ -207,14 +209,6 @@ struct LaneTwT {
     const C *t1;   // + lane
     const C *t2;   // + (lane & 3)
 };
-typedef LaneTwT<c2> LaneTw;
-
-// tw holds exp(-2 pi i k / 1024) for k < 512
-__device__ __forceinline__ c2 w1024(const c2 *__restrict__ tw, int k) {
-    k &= 1023;
-    const c2 v = tw[k & 511];
-    return (k & 512) ? c2{-v.x, -v.y} : v;
-}
 
 // Cooperative fill by the whole workgroup from the precomputed image (16-byte copies, the table
 // offset inside the blob is 16-byte aligned); the caller synchronises before first use.
@@ -290,95 +284,12 @@ __device__ __forceinline__ void store_natural(const C (&r)[16], C *buf, int lane
         for (int d = 0; d < 4; ++d) buf[base + 16 * cc + 264 * d] = r[4 * cc + d];   // nat(k1 + 16 c + 256 d)
 }
 
-// Frame at padded sample p0 of a signal -> layout-A registers (windowed, packed):
-// r[j] = z[lane + 64 j].  Frames that are wholly inside the signal and suitably aligned
-// are loaded straight into registers; any other frame (zero-padded tail, odd alignment,
-// more than two channels) is staged through the wave's LDS buffer by a rolled loop.
-__device__ __noinline__ void stage_frame_generic(c2 *buf, const float *__restrict__ xs, int64_t n, int n_ch,
-                                                 int64_t p0, const float *__restrict__ window, int lane) {
-#pragma unroll 1
-    for (int i = lane; i < NC; i += 64) {
-        const float a = fold_sample(xs, p0 + 2 * i, n, n_ch), b = fold_sample(xs, p0 + 2 * i + 1, n, n_ch);
-        buf[nat(i)] = c2{a * window[2 * i], b * window[2 * i + 1]};
-    }
-}
-
-__device__ __forceinline__ void load_frame(c2 (&r)[16], c2 *buf, const float *__restrict__ xs, int64_t n,
-                                           int n_ch, int64_t p0, const float *__restrict__ window, int lane) {
-    const c2 *wv = reinterpret_cast<const c2 *>(window);
-    // All loads of the frame are issued before anything uses them (the scheduling barriers keep
-    // the compiler from sinking a load next to its use, which serialises sixteen round trips).
-    if (p0 + 2048 <= n && n_ch == 1 && (reinterpret_cast<uintptr_t>(xs + p0) & 7) == 0) {
-        const c2 *xv = reinterpret_cast<const c2 *>(xs + p0) + lane;
-        c2 a[16];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) a[j] = xv[64 * j];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const c2 w = wv[lane + 64 * j];
-            r[j] = c2{a[j].x * w.x, a[j].y * w.y};
-        }
-    } else if (p0 + 2048 <= n && n_ch == 2 && (reinterpret_cast<uintptr_t>(xs + 2 * p0) & 15) == 0) {
-        const float4 *xv = reinterpret_cast<const float4 *>(xs + 2 * p0) + lane;
-        float4 a[16];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) a[j] = xv[64 * j];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const c2 w = wv[lane + 64 * j];
-            r[j] = c2{(a[j].x + a[j].y) / 2.0f * w.x, (a[j].z + a[j].w) / 2.0f * w.y};
-        }
-    } else {
-        stage_frame_generic(buf, xs, n, n_ch, p0, window, lane);
-        wave_sync();
-#pragma unroll
-        for (int j = 0; j < 16; ++j) r[j] = buf[nat(lane + 64 * j)];
-        wave_sync();
-    }
-}
-
-// Raw samples of a frame fetched one iteration ahead (no arithmetic: the loads are in flight while
-// the workgroup overlap-adds).  mode 1: mono, pf[j >> 1] holds x[lane + 64 j] pairs; mode 2: stereo,
-// pf[j] holds the two (left, right) pairs of packed point lane + 64 j; 0: the frame needs the
-// ordinary loader (tail of the signal, odd alignment, more channels).
-__device__ __forceinline__ int prefetch_frame(float4 (&pf)[8], const float *__restrict__ xs, int64_t n, int n_ch,
-                                              int64_t p0, int lane) {
-    if (p0 + 2048 <= n && n_ch == 1 && (reinterpret_cast<uintptr_t>(xs + p0) & 7) == 0) {
-        const c2 *xv = reinterpret_cast<const c2 *>(xs + p0) + lane;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 16; j += 2) {
-            const c2 a = xv[64 * j], b = xv[64 * (j + 1)];
-            pf[j >> 1] = float4{a.x, a.y, b.x, b.y};
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        return 1;
-    }
-    return 0;
-}
-
-__device__ __forceinline__ void window_prefetched(c2 (&r)[16], const float4 (&pf)[8], int mode,
-                                                  const float *__restrict__ window, int lane) {
-    const c2 *wv = reinterpret_cast<const c2 *>(window);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const float4 q = pf[j >> 1];
-        const c2 w = wv[lane + 64 * j];
-        r[j] = (j & 1) ? c2{q.z * w.x, q.w * w.y} : c2{q.x * w.x, q.y * w.y};
-    }
-}
-
 // Real-signal spectrum of the packed transform held in buf (natural, padded).
 // lo[j] = X[k], hi[j] = X[1024-k] for k = lane + 64 j (lane 0, j 0: X[0] and X[1024]); mid = X[512].
 template <typename C>
 struct SpecT {
     C lo[8], hi[8], mid;
 };
-typedef SpecT<c2> Spec;
 
 // Addresses of the two kinds of accesses to the natural (padded) spectrum image: bin lane + 64 j
 // and its mirror 1024 - lane - 64 j.  Both are one base address per lane plus compile-time
@@ -392,7 +303,6 @@ struct NatAddrT {
     const C *mir;     // buf + 64 - lane
     const C *mir4;    // the same, + 8 for lane 0: mirror base of j = 4, 8, 12
 };
-typedef NatAddrT<c2> NatAddr;
 template <typename C>
 __device__ __forceinline__ NatAddrT<C> nat_addr(const C *buf, int lane) {
     return NatAddrT<C>{buf + lane, buf + 64 - lane, buf + 64 - lane + (lane == 0 ? 8 : 0)};
@@ -433,37 +343,7 @@ __device__ __forceinline__ void split_spectrum(SpecT<C> &s, const C *buf, const 
     s.mid = C{z.x * scale, -z.y * scale};
 }
 
-// Inverse of split_spectrum: writes the packed spectrum Z' (natural, padded) into buf.
-template <int J>
-__device__ __forceinline__ void merge_bin(const Spec &s, c2 *buf, const NatAddr &na, const c2 (&rtw)[8], int lane) {
-    const c2 xk = s.lo[J], xm = s.hi[J];
-    c2 *fwd = const_cast<c2 *>(na.fwd), *mir = const_cast<c2 *>((J & 3) == 0 ? na.mir4 : na.mir);
-    if (J == 0 && lane == 0) {
-        buf[0] = c2{(xk.x + xm.x) * 0.5f, (xk.x - xm.x) * 0.5f};
-    } else {
-        const c2 e = add_conj(xk, xm) * 0.5f;              // ((xk.x + xm.x) / 2, (xk.y - xm.y) / 2)
-        c2 d;                                              // (xk.x - xm.x, xk.y + xm.y)
-        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(d) : "v"(xk), "v"(xm));
-        const c2 o = mulc(d * 0.5f, rtw[J]);
-        fwd[nat_fwd_off<J>()] = add_rot<true>(e, o);       // e + i o = (e.x - o.y, e.y + o.x)
-        mir[nat_mir_off<J>()] = conj_sub_rot(e, o);        // conj(e - i o) = (e.x + o.y, o.x - e.y)
-    }
-}
-
-__device__ __forceinline__ void merge_spectrum(const Spec &s, c2 *buf, const c2 (&rtw)[8], int lane) {
-    const NatAddr na = nat_addr(buf, lane);
-    merge_bin<0>(s, buf, na, rtw, lane);
-    merge_bin<1>(s, buf, na, rtw, lane);
-    merge_bin<2>(s, buf, na, rtw, lane);
-    merge_bin<3>(s, buf, na, rtw, lane);
-    merge_bin<4>(s, buf, na, rtw, lane);
-    merge_bin<5>(s, buf, na, rtw, lane);
-    merge_bin<6>(s, buf, na, rtw, lane);
-    merge_bin<7>(s, buf, na, rtw, lane);
-    if (lane == 0) buf[nat(512)] = c2{s.mid.x, -s.mid.y};
-}
-
-// The same for a wave that transforms the result itself: the lower half of the packed spectrum, Z'[lane + 64 j]
+// Inverse of split_spectrum for a wave that transforms the result itself: the lower half of the packed spectrum, Z'[lane + 64 j]
 // for j < 8, is what the inverse transform wants in r[j] of this very lane, so it stays in registers; only the
 // mirrored bins (the upper half, owned by other lanes) go through buf.
 template <int J, typename C>
@@ -497,11 +377,6 @@ __device__ __forceinline__ void merge_spectrum_keep(const SpecT<C> &s, C (&r)[16
     merge_bin_keep<6>(s, r, na, rtw, lane);
     merge_bin_keep<7>(s, r, na, rtw, lane);
     if (lane == 0) buf[nat(512)] = C{s.mid.x, -s.mid.y};
-}
-
-__device__ __forceinline__ void load_rtw(c2 (&rtw)[8], const c2 *tab, int lane) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) rtw[j] = tab[lane + 64 * j];
 }
 
 // exp(-2 pi i (lane + 64 j) / 2048) = rtw0 * exp(-i pi j / 16)
@@ -615,7 +490,7 @@ __global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ 
     fill_tw_table(twtab, tb.fast_tw, threadIdx.x, W * 64);
     for (int i = threadIdx.x; i < 2048; i += W * 64) wtab[i] = tb.window[i];
     __syncthreads();
-    const LaneTw tw = lane_tw(twtab, lane);
+    const LaneTwT<c2> tw = lane_tw(twtab, lane);
     c2 rtw[8];
     derive_rtw(rtw, as_c2(tb.rtw)[lane]);            // as the one-wave-per-run kernels derive them
     const float scale = (float)(1.0 / tb.wsum);
@@ -655,7 +530,7 @@ __global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ 
             wave_fft1024<false>(r, buf, tw, lane);
             store_natural(r, buf, lane);
             wave_sync();
-            Spec s;
+            SpecT<c2> s;
             split_spectrum(s, buf, rtw, scale, lane);
             wave_sync();
 #pragma unroll
@@ -701,450 +576,6 @@ __global__ __launch_bounds__(W * 64) void k_rows_fast(const float *__restrict__ 
         for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
         if (lane == 0) atomicMax(&sig_max[sig], (unsigned long long)key_of((double)vmax));
     }
-}
-
-// ------------------------------------ fused STFT -> modify -> ISTFT overlap-add
-// Workgroup = W waves sliding along one segment of one signal.  Per iteration the waves
-// transform W NEW consecutive frames (stage A), every wave then modifies and inverse-transforms
-// one frame (stage B), and all threads overlap-add the finished frames into a ring of hop
-// accumulators, emitting the hops that are complete.
-// SUBTRACT mode smooths over the two neighbouring frames: the smoothed-magnitude rows live in a
-// ring of W + 2 rows that survives the iteration, and the last frame of an iteration, whose right
-// neighbour does not exist yet, has its spectrum parked in LDS; the last wave synthesises the
-// frame parked by the previous iteration instead.  No frame is transformed twice inside a segment.
-template <int W, int MODE, bool PROF>
-__global__ __launch_bounds__(W * 64) void k_apply_fast(ApplyArgs<float> a) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const Tables<float> &tb = a.tb;
-    const int H = a.sg.hop, R = 2048 / H, LOGH = 31 - __clz(H);
-    const int RING = W + R;
-    c2 *bufs = reinterpret_cast<c2 *>(smem);
-    float *mags = reinterpret_cast<float *>(bufs + (size_t)W * WBUF);                 // [W][MROW]
-    constexpr int MR = W + 2;                                                         // magnitude rows kept
-    c2 *park = reinterpret_cast<c2 *>(mags + (MODE == APPLY_SUBTRACT ? (size_t)MR * MROW : 0));   // [PARK] SUBTRACT only
-    float *acc = reinterpret_cast<float *>(park + (MODE == APPLY_SUBTRACT ? PARK : 0));            // [RING][H]
-    float *wsq = acc + (size_t)RING * H;                                              // [H] full-overlap norm
-    c2 *twtab = reinterpret_cast<c2 *>(wsq + H);
-    // the window lives in LDS (analysis and synthesis reads)
-    float *wtab = reinterpret_cast<float *>(twtab + TWTAB);                           // [2048]
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
-    const int64_t sig = blockIdx.x / a.segs_per_sig, seg = blockIdx.x % a.segs_per_sig;
-    const int64_t n = a.sg.len[sig];
-    const int64_t Tn64 = stft_frames(n, 2048, H, 1);
-    const int64_t g0 = seg * a.seg_hops;
-    if (Tn64 < 1 || g0 >= Tn64 - 1) return;
-    // frame / hop indices of one signal fit 32 bits (the host checks max_len)
-    const int Tn = (int)Tn64;
-    const int out_hops = Tn - 1;
-    const int g1 = ((int)g0 + a.seg_hops < out_hops) ? (int)g0 + a.seg_hops : out_hops;
-    const int ph0 = (int)g0 + R / 2, ph1 = g1 + R / 2;
-    int next_u = ph0 - R + 1;
-    next_u = next_u < 0 ? 0 : next_u;
-    const int last_u = (ph1 - 1 < Tn - 1) ? ph1 - 1 : Tn - 1;
-    const int h = MODE == APPLY_SUBTRACT ? a.st / 2 : 0;
-    const int hr = MODE == APPLY_SUBTRACT ? a.st - h - 1 : 0;
-    const float *xs = a.x + a.sg.off[sig];
-    float *ys = a.y + a.y_off[sig];
-    int16_t *ps = a.pcm ? a.pcm + a.y_off[sig] : nullptr;
-    const float *row = a.row + sig * a.row_stride;
-    const float fscale = (float)(1.0 / tb.wsum);
-    const float iscale = (float)(tb.wsum / 1024.0);
-    c2 *buf = bufs + wave * WBUF;
-    float *bufr = reinterpret_cast<float *>(buf);
-    // hop 512 with four-fold overlap: the overlap-add owns fixed sample positions per thread and applies
-    // the synthesis window (and the inverse-transform scale) there, from four 16-byte loads per
-    // iteration, instead of sixteen 8-byte window loads per frame after the inverse transform
-    const bool win_in_ola = (H == 512 && R == 4);
-
-    fill_tw_table(twtab, tb.fast_tw, tid, W * 64);
-    const LaneTw tw = lane_tw(twtab, lane);
-    c2 rtw[8];
-    load_rtw(rtw, as_c2(tb.rtw), lane);
-
-    for (int i = tid; i < 2048; i += W * 64) wtab[i] = tb.window[i];
-    for (int i = tid; i < RING * H; i += W * 64) acc[i] = 0.0f;
-    for (int i = tid; i < H; i += W * 64) {
-        float s = 0.0f;
-        for (int r = 0; r < R; ++r) {
-            const float w = tb.window[i + r * H];
-            s += w * w;
-        }
-        wsq[i] = 1.0f / (s > 1e-10f ? s : 1.0f);     // reciprocal of the full-overlap norm
-    }
-    __syncthreads();
-
-    unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    constexpr bool prof = PROF;
-    // first new frame of the iteration; later iterations continue where the analysis stopped
-    int base = next_u - h;
-    base = base < 0 ? 0 : base;
-    int park_t = -1;                                       // frame whose spectrum is parked (last wave only)
-    float4 pf[8];                                          // next iteration's (mono) frame, fetched during the overlap-add
-    int pf_mode = 0;
-#pragma unroll 1
-    while (next_u <= last_u) {
-        unsigned long long tk = prof ? clock64() : 0;
-        auto tick = [&](int i) {
-            if (prof) {
-                const unsigned long long now = clock64();
-                ph[i] += now - tk;
-                tk = now;
-            }
-        };
-        int t = base + wave;
-        int a_last = last_u + hr;
-        a_last = a_last > Tn - 1 ? Tn - 1 : a_last;
-        Spec s;
-        // ---- stage A: spectrum of frame t
-        if (t <= a_last && !(a.ablate & 1)) {
-            c2 r[16];
-            if (pf_mode) window_prefetched(r, pf, pf_mode, wtab, lane);
-            else load_frame(r, buf, xs, n, a.sg.n_ch, (int64_t)t * H, wtab, lane);
-            if (prof) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            tick(6);
-            wave_fft1024<false>(r, buf, tw, lane);
-            tick(7);
-            store_natural(r, buf, lane);
-            wave_sync();
-            split_spectrum(s, buf, rtw, fscale, lane);
-            wave_sync();
-            tick(8);
-            if (MODE == APPLY_SUBTRACT) {
-                // clean magnitudes of the lane's bins -> raw row in the wave's own buffer, stored
-                // with an offset of RAWPAD so that the box filter can read past both ends
-                float *raw = bufr + RAWPAD;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = lane + 64 * j;
-                    const float m0 = __builtin_amdgcn_sqrtf(s.lo[j].x * s.lo[j].x + s.lo[j].y * s.lo[j].y);
-                    const float m1 = __builtin_amdgcn_sqrtf(s.hi[j].x * s.hi[j].x + s.hi[j].y * s.hi[j].y);
-                    raw[k] = fmaxf(m0 - a.alpha * row[k], a.beta * m0);
-                    raw[1024 - k] = fmaxf(m1 - a.alpha * row[1024 - k], a.beta * m1);
-                }
-                if (lane == 0) {
-                    const float mm = __builtin_amdgcn_sqrtf(s.mid.x * s.mid.x + s.mid.y * s.mid.y);
-                    raw[512] = fmaxf(mm - a.alpha * row[512], a.beta * mm);
-                }
-                wave_sync();
-                const int fl = a.sf / 2, fr = a.sf - fl - 1;
-                // edge replication: copies of the first / last bin beyond the row's ends
-                if (lane < RAWPAD) {
-                    raw[-1 - lane] = raw[0];
-                    raw[1025 + lane] = raw[1024];
-                }
-                wave_sync();
-                // box mean along frequency -> shared row of this frame
-                float *mrow = mags + (t % MR) * MROW;
-                const float inv_sf = 1.0f / (float)a.sf;
-                if (a.sf == 5) {
-                    // the reference's box (smooth_freq = 5): all reads of a group of bins are
-                    // issued together; same summation order as the general loop
-#pragma unroll
-                    for (int j0 = 0; j0 < 16; j0 += 8) {
-                        float rv[8][5];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j)
-#pragma unroll
-                            for (int d = 0; d < 5; ++d) rv[j][d] = raw[lane + 64 * (j0 + j) + d - 2];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            float fs = 0.0f;
-#pragma unroll
-                            for (int d = 0; d < 5; ++d) fs += rv[j][d];
-                            mrow[lane + 64 * (j0 + j)] = fs * inv_sf;
-                        }
-                    }
-                    if (lane == 0) {
-                        float fs = 0.0f;
-#pragma unroll
-                        for (int d = 0; d < 5; ++d) fs += raw[1024 + d - 2];
-                        mrow[1024] = fs * inv_sf;
-                    }
-                } else {
-#pragma unroll 1
-                    for (int k = lane; k <= 1024; k += 64) {
-                        float fs = 0.0f;
-                        for (int df = -fl; df <= fr; ++df) fs += raw[k + df];
-                        mrow[k] = fs * inv_sf;
-                    }
-                }
-            }
-        }
-        tick(0);
-        if (MODE == APPLY_SUBTRACT) lds_barrier();
-        tick(1);
-        const int ub = next_u;
-        // SUBTRACT: frames up to base + W - 2 have their right neighbour; the last wave's own frame
-        // is always parked and synthesised one iteration later
-        int ue = base + W - 1 - hr;
-        if (MODE == APPLY_GAIN && base + W - 1 >= Tn - 1) ue = Tn - 1;
-        ue = ue > last_u ? last_u : ue;
-        if (MODE == APPLY_SUBTRACT && wave == W - 1) {
-            // swap the own spectrum (if any) with the parked one
-            const int own_t = t <= a_last ? t : -1;
-            if (park_t >= 0 || own_t >= 0) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const c2 plo = park[j * 64 + lane], phi = park[(8 + j) * 64 + lane];
-                    park[j * 64 + lane] = s.lo[j];
-                    park[(8 + j) * 64 + lane] = s.hi[j];
-                    s.lo[j] = plo;
-                    s.hi[j] = phi;
-                }
-                const c2 pm = park[1024];
-                wave_sync();
-                if (lane == 0) park[1024] = s.mid;
-                s.mid = pm;
-            }
-            t = park_t;                                    // -1: nothing to synthesise
-            park_t = own_t;
-        }
-        // ---- stage B: modify, inverse transform, window
-        if (t >= ub && t <= ue && !(a.ablate & 2)) {
-            if (MODE == APPLY_SUBTRACT) {
-                const float inv_st = 1.0f / (float)a.st;
-                // rows of the time neighbours, clamped at the signal's first / last frame
-                const float *rows[FAST_ST];
-#pragma unroll
-                for (int i = 0; i < FAST_ST; ++i) {
-                    int tt = t - h + i;
-                    tt = tt < 0 ? 0 : (tt > Tn - 1 ? Tn - 1 : tt);
-                    rows[i] = mags + (tt % MR) * MROW;
-                }
-                auto smooth = [&](int k) {
-                    float ts = 0.0f;
-#pragma unroll
-                    for (int i = 0; i < FAST_ST; ++i) ts += rows[i][k];
-                    return ts * inv_st;
-                };
-                // clean * exp(i angle(Z)) = clean * Z / |Z|, and angle(0) = 0
-                auto rephase = [&](c2 z, float sm) {
-                    const float p2 = z.x * z.x + z.y * z.y;
-                    const float g = sm * __builtin_amdgcn_rsqf(p2);
-                    return p2 > 0.0f ? c2{z.x * g, z.y * g} : c2{sm, 0.0f};
-                };
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = lane + 64 * j;
-                    s.lo[j] = rephase(s.lo[j], smooth(k));
-                    s.hi[j] = rephase(s.hi[j], smooth(1024 - k));
-                }
-                s.mid = rephase(s.mid, smooth(512));
-            } else {
-                const float *grow = row + (int64_t)t * a.row_t_stride;     // per-frame gain rows (masks) or one row
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int k = lane + 64 * j;
-                    const float g0v = grow[k], g1v = grow[1024 - k];
-                    s.lo[j] = c2{s.lo[j].x * g0v, s.lo[j].y * g0v};
-                    s.hi[j] = c2{s.hi[j].x * g1v, s.hi[j].y * g1v};
-                }
-                const float gm = grow[512];
-                s.mid = c2{s.mid.x * gm, s.mid.y * gm};
-            }
-            tick(9);
-            merge_spectrum(s, buf, rtw, lane);
-            wave_sync();
-            c2 r[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) r[j] = buf[nat(lane + 64 * j)];
-            wave_sync();
-            tick(10);
-            wave_fft1024<true>(r, buf, tw, lane);
-            tick(11);
-            if (!win_in_ola) {
-                // time samples of this lane: n = k1 + 16 (4 cq + cc) + 256 d; apply the synthesis window
-                const c2 *wv = reinterpret_cast<const c2 *>(wtab) + (lane & 15) + 64 * (lane >> 4);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const c2 w = wv[16 * (i >> 2) + 256 * (i & 3)];
-                    r[i] = c2{r[i].x * iscale * w.x, r[i].y * iscale * w.y};
-                }
-            }
-            store_natural(r, buf, lane);
-        }
-        // the frame of the next iteration: loads issued now, consumed after the overlap-add
-        pf_mode = 0;
-        {
-            const int tn = base + W + wave;
-            if (tn <= a_last && !(a.ablate & 8)) pf_mode = prefetch_frame(pf, xs, n, a.sg.n_ch, (int64_t)tn * H, lane);
-        }
-        tick(2);
-        lds_barrier();
-        tick(3);
-        // ---- overlap-add of frames [ub, ue] into padded hops [ub, ue + R - 1]
-        if (ue >= ub && !(a.ablate & 4)) {
-            const bool final_group = (ue == Tn - 1);
-            const int nj = ue - ub + R;                     // hops touched
-            const float *fbase = reinterpret_cast<const float *>(bufs);
-            // one hop j, sample i of it: add the frames that overlap the hop, emit it if complete
-            auto hop_sample = [&](int j, int i, float *slot, const int (&off)[4], int r_eff, float wq) {
-                float v = *slot;
-                // all four reads are issued together (a frame outside [ub, ue] reads frame slot 0
-                // and contributes zero), then added oldest frame first
-                float c[4];
-                bool ok[4];
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const int u = j - qq;
-                    ok[qq] = qq < r_eff && u >= ub && u <= ue;
-                    c[qq] = fbase[(ok[qq] ? (u - base) & (W - 1) : 0) * (2 * WBUF) + off[qq]];
-                }
-#pragma unroll
-                for (int qq = 3; qq >= 0; --qq) v += ok[qq] ? c[qq] : 0.0f;
-                if (j <= ue || final_group) {
-                    if (j >= ph0 && j < ph1) {
-                        float o;
-                        if (j - R + 1 >= 0 && j <= Tn - 1) {
-                            o = v * wq;
-                        } else {
-                            float norm = 0.0f;
-                            int t_lo = j - R + 1;
-                            t_lo = t_lo < 0 ? 0 : t_lo;
-                            const int t_hi = j < Tn - 1 ? j : Tn - 1;
-                            for (int tt = t_lo; tt <= t_hi; ++tt) {
-                                const float w = tb.window[((j - tt) << LOGH) + i];
-                                norm += w * w;
-                            }
-                            o = v / (norm > 1e-10f ? norm : 1.0f);
-                        }
-                        if (!a.no_clip) o = o < -1.0f ? -1.0f : (o > 1.0f ? 1.0f : o);
-                        if (ps) {
-                            const int k = pcm_int32(o) >> 16;
-                            ps[(int64_t)(j - R / 2) * H + i] = (int16_t)k;
-                            o = (float)k * (1.0f / 32768.0f);
-                        }
-                        ys[(int64_t)(j - R / 2) * H + i] = o;
-                    }
-                    *slot = 0.0f;
-                } else {
-                    *slot = v;
-                }
-            };
-            if (H == 512 && R == 4) {
-                // 128 threads per hop: a thread owns FOUR consecutive samples
-                // i .. i+3 of every NG-th hop, so every LDS access is 16 bytes, the finished
-                // samples leave in one 16-byte store, and the sample offsets inside a frame
-                // and the norm are per-thread constants
-                constexpr int NG = W / 2;                        // groups of 128 threads, one hop each
-                const int i = (tid & 127) * 4;
-                int off[4];
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) off[qq] = natf((qq << LOGH) + i);
-                const float4 wq = *reinterpret_cast<const float4 *>(wsq + i);
-                float4 wsyn[4];                                  // synthesis window * scale at (qq * H + i ..)
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const float4 w = *reinterpret_cast<const float4 *>(wtab + (qq << LOGH) + i);
-                    wsyn[qq] = float4{w.x * iscale, w.y * iscale, w.z * iscale, w.w * iscale};
-                }
-                const bool y_vec = (reinterpret_cast<uintptr_t>(ys) & 15) == 0;
-                const int jj0 = tid >> 7;                        // 0..NG-1
-                int slot_i = (ub + jj0) % RING;
-#pragma unroll 1
-                for (int jj = jj0; jj < nj; jj += NG) {
-                    const int j = ub + jj;
-                    float4 *slot = reinterpret_cast<float4 *>(acc + slot_i * H + i);
-                    float4 v = *slot;
-                    float4 c[4];
-                    bool ok[4];
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) {
-                        const int u = j - qq;
-                        ok[qq] = u >= ub && u <= ue;
-                        c[qq] = *reinterpret_cast<const float4 *>(fbase + (ok[qq] ? (u - base) & (W - 1) : 0) * (2 * WBUF) + off[qq]);
-                    }
-#pragma unroll
-                    for (int qq = 3; qq >= 0; --qq) {          // oldest frame first
-                        v.x += ok[qq] ? c[qq].x * wsyn[qq].x : 0.0f;
-                        v.y += ok[qq] ? c[qq].y * wsyn[qq].y : 0.0f;
-                        v.z += ok[qq] ? c[qq].z * wsyn[qq].z : 0.0f;
-                        v.w += ok[qq] ? c[qq].w * wsyn[qq].w : 0.0f;
-                    }
-                    if (j <= ue || final_group) {
-                        if (j >= ph0 && j < ph1) {
-                            float4 o;
-                            if (j - R + 1 >= 0 && j <= Tn - 1) {
-                                o = float4{v.x * wq.x, v.y * wq.y, v.z * wq.z, v.w * wq.w};
-                            } else {
-                                float nrm[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-                                int t_lo = j - R + 1;
-                                t_lo = t_lo < 0 ? 0 : t_lo;
-                                const int t_hi = j < Tn - 1 ? j : Tn - 1;
-                                for (int tt = t_lo; tt <= t_hi; ++tt)
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) {
-                                        const float w = tb.window[((j - tt) << LOGH) + i + e];
-                                        nrm[e] += w * w;
-                                    }
-                                o = float4{v.x / (nrm[0] > 1e-10f ? nrm[0] : 1.0f), v.y / (nrm[1] > 1e-10f ? nrm[1] : 1.0f),
-                                           v.z / (nrm[2] > 1e-10f ? nrm[2] : 1.0f), v.w / (nrm[3] > 1e-10f ? nrm[3] : 1.0f)};
-                            }
-                            if (!a.no_clip) {
-                                o.x = o.x < -1.0f ? -1.0f : (o.x > 1.0f ? 1.0f : o.x);
-                                o.y = o.y < -1.0f ? -1.0f : (o.y > 1.0f ? 1.0f : o.y);
-                                o.z = o.z < -1.0f ? -1.0f : (o.z > 1.0f ? 1.0f : o.z);
-                                o.w = o.w < -1.0f ? -1.0f : (o.w > 1.0f ? 1.0f : o.w);
-                            }
-                            if (ps) {
-                                const int k0 = pcm_int32(o.x) >> 16, k1 = pcm_int32(o.y) >> 16;
-                                const int k2 = pcm_int32(o.z) >> 16, k3 = pcm_int32(o.w) >> 16;
-                                int16_t *pp = ps + (int64_t)(j - R / 2) * H + i;
-                                if ((reinterpret_cast<uintptr_t>(ps) & 7) == 0) {
-                                    *reinterpret_cast<uint2 *>(pp) = uint2{(unsigned)(k0 & 0xFFFF) | ((unsigned)k1 << 16),
-                                                                          (unsigned)(k2 & 0xFFFF) | ((unsigned)k3 << 16)};
-                                } else {
-                                    pp[0] = (int16_t)k0;
-                                    pp[1] = (int16_t)k1;
-                                    pp[2] = (int16_t)k2;
-                                    pp[3] = (int16_t)k3;
-                                }
-                                o = float4{(float)k0 * (1.0f / 32768.0f), (float)k1 * (1.0f / 32768.0f),
-                                           (float)k2 * (1.0f / 32768.0f), (float)k3 * (1.0f / 32768.0f)};
-                            }
-                            float *yp = ys + (int64_t)(j - R / 2) * H + i;
-                            if (y_vec) {
-                                *reinterpret_cast<float4 *>(yp) = o;
-                            } else {
-                                yp[0] = o.x;
-                                yp[1] = o.y;
-                                yp[2] = o.z;
-                                yp[3] = o.w;
-                            }
-                        }
-                        *slot = float4{0.0f, 0.0f, 0.0f, 0.0f};
-                    } else {
-                        *slot = v;
-                    }
-                    slot_i += NG;
-                    slot_i = slot_i >= RING ? slot_i - RING : slot_i;
-                }
-            } else {
-#pragma unroll 1
-                for (int idx = tid; idx < (nj << LOGH); idx += W * 64) {
-                    const int jj = idx >> LOGH, i = idx & (H - 1);
-                    const int j = ub + jj;
-                    int off[4];
-#pragma unroll
-                    for (int qq = 0; qq < 4; ++qq) off[qq] = natf((qq << LOGH) + i);
-                    // R > 4 (hop < 512): the frames beyond the four unrolled ones
-                    float *slot = acc + (j % RING) * H + i;
-                    for (int qq = R - 1; qq >= 4; --qq) {
-                        const int u = j - qq;
-                        if (u >= ub && u <= ue) *slot += fbase[((u - base) & (W - 1)) * (2 * WBUF) + natf((qq << LOGH) + i)];
-                    }
-                    hop_sample(j, i, slot, off, R < 4 ? R : 4, wsq[i]);
-                }
-            }
-        }
-        tick(4);
-        lds_barrier();
-        tick(5);
-        next_u = ue + 1;
-        base = MODE == APPLY_SUBTRACT ? base + W : next_u;
-    }
-    if (prof && tid == 0)
-        for (int i = 0; i < 12; ++i) atomicAdd(&a.dbg[i], ph[i]);
 }
 
 // ------------------------------------ fused STFT -> modify -> ISTFT, one wave per run of hops
@@ -1811,14 +1242,6 @@ static size_t apply_wave_lds(int W, int mode, size_t real_bytes) {
     return ((size_t)W * WBUF * 2 + (size_t)W * slot * 2 + (size_t)TWTAB * 2 + (1024 + 512 + (row_in_lds ? GROW : 0))) * real_bytes;
 }
 
-static size_t apply_lds(int W, int mode, int hop) {
-    const int R = 2048 / hop;
-    return (size_t)W * WBUF * sizeof(c2) +
-           (mode == APPLY_SUBTRACT ? (size_t)(W + 2) * MROW * sizeof(float) + (size_t)PARK * sizeof(c2) : 0) +
-           (size_t)(W + R) * hop * sizeof(float) + (size_t)hop * sizeof(float) + (size_t)TWTAB * sizeof(c2) +
-           2048 * sizeof(float);
-}
-
 }  // namespace fast
 
 // hop 512: one wave per run of hops
@@ -2019,49 +1442,15 @@ static int apply_wave(Ctx *c, ApplyArgs<R> a, int64_t n_sig, int64_t Tmax) {
     return ADN_OK;
 }
 
+// binary32, n_fft 2048, hop 512, gain (no smoothing) or subtraction with the reference's 5 x 3 smoothing: the shapes the
+// one-wave-per-run kernel is built for; every other shape runs the shape-generic kernels
 template <int MODE>
 int apply_fast(Ctx *c, ApplyArgs<float> a, int64_t n_sig, int64_t Tmax) {
-    if (a.sg.hop == 512 && (c->ablate & 15) == 0 && (MODE == APPLY_GAIN || (a.sf == 5 && a.st == fast::FAST_ST)))
-        return apply_wave<float, MODE>(c, a, n_sig, Tmax);
-    // 8 waves per workgroup.  4-wave workgroups, two per CU, measured the same in GAIN mode (the
-    // overlap-add path handles W = 4 too) and do not fit LDS twice in SUBTRACT mode.
-    constexpr int W = 8;
-    const int64_t out_hops = Tmax - 1;
-    if (out_hops <= 0) return ADN_OK;
-    const size_t lds = fast::apply_lds(W, MODE, a.sg.hop);
-    int64_t seg = ceil_div(n_sig * out_hops, (int64_t)c->num_cus * 8);
-    seg = seg < 24 ? 24 : (seg > 192 ? 192 : seg);
-    a.seg_hops = (int)seg;
-    a.segs_per_sig = ceil_div(out_hops, seg);
-    a.ablate = c->ablate;
-    a.dbg = nullptr;
-    if (c->ablate & 16) {       // diagnostics: per-phase cycle totals, printed after the launch
-        ADN_HIP(hipMalloc(&a.dbg, 12 * sizeof(unsigned long long)));
-        ADN_HIP(hipMemset(a.dbg, 0, 12 * sizeof(unsigned long long)));
-    }
-    auto kern = a.dbg ? fast::k_apply_fast<W, MODE, true> : fast::k_apply_fast<W, MODE, false>;
-    ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    ADN_LAUNCH_NAMED((MODE == APPLY_SUBTRACT ? "k_apply_fast<SUBTRACT>" : "k_apply_fast<GAIN>"), kern, dim3((unsigned)(a.segs_per_sig * n_sig)), dim3(W * 64), lds, c->stream, a);
-    ADN_HIP(hipGetLastError());
-    if (a.dbg) {
-        unsigned long long hp[12];
-        ADN_HIP(hipStreamSynchronize(c->stream));
-        ADN_HIP(hipMemcpy(hp, a.dbg, sizeof(hp), hipMemcpyDeviceToHost));
-        ADN_HIP(hipFree(a.dbg));
-        fprintf(stderr, "k_apply_fast<%d> wave-0 cycles: stageA %llu barrier %llu stageB %llu barrier %llu ola %llu barrier %llu (workgroups %lld)\n",
-                MODE, hp[0], hp[1], hp[2], hp[3], hp[4], hp[5], (long long)(a.segs_per_sig * n_sig));
-        // the finer marks restart the interval clock: stage A = load + fft + split + rest (hp[0]),
-        // stage B = modify (hp[9]) + merge/reload (hp[10]) + inverse fft (hp[11]) + window/store (hp[2])
-        fprintf(stderr, "  stage A: load %llu fft %llu store+split %llu rest %llu | stage B: modify %llu merge+reload %llu ifft %llu window+store %llu\n",
-                hp[6], hp[7], hp[8], hp[0], hp[9], hp[10], hp[11], hp[2]);
-    }
-    return ADN_OK;
+    return apply_wave<float, MODE>(c, a, n_sig, Tmax);
 }
 
 bool apply_fast_ok(int n_fft, int hop, int st, int sf) {
-    if (n_fft != 2048 || hop < 64 || (st != fast::FAST_ST && st != 1) || sf > 2 * fast::RAWPAD) return false;
-    return fast::apply_lds(8, APPLY_SUBTRACT, hop) <= 160 * 1024;
+    return n_fft == 2048 && hop == 512 && ((st == 1 && sf == 1) || (st == fast::FAST_ST && sf == 5));
 }
 
 int rows_fast(Ctx *c, const float *d_x, const Signals &sg, const Tables<float> &tb, int64_t n_sig,

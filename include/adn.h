@@ -79,9 +79,9 @@ int adn_synchronize(adn_ctx *ctx);
  * ADN_OPT_FORCE_FALLBACK: the single-pass threshold statistics hand every block to their exact
  *   per-block fallback (independent of ADN_OPT_FORCE_GENERIC).
  * ADN_OPT_ABLATE (diagnostics): a bit mask.
- *   Bits that make results WRONG (timing only): 1 analysis, 2 synthesis, 4 overlap-add, 8 next-frame prefetch of
- *   the fused STFT kernels skipped (the mono tile kernels read 1, 2, 4, 8 the same way: levels, shrink, deeper
- *   levels, synthesis); 32 the row select decides no bit / the generic subtract kernel skips its magnitudes.
+ *   Bits that make results WRONG (timing only): 1 analysis, 2 synthesis, 4 overlap-add of the shape-generic
+ *   STFT kernels skipped (the mono tile kernels read 1, 2, 4, 8 the same way: levels, shrink, deeper levels,
+ *   synthesis); 32 the row select decides no bit / the generic subtract kernel skips its magnitudes.
  *   Bit 16: the fused STFT kernels record per-phase shader clocks of wave 0; the launch then ALLOCATES a counter
  *   buffer (hipMalloc), SYNCHRONISES the stream and prints the totals to stderr.
  *   Bits that change no result (they pick another route to the same values, for tests): 64 per-bin statistics on

@@ -24,7 +24,8 @@ def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     clips = int(sys.argv[3])
-    out = {"clips": clips, "unit": "bytes per launch (largest launch of each kernel)",
+    import os
+    out = {"clips": clips, "commit": os.environ.get("ADN_COMMIT", "?"), "unit": "bytes per launch (largest launch of each kernel)",
            "correction": "FETCH_SIZE x 2 (gfx950), WRITE_SIZE x 1, KiB -> bytes", "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         f = 2.0 * fetch.get(k, 0.0) * 1024.0
