@@ -84,11 +84,17 @@ __device__ __forceinline__ Pk<double>::type pk_fma_half(int half, Pk<double>::ty
 struct Rg {
     int s, c, N;
 };
+// s mod N for an s that a tile's halo can only take one period outside [0, N) (any s is still reduced correctly: the
+// division is the rare path).  An integer division costs some thirty instructions, a tile's plan needs seven or more
+// of them, and a one-wave tile has fewer than a thousand instructions in all.
+__device__ __forceinline__ int mod_near(int s, int N) {
+    if (s >= -N && s < 2 * N) return s < 0 ? s + N : (s >= N ? s - N : s);
+    int m = s % N;
+    return m < 0 ? m + N : m;
+}
 __device__ __forceinline__ Rg rg_make(int s, int c, int N) {
     if (c >= N) return Rg{0, N, N};
-    int m = s % N;
-    if (m < 0) m += N;
-    return Rg{m, c, N};
+    return Rg{mod_near(s, N), c, N};
 }
 __device__ __forceinline__ int rg_local(const Rg &r, int q) {
     int li = q - r.s;
@@ -203,8 +209,7 @@ __device__ __forceinline__ Plan<TL> make_plan(int n, int n0, int n1) {
         const Rg &g = p.G[l + 1];
         const int lo = 2 * g.s - F / 2 + 1;
         const int cnt = 2 * (g.c - 1) + F + 2;   // +2: the replicated pad sample shifts indices by one
-        int lo_c = lo % p.M[l];
-        if (lo_c < 0) lo_c += p.M[l];
+        int lo_c = mod_near(lo, p.M[l]);
         if (lo_c == p.N[l]) lo_c = p.N[l] - 1;   // landed on the pad position
         p.G[l] = rg_make(lo_c - 1, cnt + 1, p.N[l]);
         interior = interior && lo >= 0 && 2 * (g.s + g.c - 1) + F / 2 <= p.N[l] - 1;
@@ -236,8 +241,10 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
     using P = typename Pk<T>::type;
     __shared__ __attribute__((aligned(16))) T lds[cap.total];
     const int tid = threadIdx.x;
-    const int64_t b = blockIdx.x / tiles_per_block;
-    const int tile = (int)(blockIdx.x % tiles_per_block);
+    // grid: x = tile of the block, (z, y) = block (no division by the runtime tile count)
+    const int64_t b = (int64_t)blockIdx.z * 32768 + blockIdx.y;
+    const int tile = (int)blockIdx.x;
+    if (b >= g.n_blocks) return;
     const int n = (int)g.frames[b];
     const int n_lim = MODE == MODE_APPLY ? n + (n & 1) : n;
     const int n0 = tile * S;
@@ -601,7 +608,8 @@ static void launch_tile(Ctx *c, const T *x, T *y, const BlockGeom &g, int64_t ma
     constexpr int S = TileS<T, F, TL, MODE>::S, THREADS = TileS<T, F, TL, MODE>::THREADS;
     const int tiles = (int)ceil_div(max_frames + 1, S);
     const TapsF<T, F> tp = make_taps_f<T, F>(wavelet);
-    ADN_LAUNCH((k_tile<T, F, TL, S, THREADS, MODE>), dim3((unsigned)(tiles * g.n_blocks)), dim3(THREADS),
+    const int64_t by = g.n_blocks < 32768 ? g.n_blocks : 32768;
+    ADN_LAUNCH((k_tile<T, F, TL, S, THREADS, MODE>), dim3((unsigned)tiles, (unsigned)by, (unsigned)ceil_div(g.n_blocks, by)), dim3(THREADS),
                        0, c->stream, x, y, g, tiles, tp, thresh, thr_mode, zeroed, d1, d1_stride, top,
                        top_stride, use_top, c->ablate);
 }

@@ -10,7 +10,8 @@ bs = e.denoise_block_frames(SR, n)
 off = np.concatenate([c * n + np.arange(0, n, bs, dtype=np.int64) for c in range(clips)])
 d_off, d_len = e._i64(off), e._i64(np.full(off.shape, bs, dtype=np.int64))
 y = torch.empty_like(x)
-run = lambda: e.wavelet_denoise(x, d_off, d_len, y, d_off, n_ch=1, wavelet="db4", level=2, max_frames=bs)
+wavelet, level = (sys.argv[1], int(sys.argv[2])) if len(sys.argv) > 2 else ("db4", 2)
+run = lambda: e.wavelet_denoise(x, d_off, d_len, y, d_off, n_ch=1, wavelet=wavelet, level=level, max_frames=bs)
 for ab in (0, 1, 2, 8, 9):
     e.lib.adn_set_option(e._h, 2, ab)
     run(); torch.cuda.synchronize()
@@ -19,5 +20,5 @@ for ab in (0, 1, 2, 8, 9):
         run()
     kt = e.kernel_times()
     e.kernel_timing(False)
-    print("ablate", ab, {k[:24]: round(v["total_ms"] / 3, 3) for k, v in kt.items() if v["total_ms"] / 3 > 0.05})
+    print(wavelet, level, "ablate", ab, {k[:24]: round(v["total_ms"] / 3, 3) for k, v in kt.items() if v["total_ms"] / 3 > 0.05})
 e.lib.adn_set_option(e._h, 2, 0)
