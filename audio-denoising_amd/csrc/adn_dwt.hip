@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "adn_kernels.hpp"
+#include "adn_dwt_shared.hpp"
 
 namespace adn {
 
@@ -87,14 +88,6 @@ __host__ __device__ inline int64_t band_off(int64_t n, int l, int F, int ext) {
     return off;
 }
 
-struct BlockGeom {
-    const int64_t *in_off;
-    const int64_t *frames;
-    const int64_t *out_off;
-    int64_t n_blocks;
-    int64_t a_stride;   // elements per block in each approximation ping-pong buffer
-    int64_t d_stride;   // elements per block in the detail region
-};
 
 // ------------------------------------------------ level-by-level kernels
 // Analysis of level l for every block.  in: x (l == 1) or A[(l-1)&1]; out: A[l&1], D band l.
@@ -138,15 +131,6 @@ __global__ __launch_bounds__(256) void k_fwd_level(const T *__restrict__ x, T *_
     cD[k] = sd;
 }
 
-template <typename T>
-__device__ __forceinline__ T shrink(T d, T t, int thr_mode) {
-    if (thr_mode == ADN_THR_SOFT) {
-        T f = (T)1 - t / fabs(d);
-        f = f < (T)0 ? (T)0 : f;   // keeps NaN (0/0), maps -inf (t/0) to 0
-        return d * f;
-    }
-    return fabs(d) < t ? (T)0 : d;
-}
 
 // Synthesis of level l for every block, with the detail band shrunk on the fly.
 // a: A[l&1] (cA_L when l == L, else the reconstruction), d: D band l.

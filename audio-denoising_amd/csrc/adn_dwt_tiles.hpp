@@ -16,69 +16,9 @@
 
 namespace tiles {
 
-enum { MODE_STATS = 0, MODE_APPLY = 1 };
 constexpr int TL_MAX = 4;
 constexpr int THREADS_MAX = 256;
 constexpr int TILE_SMALL_TL = 2;
-
-template <typename T> struct Pk;
-template <> struct Pk<float> { typedef float type __attribute__((ext_vector_type(2))); };
-template <> struct Pk<double> { typedef double type __attribute__((ext_vector_type(2))); };
-
-template <typename T, int F>
-struct TapsF {
-    T h[F], g[F], rl[F], rh[F];
-    // the same taps as operand pairs of the two-wide multiply-adds:
-    // hg[j] = (h[j], g[j]); rlp[q] = (rl[2q+1], rl[2q]); rhp[q] = (rh[2q+1], rh[2q])
-    typename Pk<T>::type hg[F], rlp[F / 2], rhp[F / 2];
-};
-
-template <typename T, int F>
-static TapsF<T, F> make_taps_f(int wavelet) {
-    const FilterBank &b = filter_bank(wavelet);
-    TapsF<T, F> t{};
-    for (int j = 0; j < F; ++j) {
-        t.h[j] = (T)b.h[j];
-        t.g[j] = (T)b.g[j];
-        t.rl[j] = (T)b.rl[j];
-        t.rh[j] = (T)b.rh[j];
-        t.hg[j].x = (T)b.h[j];
-        t.hg[j].y = (T)b.g[j];
-    }
-    for (int q = 0; q < F / 2; ++q) {
-        t.rlp[q].x = (T)b.rl[2 * q + 1];
-        t.rlp[q].y = (T)b.rl[2 * q];
-        t.rhp[q].x = (T)b.rh[2 * q + 1];
-        t.rhp[q].y = (T)b.rh[2 * q];
-    }
-    return t;
-}
-
-// pywt.threshold with the fp32 division replaced by the hardware reciprocal (1 ulp); keeps the
-// NaN / inf behaviour of the exact form (0/0 -> NaN, t/0 -> inf -> factor 0)
-__device__ __forceinline__ float shrink_fast(float d, float t, int thr_mode) {
-    if (thr_mode == ADN_THR_SOFT) {
-        float f = 1.0f - t * __builtin_amdgcn_rcpf(fabsf(d));
-        f = f < 0.0f ? 0.0f : f;
-        return d * f;
-    }
-    return fabsf(d) < t ? 0.0f : d;
-}
-__device__ __forceinline__ double shrink_fast(double d, double t, int thr_mode) { return shrink(d, t, thr_mode); }
-
-// acc + coef * (q.x, q.x) (HALF = 0) or coef * (q.y, q.y) (HALF = 1): the two-wide fused multiply-add with one half
-// of its second operand selected for both results
-// (half is a constant after unrolling: the branch folds away)
-__device__ __forceinline__ Pk<float>::type pk_fma_half(int half, Pk<float>::type coef, Pk<float>::type q, Pk<float>::type acc) {
-    Pk<float>::type r;
-    if (half == 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "s"(coef), "v"(q), "v"(acc));
-    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]" : "=v"(r) : "s"(coef), "v"(q), "v"(acc));
-    return r;
-}
-__device__ __forceinline__ Pk<double>::type pk_fma_half(int half, Pk<double>::type coef, Pk<double>::type q, Pk<double>::type acc) {
-    const double x = half ? q.y : q.x;
-    return __builtin_elementwise_fma(coef, Pk<double>::type{x, x}, acc);
-}
 
 // canonical contiguous range: indices (s + i) mod N for i < c
 struct Rg {
@@ -163,7 +103,7 @@ struct Plan {
 };
 
 template <int F, int TL, int MODE>
-__device__ __forceinline__ Plan<TL> make_plan(int n, int n0, int n1) {
+__device__ __forceinline__ Plan<TL> make_plan(int n, int n0, int n1, int c0, int c1) {
     Plan<TL> p;
     p.N[0] = n;
 #pragma unroll
@@ -174,9 +114,11 @@ __device__ __forceinline__ Plan<TL> make_plan(int n, int n0, int n1) {
     p.M[TL] = p.N[TL] + (p.N[TL] & 1);
     bool interior = true;
     {
-        int lo = n0, hi = n1;
-        p.own_lo[0] = n0;
-        p.own_hi[0] = n1;
+        // coefficients above the samples [c0, c1) are this tile's to count and export ([n0, n1) unless the tile
+        // borders the wave-resident tiles, whose stored samples sit one position right of their coefficients)
+        int lo = c0, hi = c1;
+        p.own_lo[0] = c0;
+        p.own_hi[0] = c1;
 #pragma unroll
         for (int l = 1; l <= TL; ++l) {
             lo >>= 1;
@@ -235,7 +177,7 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
                                                   int thr_mode, int64_t *__restrict__ zeroed,
                                                   T *__restrict__ d1_out, int64_t d1_stride,
                                                   T *__restrict__ top, int64_t top_stride,
-                                                  int use_top, int ablate) {
+                                                  int use_top, int ablate, WresPlan wp) {
     constexpr Cap<S, F, TL> cap{};
     using V2 = typename Vec2T<T>::type;
     using P = typename Pk<T>::type;
@@ -247,10 +189,32 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
     if (b >= g.n_blocks) return;
     const int n = (int)g.frames[b];
     const int n_lim = MODE == MODE_APPLY ? n + (n & 1) : n;
-    const int n0 = tile * S;
-    if (n0 >= n_lim) return;
-    const int n1 = n0 + S < n_lim ? n0 + S : n_lim;
-    const Plan<TL> p = make_plan<F, TL, MODE>(n, n0, n1);
+    // samples [n0, n1) are this tile's to produce, the coefficients above [c0, c1) its to count and export
+    int n0, n1, c0, c1;
+    if (wp.window > 0 && wres_ring(n, wp.window, wp.run)) return;          // the wave-resident tiles cover this block
+    const int n_windows = wp.window > 0 && n >= wp.window ? (n - wp.window) / wp.advance + 1 : 0;
+    if (n_windows == 0) {
+        n0 = tile * S;
+        if (n0 >= n_lim) return;
+        n1 = n0 + S < n_lim ? n0 + S : n_lim;
+        c0 = n0;
+        c1 = n1;
+    } else {
+        // the wave-resident tiles have the middle of the block: this kernel runs on the head [0, lead) and on the
+        // tail [n_windows advance + lead, n_lim)
+        const int head_tiles = (wp.lead + S - 1) / S;
+        if (tile < head_tiles) {
+            n0 = tile * S;
+            n1 = n0 + S < wp.lead ? n0 + S : wp.lead;
+        } else {
+            n0 = n_windows * wp.advance + wp.lead + (tile - head_tiles) * S;
+            if (n0 >= n_lim) return;
+            n1 = n0 + S < n_lim ? n0 + S : n_lim;
+        }
+        c0 = n0;
+        c1 = n1;
+    }
+    const Plan<TL> p = make_plan<F, TL, MODE>(n, n0, n1, c0, c1);
     const bool interior = p.interior;
 
     // alignment shift of every forward source array: window starts land on even LDS indices
@@ -604,25 +568,38 @@ static constexpr int TILE_MIN_S = 512;      // the smallest of the sizes above
 template <typename T, int F, int TL, int MODE>
 static void launch_tile(Ctx *c, const T *x, T *y, const BlockGeom &g, int64_t max_frames, int wavelet,
                         const double *thresh, int thr_mode, int64_t *zeroed, T *d1, int64_t d1_stride,
-                        T *top, int64_t top_stride, int use_top) {
+                        T *top, int64_t top_stride, int use_top, WresPlan wp) {
     constexpr int S = TileS<T, F, TL, MODE>::S, THREADS = TileS<T, F, TL, MODE>::THREADS;
-    const int tiles = (int)ceil_div(max_frames + 1, S);
+    int tiles = (int)ceil_div(max_frames + 1, S);
+    if (wp.window > 0 && max_frames >= wp.window) {
+        // blocks that hold a window: head and tail only; shorter blocks: all of them
+        const int short_tiles = (int)ceil_div(wp.window + 1, S);
+        const int edge_tiles = (int)(ceil_div(wp.lead, S) + ceil_div(wp.window + wp.advance, S) + 1);
+        tiles = short_tiles > edge_tiles ? short_tiles : edge_tiles;
+    }
     const TapsF<T, F> tp = make_taps_f<T, F>(wavelet);
     const int64_t by = g.n_blocks < 32768 ? g.n_blocks : 32768;
     ADN_LAUNCH((k_tile<T, F, TL, S, THREADS, MODE>), dim3((unsigned)tiles, (unsigned)by, (unsigned)ceil_div(g.n_blocks, by)), dim3(THREADS),
                        0, c->stream, x, y, g, tiles, tp, thresh, thr_mode, zeroed, d1, d1_stride, top,
-                       top_stride, use_top, c->ablate);
+                       top_stride, use_top, c->ablate, wp);
 }
 
 template <typename T, int F, int MODE>
 static void launch_tile_tl(Ctx *c, int TL, const T *x, T *y, const BlockGeom &g, int64_t max_frames,
                            int wavelet, const double *thresh, int thr_mode, int64_t *zeroed, T *d1,
                            int64_t d1_stride, T *top, int64_t top_stride, int use_top) {
+    // binary32: the wave-resident tiles take every window that fits its block, the LDS tiles what is left
+    WresPlan wp{0, 0, 0, 1};
+    if constexpr (sizeof(T) == 4) {
+        if (!(c->ablate & 4096))
+            wres_tiles(c, F, TL < 1 ? 1 : (TL > 4 ? 4 : TL), MODE, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top,
+                       top_stride, use_top, &wp);
+    }
     switch (TL) {
-        case 1: launch_tile<T, F, 1, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top); break;
-        case 2: launch_tile<T, F, 2, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top); break;
-        case 3: launch_tile<T, F, 3, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top); break;
-        default: launch_tile<T, F, 4, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top); break;
+        case 1: launch_tile<T, F, 1, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, wp); break;
+        case 2: launch_tile<T, F, 2, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, wp); break;
+        case 3: launch_tile<T, F, 3, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, wp); break;
+        default: launch_tile<T, F, 4, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, wp); break;
     }
 }
 

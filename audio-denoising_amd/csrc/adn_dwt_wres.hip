@@ -1,0 +1,515 @@
+// Wave-resident tiles of the mono (time-axis, periodization) VisuShrink block denoiser, binary32.
+//
+// pywt.wavedec (denoise.py:77), pywt.threshold (denoise.py:84) and pywt.waverec (denoise.py:87) of up to four
+// levels for the part of a block that lies away from its ends.  One wavefront owns a window of 64 * C consecutive
+// samples; lane l holds samples [l C, (l + 1) C) and every coefficient of every level that sits above them, all in
+// registers.  There is no LDS array, no barrier and no loop: the code of a tile is one straight line of two-wide
+// fused multiply-adds whose operands are selected at compile time, and what a lane needs from beyond its own run
+// (F / 2 - 1 values on either side for an analysis level, F / 4 for a synthesis level) comes from the two
+// neighbouring lanes through whole-wave shifts.
+//
+// Lane 0 has no left neighbour and lane 63 no right one: what they receive instead is wrong, and the error spreads
+// by the filter length per level.  CONE is the number of output samples at either end of the window that can be
+// affected; lanes [LV0, LV1) are clean in full and are the ones that store.  Successive windows of a block advance
+// by A = (LV1 - LV0) C samples, so the clean lanes tile the block; the head and the tail of a block (and blocks
+// shorter than a window, and every wrapped or odd-length case) are left to the LDS tile kernel k_tile, which is
+// launched on those ranges only.  Results are bit-identical to k_tile's: the same products are added in the same
+// order (tap 0 first in the analysis, pywt's order in the synthesis).
+//
+// Index rules (periodization, away from the ends; N even or odd makes no difference there):
+//   analysis   a_l[k], d_l[k] = sum_j (h[j], g[j]) * a_{l-1}[2k + F/2 - j],               j = 0 .. F-1
+//   synthesis  a_{l-1}[2m+1]  = sum_q rl[2q]   a_l[m + F/4 - q] + rh[2q]   d_l[m + F/4 - q], q = 0 .. F/2-1
+//              a_{l-1}[2m+2]  = sum_q rl[2q+1] a_l[m + F/4 - q] + rh[2q+1] d_l[m + F/4 - q]
+// The two synthesis outputs that share their coefficients are an odd sample and the NEXT even one, so between the
+// levels a lane's synthesis results sit one position to the right of its analysis run; the last level pairs an even
+// sample with the next odd one instead (operand pairs put together from neighbouring coefficients) and ends in place.
+#include "adn_dwt_shared.hpp"
+
+namespace adn {
+namespace wres {
+
+using tiles::MODE_APPLY;
+using tiles::MODE_STATS;
+using tiles::TapsF;
+typedef tiles::Pk<float>::type P;
+
+// lane l receives lane l - 1's value (lane 0: zero)
+__device__ __forceinline__ float lane_prev(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));     // wave_shr:1
+}
+// lane l receives lane l + 1's value (lane 63: zero)
+__device__ __forceinline__ float lane_next(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));     // wave_shl:1
+}
+
+// orders a wave's LDS writes before its own later reads (no other wave touches the slot)
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// acc + coef * (q.half, q.half)
+__device__ __forceinline__ P fma_half(int half, P coef, P q, P acc) { return tiles::pk_fma_half(half, coef, q, acc); }
+
+template <int F, int TL, int C>
+struct WresGeom {
+    static constexpr int W = 64 * C;
+    static constexpr int cone() {
+        int dinv[TL + 1] = {};
+        int inv = 0;
+        for (int l = 1; l <= TL; ++l) {
+            inv = (inv + F / 2) / 2;            // ceil((inv + F/2 - 1) / 2): coefficients of level l that see beyond the window
+            dinv[l] = inv;
+        }
+        int s = dinv[TL];
+        for (int l = TL; l >= 1; --l) {
+            const int m = s > dinv[l] ? s : dinv[l];
+            s = 2 * m + F / 2 - 1;
+        }
+        return s;
+    }
+    static constexpr int CONE = cone();
+    static constexpr int LV0 = (CONE + C - 1) / C;         // lane l stores samples [l C, l C + C)
+    static constexpr int LV1 = (W - CONE) / C;
+    static constexpr int A = (LV1 - LV0) * C;
+    static constexpr int LEAD = LV0 * C;                   // first sample a block's first window stores
+    static_assert(C % (1 << TL) == 0 && (C >> (TL - 1)) >= F / 2 && (C >> TL) >= F / 4, "halos come from the adjacent lanes only");
+    static_assert(LV1 > LV0, "no clean lane");
+};
+
+template <int F, int TL, int C, int MODE>
+struct Wres {
+    typedef WresGeom<F, TL, C> G;
+    static constexpr int Q = F / 4;
+
+    struct St {
+        P s0[C / 2];               // samples (x[2p], x[2p+1])
+        P lev[TL + 1][C / 2];      // lev[l][i] = (a_l[i], d_l[i]), i < C >> l: as the analysis leaves them
+        // what stays alive through the turn: the details of every level (shrunk) and the last approximation, two to a
+        // pair -- half the registers of the (a, d) pairs, whose approximation halves are dead once the next level exists
+        P dp[TL + 1][C / 4];       // dp[l][p] = (d_l[2p], d_l[2p+1])
+        P ap[C / 4];               // (a_TL[2p], a_TL[2p+1])
+    };
+    // element i of an array packed two to a pair
+    static __device__ __forceinline__ float at(const P *v, int i) { return (i & 1) ? v[i >> 1].y : v[i >> 1].x; }
+
+    // ---- analysis of level L from level L - 1
+    template <int L>
+    static __device__ __forceinline__ void ana(St &s, const TapsF<float, F> &tp) {
+        constexpr int cs = C >> (L - 1), c = C >> L;
+        if constexpr (L == 1) {
+            // neighbours' samples, packed as they are held: Q pairs on either side (one sample more than needed)
+            P hl[Q], hr[Q];
+#pragma unroll
+            for (int h = 0; h < Q; ++h) {
+                hl[h] = P{lane_prev(s.s0[C / 2 - Q + h].x), lane_prev(s.s0[C / 2 - Q + h].y)};
+                hr[h] = P{lane_next(s.s0[h].x), lane_next(s.s0[h].y)};
+            }
+#pragma unroll
+            for (int i = 0; i < c; ++i) {
+                P acc = {0.0f, 0.0f};
+#pragma unroll
+                for (int j = 0; j < F; ++j) {
+                    const int idx = 2 * i + F / 2 - j;                    // sample relative to the lane's first
+                    const int pi = ((idx + 2 * Q) >> 1) - Q, half = idx & 1;
+                    const P q = pi < 0 ? hl[pi + Q] : (pi >= C / 2 ? hr[pi - C / 2] : s.s0[pi]);
+                    acc = fma_half(half, tp.hg[j], q, acc);
+                }
+                s.lev[1][i] = acc;
+            }
+        } else {
+            // neighbours' approximation coefficients (the low halves of their pairs), packed two to a pair:
+            // slot idx + F/2 on the left (idx = -F/2+1 .. -1), slot idx - cs on the right (idx = cs .. cs + F/2 - 2)
+            constexpr int HV = F / 2;
+            P hl[HV / 2], hr[HV / 2];
+#pragma unroll
+            for (int sl = 0; sl < HV; ++sl) {
+                const float vl = sl >= 1 ? lane_prev(s.lev[L - 1][cs - HV + sl].x) : 0.0f;
+                const float vr = sl <= HV - 2 ? lane_next(s.lev[L - 1][sl].x) : 0.0f;
+                if (sl & 1) {
+                    hl[sl >> 1].y = vl;
+                    hr[sl >> 1].y = vr;
+                } else {
+                    hl[sl >> 1].x = vl;
+                    hr[sl >> 1].x = vr;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < c; ++i) {
+                P acc = {0.0f, 0.0f};
+#pragma unroll
+                for (int j = 0; j < F; ++j) {
+                    const int idx = 2 * i + F / 2 - j;
+                    if (idx < 0) acc = fma_half((idx + HV) & 1, tp.hg[j], hl[(idx + HV) >> 1], acc);
+                    else if (idx >= cs) acc = fma_half((idx - cs) & 1, tp.hg[j], hr[(idx - cs) >> 1], acc);
+                    else acc = fma_half(0, tp.hg[j], s.lev[L - 1][idx], acc);
+                }
+                s.lev[L][i] = acc;
+            }
+        }
+    }
+    // ---- the details of level L, shrunk (KIND 1: soft, 2: hard, 0: as they are), into their packed array; returns
+    // how many fall below the threshold
+    template <int L, int KIND>
+    static __device__ __forceinline__ int pack(St &s, float thr) {
+        constexpr int c = C >> L;
+        int nz = 0;
+#pragma unroll
+        for (int p = 0; p < c / 2; ++p) {
+            float d0 = s.lev[L][2 * p].y, d1 = s.lev[L][2 * p + 1].y;
+            if (KIND != 0) {
+                nz += (fabsf(d0) < thr ? 1 : 0) + (fabsf(d1) < thr ? 1 : 0);
+                d0 = tiles::shrink_fast(d0, thr, KIND == 1 ? ADN_THR_SOFT : ADN_THR_HARD);
+                d1 = tiles::shrink_fast(d1, thr, KIND == 1 ? ADN_THR_SOFT : ADN_THR_HARD);
+            }
+            s.dp[L][p] = P{d0, d1};
+        }
+        if constexpr (L == TL) {
+#pragma unroll
+            for (int p = 0; p < c / 2; ++p) s.ap[p] = P{s.lev[L][2 * p].x, s.lev[L][2 * p + 1].x};
+        }
+        return nz;
+    }
+    // thr_mode: ADN_THR_SOFT / ADN_THR_HARD, or -1 for the statistics pass (no shrinking)
+    template <int L>
+    static __device__ __forceinline__ int ana_all(St &s, const TapsF<float, F> &tp, float thr, int thr_mode) {
+        if constexpr (L <= TL) {
+            ana<L>(s, tp);
+            int nz;
+            if (MODE == MODE_STATS) nz = pack<L, 0>(s, thr);
+            else if (thr_mode == ADN_THR_SOFT) nz = pack<L, 1>(s, thr);
+            else nz = pack<L, 2>(s, thr);
+            return nz + ana_all<L + 1>(s, tp, thr, thr_mode);
+        } else {
+            return 0;
+        }
+    }
+
+    // ---- synthesis of level L - 1 from level L.  rin: the level-L approximation as left by the previous stage
+    // (positions 1 .. c of the lane's run, two to a pair) -- unused for L == TL, whose approximation is ap.
+    // rout[m] = (position 2m + 1, position 2m + 2) of level L - 1.
+    template <int L>
+    static __device__ __forceinline__ void syn(const St &s, const TapsF<float, F> &tp, const P (&rin)[C / 2], P (&rout)[C / 2]) {
+        constexpr int c = C >> L;
+        // details: slot idx + Q on the left (idx = -Q+1 .. -1), slot idx - c on the right (idx = c .. c + Q - 1)
+        P dl[Q / 2], dr[Q / 2], al[Q / 2], ar[Q / 2];
+#pragma unroll
+        for (int sl = 0; sl < Q; ++sl) {
+            const float vl = sl >= 1 ? lane_prev(at(s.dp[L], c - Q + sl)) : 0.0f;
+            const float vr = lane_next(at(s.dp[L], sl));
+            float wl, wr;
+            if constexpr (L == TL) {
+                wl = sl >= 1 ? lane_prev(at(s.ap, c - Q + sl)) : 0.0f;
+                wr = lane_next(at(s.ap, sl));
+            } else {
+                // approximation at positions -Q+1 .. 0 (slot pos + Q - 1): the left lane's positions c-Q+1 .. c;
+                // at positions c+1 .. c+Q-1 (slot pos - c - 1): the right lane's positions 1 .. Q-1
+                wl = lane_prev(at(rin, c - Q + sl));         // held index = position - 1
+                wr = sl <= Q - 2 ? lane_next(at(rin, sl)) : 0.0f;
+            }
+            if (sl & 1) {
+                dl[sl >> 1].y = vl;
+                dr[sl >> 1].y = vr;
+                al[sl >> 1].y = wl;
+                ar[sl >> 1].y = wr;
+            } else {
+                dl[sl >> 1].x = vl;
+                dr[sl >> 1].x = vr;
+                al[sl >> 1].x = wl;
+                ar[sl >> 1].x = wr;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < c; ++m) {
+            P acc = {0.0f, 0.0f};
+#pragma unroll
+            for (int q = 0; q < F / 2; ++q) {
+                const int idx = m + Q - q;                     // coefficient relative to the lane's first
+                const P rl2 = {tp.rl[2 * q], tp.rl[2 * q + 1]}, rh2 = {tp.rh[2 * q], tp.rh[2 * q + 1]};
+                if constexpr (L == TL) {
+                    if (idx < 0) acc = fma_half((idx + Q) & 1, rl2, al[(idx + Q) >> 1], acc);
+                    else if (idx >= c) acc = fma_half((idx - c) & 1, rl2, ar[(idx - c) >> 1], acc);
+                    else acc = fma_half(idx & 1, rl2, s.ap[idx >> 1], acc);
+                } else {
+                    if (idx <= 0) acc = fma_half((idx + Q - 1) & 1, rl2, al[(idx + Q - 1) >> 1], acc);
+                    else if (idx >= c + 1) acc = fma_half((idx - c - 1) & 1, rl2, ar[(idx - c - 1) >> 1], acc);
+                    else acc = fma_half((idx - 1) & 1, rl2, rin[(idx - 1) >> 1], acc);
+                }
+                if (idx < 0) acc = fma_half((idx + Q) & 1, rh2, dl[(idx + Q) >> 1], acc);
+                else if (idx >= c) acc = fma_half((idx - c) & 1, rh2, dr[(idx - c) >> 1], acc);
+                else acc = fma_half(idx & 1, rh2, s.dp[L][idx >> 1], acc);
+            }
+            rout[m] = acc;
+        }
+    }
+    // ---- the last synthesis level with its results in place: rout[m] = (sample 2m, sample 2m + 1) of the lane's run.
+    //   x[2m]   = sum_q rl[2q+1] a_1[m + F/4 - 1 - q] + rh[2q+1] d_1[m + F/4 - 1 - q]
+    //   x[2m+1] = sum_q rl[2q]   a_1[m + F/4 - q]     + rh[2q]   d_1[m + F/4 - q]
+    // The two results take neighbouring coefficients, so an operand is a pair (c[j], c[j+1]): every other one is a pair
+    // as held, the rest are put together from two registers; one level pays that so that a lane's samples leave at
+    // 16-byte aligned addresses.
+    static __device__ __forceinline__ void syn_last(const St &s, const TapsF<float, F> &tp, const P (&rin)[C / 2], P (&rout)[C / 2]) {
+        constexpr int c = C >> 1;
+        float av[c + 2 * Q], dv[c + 2 * Q];               // coefficients -Q .. c + Q - 1 at index + Q
+#pragma unroll
+        for (int j = 0; j < c; ++j) dv[j + Q] = at(s.dp[1], j);
+#pragma unroll
+        for (int h = 0; h < Q; ++h) {
+            dv[h] = lane_prev(at(s.dp[1], c - Q + h));
+            dv[c + Q + h] = lane_next(at(s.dp[1], h));
+        }
+        if constexpr (TL == 1) {
+#pragma unroll
+            for (int j = 0; j < c; ++j) av[j + Q] = at(s.ap, j);
+#pragma unroll
+            for (int h = 0; h < Q; ++h) {
+                av[h] = lane_prev(at(s.ap, c - Q + h));
+                av[c + Q + h] = lane_next(at(s.ap, h));
+            }
+        } else {
+            // rin holds positions 1 .. c: position p is element p - 1
+#pragma unroll
+            for (int p = 1; p <= c; ++p) av[p + Q] = at(rin, p - 1);
+#pragma unroll
+            for (int h = 0; h <= Q; ++h) av[h] = lane_prev(at(rin, c - Q + h - 1));      // positions -Q .. 0: the left lane's c - Q .. c
+#pragma unroll
+            for (int h = 1; h < Q; ++h) av[c + Q + h] = lane_next(at(rin, h - 1));      // positions c + 1 .. c + Q - 1: the right lane's 1 .. Q - 1
+        }
+#pragma unroll
+        for (int m = 0; m < c; ++m) {
+            P acc = {0.0f, 0.0f};
+#pragma unroll
+            for (int q = 0; q < F / 2; ++q) {
+                const int j = m + Q - 1 - q + Q;           // index of the pair's first coefficient in av / dv
+                acc = __builtin_elementwise_fma(tp.rlp[q], P{av[j], av[j + 1]}, acc);
+                acc = __builtin_elementwise_fma(tp.rhp[q], P{dv[j], dv[j + 1]}, acc);
+            }
+            rout[m] = acc;
+        }
+    }
+    template <int L>
+    static __device__ __forceinline__ void syn_all(const St &s, const TapsF<float, F> &tp, const P (&rin)[C / 2], P (&rout)[C / 2]) {
+        if constexpr (L == 1) {
+            syn_last(s, tp, rin, rout);
+        } else {
+            P mid[C / 2];
+            syn<L>(s, tp, rin, mid);
+            syn_all<L - 1>(s, tp, mid, rout);
+        }
+    }
+};
+
+template <int N>
+__device__ __forceinline__ void load_run(float (&v)[N], const float *__restrict__ p) {
+    if constexpr (N % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i) {
+            float4 q;
+            __builtin_memcpy(&q, p + 4 * i, 16);             // 4-byte alignment is all the address has
+            v[4 * i] = q.x;
+            v[4 * i + 1] = q.y;
+            v[4 * i + 2] = q.z;
+            v[4 * i + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = p[i];
+    }
+}
+template <int N>
+__device__ __forceinline__ void store_run(float *__restrict__ p, const float (&v)[N]) {
+    if constexpr (N % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < N / 4; ++i) {
+            const float4 q = {v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+            __builtin_memcpy(p + 4 * i, &q, 16);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) p[i] = v[i];
+    }
+}
+
+// The NV values every lane holds for consecutive positions (lane l: positions first + l NV ...) to dst, through the
+// wave's LDS slot so that a store instruction writes whole cache lines (eight lanes one 128-byte piece of a lane's
+// values) instead of sixteen bytes out of every lane's: R values of every lane at a time (NV / R passes), lane l's at
+// dword l (R + 4) of the slot (the pad keeps the 16-byte accesses of neighbouring lanes on different banks), then
+// 16-byte piece f = 64 k + lane of the pass by the k-th instruction.  Positions at or beyond `wrap` continue at 0
+// (windows that go round their block); lanes outside [lv0, lv1), and those whose first position is at or beyond
+// `stop`, hold nothing to keep.  dst + first must be 16-byte aligned.
+template <int NV>
+struct Staged {
+    static constexpr int R = NV < 32 ? NV : 32;
+    static constexpr int SLOT = 64 * (R + 4);              // floats per wave
+    static __device__ __forceinline__ void store(const float (&v)[NV], float *slot, float *__restrict__ dst, int64_t first,
+                                                 int64_t wrap, int64_t stop, int lv0, int lv1, int lane) {
+        float4 *mine = reinterpret_cast<float4 *>(slot + lane * (R + 4));
+#pragma unroll
+        for (int h = 0; h < NV / R; ++h) {
+            if (h > 0) wave_sync_lds();
+#pragma unroll
+            for (int k = 0; k < R / 4; ++k)
+                mine[k] = float4{v[h * R + 4 * k], v[h * R + 4 * k + 1], v[h * R + 4 * k + 2], v[h * R + 4 * k + 3]};
+            wave_sync_lds();
+#pragma unroll
+            for (int k = 0; k < R / 4; ++k) {
+                const int f = 64 * k + lane, owner = f / (R / 4), within = f % (R / 4);
+                const float4 q = *reinterpret_cast<const float4 *>(slot + owner * (R + 4) + 4 * within);
+                const int64_t run = first + (int64_t)owner * NV;
+                int64_t at = run + h * R + 4 * within;
+                at = at >= wrap ? at - wrap : at;
+                if (owner >= lv0 && owner < lv1 && run < stop) *reinterpret_cast<float4 *>(dst + at) = q;
+            }
+        }
+    }
+};
+
+// One window per wave, four waves per workgroup.  STATS: the finest-band details of the clean lanes to d1_out and,
+// when top != null, their level-TL approximation to top.  APPLY: analysis, shrink, synthesis; the level-TL
+// approximation comes from `top` when use_top (the deep levels' result), else from the window's own analysis.
+template <int F, int TL, int C, int MODE>
+__global__ __launch_bounds__(256) void k_wres(const float *__restrict__ x, float *__restrict__ y, BlockGeom g,
+                                              TapsF<float, F> tp, const double *__restrict__ thresh, int thr_mode,
+                                              int64_t *__restrict__ zeroed, float *__restrict__ d1_out, int64_t d1_stride,
+                                              float *__restrict__ top, int64_t top_stride, int use_top, int ablate) {
+    typedef Wres<F, TL, C, MODE> K;
+    typedef typename K::G G;
+    constexpr int NV = MODE == MODE_APPLY ? C : C / 2;      // values a lane sends out through the stage
+    __shared__ __attribute__((aligned(16))) float stage[4 * Staged<NV>::SLOT];
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.z * 32768 + blockIdx.y;
+    if (b >= g.n_blocks) return;
+    const int64_t n = g.frames[b];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t W0 = ((int64_t)blockIdx.x * 4 + wave) * G::A;                    // first sample of the window
+    // A block whose length is a multiple of the lanes' run is periodic at every level without a repeated last sample:
+    // its windows go round the block (the last ones wrap to its start, a lane's run never straddles the end) and
+    // cover it whole.  Any other block: the windows that fit, the LDS tiles take its two ends.
+    const bool ring = wres_ring(n, G::W, C);
+    if (ring ? W0 >= n : W0 + G::W > n) return;
+    int64_t start = W0 + lane * C;                                                  // the lane's first sample
+    bool clean = lane >= G::LV0 && lane < G::LV1;
+    if (ring) {
+        start = start >= n ? start - n : start;
+        // the last window of the ring stops where the first one's clean lanes begin
+        clean = clean && W0 + (int64_t)(lane - G::LV0) * C < n;
+    }
+
+    typename K::St s;
+    {
+        float v[C];
+        load_run(v, x + g.in_off[b] + start);
+#pragma unroll
+        for (int p = 0; p < C / 2; ++p) s.s0[p] = P{v[2 * p], v[2 * p + 1]};
+    }
+    const float thr = MODE == MODE_APPLY ? (float)thresh[b] : 0.0f;
+    int nz = K::template ana_all<1>(s, tp, thr, thr_mode);
+
+    if (MODE == MODE_STATS) {
+        {
+            float d[C / 2];
+#pragma unroll
+            for (int i = 0; i < C / 2; ++i) d[i] = K::at(s.dp[1], i);
+            float *db = d1_out + b * d1_stride;
+            if ((reinterpret_cast<uintptr_t>(db) & 15) == 0)
+                Staged<C / 2>::store(d, stage + wave * Staged<C / 2>::SLOT, db, W0 >> 1, ring ? n >> 1 : INT64_MAX,
+                                     ring ? (n >> 1) + (int64_t)G::LV0 * (C / 2) : INT64_MAX, G::LV0, G::LV1, lane);
+            else if (clean)
+                store_run(db + (start >> 1), d);
+        }
+        if (!clean) return;
+        if (top != nullptr) {
+            float a[C >> TL];
+#pragma unroll
+            for (int i = 0; i < (C >> TL); ++i) a[i] = K::at(s.ap, i);
+            store_run(top + b * top_stride + (start >> TL), a);
+        }
+        return;
+    }
+
+    if (zeroed != nullptr) {
+        nz = clean ? nz : 0;
+        for (int d = 32; d >= 1; d >>= 1) nz += __shfl_xor(nz, d);
+        if (lane == 0 && nz) atomicAdd((unsigned long long *)&zeroed[b], (unsigned long long)nz);
+    }
+    if (use_top) {
+        float a[C >> TL];
+        load_run(a, top + b * top_stride + (start >> TL));
+#pragma unroll
+        for (int p = 0; p < (C >> TL) / 2; ++p) s.ap[p] = P{a[2 * p], a[2 * p + 1]};
+    }
+    P out[C / 2];
+    {
+        P none[C / 2];
+#pragma unroll
+        for (int i = 0; i < C / 2; ++i) none[i] = P{0.0f, 0.0f};
+        K::template syn_all<TL>(s, tp, none, out);
+    }
+    float v[C];
+#pragma unroll
+    for (int p = 0; p < C / 2; ++p) {
+        v[2 * p] = out[p].x;
+        v[2 * p + 1] = out[p].y;
+    }
+    if (ablate & 8192) return;                             // timing only
+    float *yb = y + g.out_off[b];
+    if ((reinterpret_cast<uintptr_t>(yb) & 15) == 0)
+        Staged<C>::store(v, stage + wave * Staged<C>::SLOT, yb, W0, ring ? n : INT64_MAX, ring ? n + (int64_t)G::LV0 * C : INT64_MAX,
+                         G::LV0, G::LV1, lane);
+    else if (clean)
+        store_run(yb + start, v);
+}
+
+// samples per lane: the smallest run whose halos come from the adjacent lanes only, but at least sixteen
+template <int F, int TL> struct RunOf { static constexpr int C = F * (1 << TL) / 4 < 16 ? 16 : F * (1 << TL) / 4; };
+
+template <int F, int TL, int MODE>
+static int launch_f_tl(Ctx *c, const float *x, float *y, const BlockGeom &g, int64_t max_frames, int wavelet, const double *thresh,
+                       int thr_mode, int64_t *zeroed, float *d1, int64_t d1_stride, float *top, int64_t top_stride, int use_top,
+                       WresPlan *plan) {
+    constexpr int C = RunOf<F, TL>::C;
+    typedef WresGeom<F, TL, C> G;
+    plan->window = G::W;
+    plan->advance = G::A;
+    plan->lead = G::LEAD;
+    plan->run = C;
+    if (max_frames < G::W) return ADN_OK;                  // no block holds a window
+    const int64_t windows = ceil_div(max_frames, G::A);    // of a ring; a block with LDS tiles at its ends has fewer
+    const TapsF<float, F> tp = tiles::make_taps_f<float, F>(wavelet);
+    const int64_t by = g.n_blocks < 32768 ? g.n_blocks : 32768;
+    ADN_LAUNCH_NAMED(MODE == MODE_APPLY ? "k_wres<APPLY>" : "k_wres<STATS>", (k_wres<F, TL, C, MODE>), dim3((unsigned)ceil_div(windows, 4), (unsigned)by, (unsigned)ceil_div(g.n_blocks, by)), dim3(256),
+               0, c->stream, x, y, g, tp, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, c->ablate);
+    return ADN_OK;
+}
+
+template <int F, int MODE>
+static int launch_f(Ctx *c, int TL, const float *x, float *y, const BlockGeom &g, int64_t max_frames, int wavelet, const double *thresh,
+                    int thr_mode, int64_t *zeroed, float *d1, int64_t d1_stride, float *top, int64_t top_stride, int use_top,
+                    WresPlan *plan) {
+    switch (TL) {
+        case 1: return launch_f_tl<F, 1, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
+        case 2: return launch_f_tl<F, 2, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
+        case 3: return launch_f_tl<F, 3, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
+        default: return launch_f_tl<F, 4, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
+    }
+}
+
+}  // namespace wres
+
+// Launches the wave-resident tiles of TL levels on every window that fits its block and reports, in *plan, how the
+// windows tile a block (window length, advance, first stored sample): the caller launches the LDS tiles on what is left.
+int wres_tiles(Ctx *c, int F, int TL, int mode, const float *x, float *y, const BlockGeom &g, int64_t max_frames, int wavelet,
+               const double *thresh, int thr_mode, int64_t *zeroed, float *d1, int64_t d1_stride, float *top, int64_t top_stride,
+               int use_top, WresPlan *plan) {
+    if (F == 8) {
+        if (mode == tiles::MODE_STATS)
+            return wres::launch_f<8, tiles::MODE_STATS>(c, TL, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
+        return wres::launch_f<8, tiles::MODE_APPLY>(c, TL, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
+    }
+    if (mode == tiles::MODE_STATS)
+        return wres::launch_f<16, tiles::MODE_STATS>(c, TL, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
+    return wres::launch_f<16, tiles::MODE_APPLY>(c, TL, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
+}
+
+}  // namespace adn

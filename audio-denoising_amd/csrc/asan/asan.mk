@@ -6,7 +6,7 @@ ASAN_OBJS := $(patsubst %.hip,$(ASAN_DIR)/%.o,$(SRCS))
 SAN       := -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer
 ASAN_FLAGS := --cuda-host-only -fno-gpu-sanitize $(SAN) -O1 -g -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable
 
-$(ASAN_DIR)/%.o: %.hip adn_common.hpp adn_kernels.hpp adn_stft_shared.hpp adn_dwt_tiles.hpp adn_dwt_mad1p.hpp adn_hpss.hpp adn_sortnet30.hpp ../../include/adn.h
+$(ASAN_DIR)/%.o: %.hip adn_common.hpp adn_kernels.hpp adn_stft_shared.hpp adn_dwt_shared.hpp adn_dwt_tiles.hpp adn_dwt_mad1p.hpp adn_hpss.hpp adn_sortnet30.hpp ../../include/adn.h
 	@mkdir -p $(ASAN_DIR)
 	$(HIPCC) $(ASAN_FLAGS) -c -x hip $< -o $@
 

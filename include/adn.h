@@ -81,7 +81,8 @@ int adn_synchronize(adn_ctx *ctx);
  * ADN_OPT_ABLATE (diagnostics): a bit mask.
  *   Bits that make results WRONG (timing only): 1 analysis, 2 synthesis, 4 overlap-add of the shape-generic
  *   STFT kernels skipped (the mono tile kernels read 1, 2, 4, 8 the same way: levels, shrink, deeper levels,
- *   synthesis); 32 the row select decides no bit / the generic subtract kernel skips its magnitudes.
+ *   synthesis); 32 the row select decides no bit / the generic subtract kernel skips its magnitudes; 8192 the
+ *   wave-resident wavelet tiles store no output.
  *   Bit 16: the fused STFT kernels record per-phase shader clocks of wave 0; the launch then ALLOCATES a counter
  *   buffer (hipMalloc), SYNCHRONISES the stream and prints the totals to stderr.
  *   Bits that change no result (they pick another route to the same values, for tests): 64 per-bin statistics on
@@ -89,7 +90,8 @@ int adn_synchronize(adn_ctx *ctx);
  *   energies in their own pass; 256 binary64 STFT stages on the shape-generic kernels; 512 mono blocks take their
  *   threshold statistics in two passes (finest band written to memory, two selections on it) instead of one pass
  *   over the samples; 1024 every grouped row is shared by two waves of the row select (what rows longer than
- *   8192 frames get by themselves).
+ *   8192 frames get by themselves); 2048 the single-pass statistics print the state of blocks that fell back to
+ *   stderr; 4096 binary32 mono blocks run on the LDS tile kernels alone (no wave-resident tiles).
  * ADN_OPT_KERNEL_TIMING: record a HIP event pair on the context's stream around every kernel
  *   launch; adn_kernel_times() reports them.  Switching it off drops unreported records. */
 enum { ADN_OPT_FORCE_GENERIC = 1, ADN_OPT_ABLATE = 2, ADN_OPT_FORCE_FALLBACK = 3, ADN_OPT_KERNEL_TIMING = 4 };
