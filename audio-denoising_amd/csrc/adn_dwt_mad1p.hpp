@@ -47,17 +47,6 @@ static constexpr int M1_TILE = 4096;        // frames per gather workgroup (256 
 static constexpr int M1_STAGE_M = 1024;     // bracket keys a tile can stage: median list (~3.5 % expected),
 static constexpr int M1_STAGE_A = 2048;     // absolute-deviation list (~9 %)
 
-struct M1State {                  // per block
-    unsigned long long lo_m, hi_m;    // key bracket of the median (lo > hi: unusable)
-    double mhat;                      // centre estimate, a value of the block's dtype
-    double alo, ahi;                  // value bracket of |d - mhat| (alo < 0: open below, ahi = inf: open above)
-    unsigned long long below_m, below_a;
-    unsigned int n_m, n_a;            // keys gathered (may exceed the capacity: overflow)
-    int has_nan, usable;
-    int spill;                        // a tile held more bracket keys than its LDS stage: lists incomplete
-    int tie_m, tie_a;                 // lo_m == hi_m (alo == ahi): the keys equal to it are counted, not gathered
-};
-
 template <typename T>
 __device__ __forceinline__ T m1_d1(T w0, T w1, T v0, T v1) {
 #pragma clang fp contract(off)     // two rounded products and one rounded sum everywhere the coefficient is formed
@@ -66,12 +55,6 @@ __device__ __forceinline__ T m1_d1(T w0, T w1, T v0, T v1) {
     s += w1 * v1;
     return s;
 }
-template <typename T>
-__device__ __forceinline__ typename KeyT<T>::type m1_key(T x) {
-    using K = typename KeyT<T>::type;
-    return x != x ? ~(K)0 : key_of(x);
-}
-
 // Where the coefficients come from.  A source knows how many coefficients a block of `frames` frames
 // has and forms any one of them from the block's samples; S is the size of the bracket sample and
 // FRAC_M / FRAC_A the candidate-list capacities (fractions of a block) that go with it: the brackets
@@ -656,7 +639,7 @@ static constexpr int D1_ADJ = 4;           // neighbouring coefficients a thread
 template <typename T, int F, int ADJ>
 __global__ __launch_bounds__(256) void k_d1_gather_direct(const T *__restrict__ x, BlockGeom g, SrcMono<T, F, 0> src,
                                                           M1State *__restrict__ st, T *__restrict__ cand_m, int64_t cap_m,
-                                                          T *__restrict__ cand_a, int64_t cap_a, int64_t tiles_per_block) {
+                                                          T *__restrict__ cand_a, int64_t cap_a, int64_t tiles_per_block, WresPlan skip) {
     using K = typename KeyT<T>::type;
     constexpr int VW = 16 / (int)sizeof(T), NCH = (F + 2 * ADJ) / VW;   // samples per piece, pieces per run
     using VQ = T __attribute__((ext_vector_type(VW)));
@@ -670,6 +653,7 @@ __global__ __launch_bounds__(256) void k_d1_gather_direct(const T *__restrict__ 
     __shared__ int s_nan;
     const int64_t b = blockIdx.x / tiles_per_block;
     const int64_t frames = g.frames[b];
+    if (skip.window > 0 && wres_ring(frames, skip.window, skip.run)) return;     // gathered by the wave-resident windows
     const int64_t n = (frames + 1) >> 1;                    // coefficients of the block
     const int64_t k0 = (blockIdx.x % tiles_per_block) * M1_TILE;
     if (k0 >= n) return;
@@ -1171,9 +1155,13 @@ template <typename T, int F, int S>
 static size_t mono_single_pass_ws_bytes(int64_t n_blocks, int64_t max_frames) {
     return m1_src_ws_bytes<T, SrcMono<T, F, S>>(n_blocks, (max_frames + 1) / 2);
 }
-template <typename T, int F, int S>
+// fused_TL > 0 (binary32): the gather pass is the wave-resident windows of fused_TL levels, which also write the level
+// approximation of every window to `top`; after_windows(plan) then launches whatever covers the rest of `top`, and the
+// direct gather takes the blocks the windows do not cover whole.
+template <typename T, int F, int S, typename After>
 static int mono_mad_single_pass(Ctx *c, const T *d_in, const BlockGeom &g, int64_t max_frames, const T *taps_g,
-                                double *d_sigma_out, double *d_thresh_out, double **thresh_ws) {
+                                double *d_sigma_out, double *d_thresh_out, double **thresh_ws, int wavelet, int fused_TL, T *top,
+                                int64_t top_stride, After after_windows) {
     const int64_t max_count = (max_frames + 1) / 2;
     const int64_t tiles = ceil_div(max_count, (int64_t)M1_TILE);
     ADN_REQUIRE(g.n_blocks * tiles < (int64_t)0x7FFFFFFF, "wavelet batch too large for one launch");
@@ -1181,9 +1169,18 @@ static int mono_mad_single_pass(Ctx *c, const T *d_in, const BlockGeom &g, int64
     SrcMono<T, F, 0> gsrc;
     for (int j = 0; j < F; ++j) src.g[j] = gsrc.g[j] = taps_g[j];
     auto gather = [&](M1State *st, T *cand_m, int64_t cap_m, T *cand_a, int64_t cap_a) -> int {
+        // binary32: blocks that the wave-resident windows cover whole are gathered by them, the rest here
+        WresPlan skip{0, 0, 0, 1};
+        if constexpr (sizeof(T) == 4) {
+            if (fused_TL > 0) {
+                ADN_TRY(wres_gather(c, F, fused_TL, d_in, g, max_frames, wavelet, WresGather{st, cand_m, cap_m, cand_a, cap_a}, top,
+                                    top_stride, &skip));
+                ADN_TRY(after_windows(skip));
+            }
+        }
         if (tiles > 0)
             ADN_LAUNCH((k_d1_gather_direct<T, F, D1_ADJ>), dim3((unsigned)(g.n_blocks * tiles)), dim3(256), 0, c->stream, d_in, g, gsrc, st,
-                               cand_m, cap_m, cand_a, cap_a, tiles);
+                               cand_m, cap_m, cand_a, cap_a, tiles, skip);
         return ADN_OK;
     };
     return mad_single_pass<T>(c, d_in, g, max_count, src, "k_d1_sample", gather, d_sigma_out, d_thresh_out, thresh_ws);

@@ -34,6 +34,32 @@ struct WresPlan {
 };
 __host__ __device__ inline bool wres_ring(int64_t n, int window, int run) { return n >= window && n % run == 0; }
 
+struct M1State {                  // per block
+    unsigned long long lo_m, hi_m;    // key bracket of the median (lo > hi: unusable)
+    double mhat;                      // centre estimate, a value of the block's dtype
+    double alo, ahi;                  // value bracket of |d - mhat| (alo < 0: open below, ahi = inf: open above)
+    unsigned long long below_m, below_a;
+    unsigned int n_m, n_a;            // keys gathered (may exceed the capacity: overflow)
+    int has_nan, usable;
+    int spill;                        // a tile held more bracket keys than its LDS stage: lists incomplete
+    int tie_m, tie_a;                 // lo_m == hi_m (alo == ahi): the keys equal to it are counted, not gathered
+};
+
+template <typename T>
+__device__ __forceinline__ typename KeyT<T>::type m1_key(T x) {
+    using K = typename KeyT<T>::type;
+    return x != x ? ~(K)0 : key_of(x);
+}
+
+// Where the single-pass statistics keep a batch's states and candidate lists (see adn_dwt_mad1p.hpp)
+struct WresGather {
+    M1State *st;
+    float *cand_m;
+    int64_t cap_m;
+    float *cand_a;
+    int64_t cap_a;
+};
+
 namespace tiles {
 
 enum { MODE_STATS = 0, MODE_APPLY = 1 };
@@ -102,5 +128,11 @@ __device__ __forceinline__ Pk<double>::type pk_fma_half(int half, Pk<double>::ty
 int wres_tiles(Ctx *c, int F, int TL, int mode, const float *x, float *y, const BlockGeom &g, int64_t max_frames, int wavelet,
                const double *thresh, int thr_mode, int64_t *zeroed, float *d1, int64_t d1_stride, float *top, int64_t top_stride,
                int use_top, WresPlan *plan);
+
+// The gather pass of the single-pass statistics (finest-band coefficients against the blocks' brackets) for every block
+// that the windows of TL levels cover whole (`*plan` says which: wres_ring(frames, plan->window, plan->run)); when
+// top != null the level-TL approximation of EVERY block's windows is written as by the statistics mode of wres_tiles.
+int wres_gather(Ctx *c, int F, int TL, const float *x, const BlockGeom &g, int64_t max_frames, int wavelet, WresGather gat,
+                float *top, int64_t top_stride, WresPlan *plan);
 
 }  // namespace adn

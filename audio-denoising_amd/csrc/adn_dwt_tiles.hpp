@@ -261,7 +261,7 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
                         nz += (k >= p.own_lo[l] && k < p.own_hi[l] && fabs(sd) < thr) ? 1 : 0;
                         dD[il] = shrink_fast(sd, thr, thr_mode);
                     }
-                } else if (l == 1) {
+                } else if (l == 1 && d1_out != nullptr) {
                     const int k = dr.s + i;
                     if (k >= p.own_lo[1] && k < p.own_hi[1]) d1_out[b * d1_stride + k] = sd;
                 }
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
                         nz += (k >= p.own_lo[l] && k < p.own_hi[l] && fabs(sd) < thr) ? 1 : 0;
                         dD[il] = shrink_fast(sd, thr, thr_mode);
                     }
-                } else if (l == 1) {
+                } else if (l == 1 && d1_out != nullptr) {
                     if (k >= p.own_lo[1] && k < p.own_hi[1]) d1_out[b * d1_stride + k] = sd;
                 }
             }
@@ -587,10 +587,12 @@ static void launch_tile(Ctx *c, const T *x, T *y, const BlockGeom &g, int64_t ma
 template <typename T, int F, int MODE>
 static void launch_tile_tl(Ctx *c, int TL, const T *x, T *y, const BlockGeom &g, int64_t max_frames,
                            int wavelet, const double *thresh, int thr_mode, int64_t *zeroed, T *d1,
-                           int64_t d1_stride, T *top, int64_t top_stride, int use_top) {
+                           int64_t d1_stride, T *top, int64_t top_stride, int use_top, const WresPlan *given = nullptr) {
     // binary32: the wave-resident tiles take every window that fits its block, the LDS tiles what is left
+    // (given: the windows have been launched by the caller)
     WresPlan wp{0, 0, 0, 1};
-    if constexpr (sizeof(T) == 4) {
+    if (given != nullptr) wp = *given;
+    else if constexpr (sizeof(T) == 4) {
         if (!(c->ablate & 4096))
             wres_tiles(c, F, TL < 1 ? 1 : (TL > 4 ? 4 : TL), MODE, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top,
                        top_stride, use_top, &wp);
@@ -641,6 +643,42 @@ static int denoise_f(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_f
     // (finest-band coefficients formed on the fly, bracket candidates gathered), no coefficient array.  The
     // small bracket sample keeps the per-block sampling cheap; its longer candidate lists must fit LDS.
     constexpr int S_SMALL = 4096, S_LARGE = 16384;
+    auto no_windows = [](const WresPlan &) -> int { return ADN_OK; };
+    // Deeper transforms, binary32: the same statistics, their gather pass fused into the wave-resident windows that
+    // write the level-TL approximation for the deep levels (no finest band in memory, one pass over the samples for
+    // both); the LDS tiles write the approximation of what the windows leave, the direct gather takes those blocks.
+    if (deep && sizeof(T) == 4 && !d_thresh_given && !(c->ablate & (512 | 4096)) && max_frames >= 4096) {
+        const bool small = mono_single_pass_applicable<T, F, S_SMALL>(c, 0, max_frames);
+        const bool large = !small && mono_single_pass_applicable<T, F, S_LARGE>(c, g.n_blocks, max_frames);
+        if (small || large) {
+            const TapsF<T, F> tp = make_taps_f<T, F>(wavelet);
+            const size_t nT = (size_t)g.n_blocks * top_stride;
+            ADN_TRY(ws_reserve(c, ws_need(nT, sizeof(T)) + (small ? mono_single_pass_ws_bytes<T, F, S_SMALL>(g.n_blocks, max_frames)
+                                                                   : mono_single_pass_ws_bytes<T, F, S_LARGE>(g.n_blocks, max_frames))));
+            T *top = ws_take<T>(c, nT);
+            auto rest_of_top = [&](const WresPlan &wp) -> int {
+                launch_tile_tl<T, F, MODE_STATS>(c, TL, d_in, (T *)nullptr, g, max_frames, wavelet, nullptr, thr_mode, nullptr, (T *)nullptr,
+                                                 d1_stride, top, top_stride, 0, &wp);
+                return ADN_OK;
+            };
+            if (small)
+                ADN_TRY((mono_mad_single_pass<T, F, S_SMALL>(c, d_in, g, max_frames, tp.g, d_sigma, d_thresh, &thresh, wavelet, TL, top,
+                                                             top_stride, rest_of_top)));
+            else
+                ADN_TRY((mono_mad_single_pass<T, F, S_LARGE>(c, d_in, g, max_frames, tp.g, d_sigma, d_thresh, &thresh, wavelet, TL, top,
+                                                             top_stride, rest_of_top)));
+            if (deep_lds > 48 * 1024)
+                ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_deep<T, F>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)deep_lds));
+            ADN_LAUNCH((k_deep<T, F>), dim3((unsigned)g.n_blocks), dim3(DEEP_THREADS), deep_lds, c->stream, top, top_stride, g, TL, level, tp,
+                       thresh, thr_mode, d_zeroed);
+            launch_tile_tl<T, F, MODE_APPLY>(c, TL, d_in, d_out, g, max_frames, wavelet, thresh, thr_mode, d_zeroed, (T *)nullptr, 0, top,
+                                             top_stride, 1);
+            ADN_HIP(hipGetLastError());
+            *handled = true;
+            return ADN_OK;
+        }
+    }
     const bool want_single = !deep && !d_thresh_given && !(c->ablate & 512);
     const bool single_small = want_single && mono_single_pass_applicable<T, F, S_SMALL>(c, 0, max_frames);
     const bool single_large = want_single && !single_small && mono_single_pass_applicable<T, F, S_LARGE>(c, g.n_blocks, max_frames);
@@ -648,10 +686,10 @@ static int denoise_f(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_f
         const TapsF<T, F> tp = make_taps_f<T, F>(wavelet);
         if (single_small) {
             ADN_TRY(ws_reserve(c, mono_single_pass_ws_bytes<T, F, S_SMALL>(g.n_blocks, max_frames)));
-            ADN_TRY((mono_mad_single_pass<T, F, S_SMALL>(c, d_in, g, max_frames, tp.g, d_sigma, d_thresh, &thresh)));
+            ADN_TRY((mono_mad_single_pass<T, F, S_SMALL>(c, d_in, g, max_frames, tp.g, d_sigma, d_thresh, &thresh, wavelet, 0, (T *)nullptr, 0, no_windows)));
         } else {
             ADN_TRY(ws_reserve(c, mono_single_pass_ws_bytes<T, F, S_LARGE>(g.n_blocks, max_frames)));
-            ADN_TRY((mono_mad_single_pass<T, F, S_LARGE>(c, d_in, g, max_frames, tp.g, d_sigma, d_thresh, &thresh)));
+            ADN_TRY((mono_mad_single_pass<T, F, S_LARGE>(c, d_in, g, max_frames, tp.g, d_sigma, d_thresh, &thresh, wavelet, 0, (T *)nullptr, 0, no_windows)));
         }
         launch_tile_tl<T, F, MODE_APPLY>(c, TL, d_in, d_out, g, max_frames, wavelet, thresh, thr_mode, d_zeroed,
                                          (T *)nullptr, 0, (T *)nullptr, 0, 0);

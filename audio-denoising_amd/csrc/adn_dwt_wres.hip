@@ -30,6 +30,7 @@ namespace wres {
 
 using tiles::MODE_APPLY;
 using tiles::MODE_STATS;
+enum { MODE_GATHER = 2 };       // statistics mode with the finest details classified against the blocks' brackets instead of stored
 using tiles::TapsF;
 typedef tiles::Pk<float>::type P;
 
@@ -177,7 +178,7 @@ struct Wres {
         if constexpr (L <= TL) {
             ana<L>(s, tp);
             int nz;
-            if (MODE == MODE_STATS) nz = pack<L, 0>(s, thr);
+            if (MODE != MODE_APPLY) nz = pack<L, 0>(s, thr);
             else if (thr_mode == ADN_THR_SOFT) nz = pack<L, 1>(s, thr);
             else nz = pack<L, 2>(s, thr);
             return nz + ana_all<L + 1>(s, tp, thr, thr_mode);
@@ -365,6 +366,112 @@ struct Staged {
     }
 };
 
+// The gather pass of the single-pass threshold statistics (adn_dwt_mad1p.hpp, k_d1_gather_direct) for the NV finest
+// details a lane holds (coefficients k0 .. k0 + NV - 1 of block b; `own`: they are this wave's to count): keys below
+// each bracket counted, keys inside appended to the block's candidate lists -- one returning atomic per list and wave,
+// positions from a prefix sum over the lanes -- keys of a bracket that is one value only counted.
+static constexpr int GSTAGE_M = 512, GSTAGE_A = 1024;    // candidates of a window that are written out through LDS, per list
+template <int NV>
+__device__ __forceinline__ void gather_details(const float (&d)[NV], bool own, int64_t b, int64_t k0, const WresGather &gat, int lane,
+                                               float *stage_m, float *stage_a, int ablate) {
+    M1State *st = gat.st + b;
+    const uint32_t lo = (uint32_t)st->lo_m, hi = (uint32_t)st->hi_m;
+    if (st->lo_m > st->hi_m) return;                       // no usable bracket: the block goes to the exact fallback
+    const unsigned long long owners = __ballot(own);
+    if (owners == 0) return;
+    if (st->lo_m == 0 && st->hi_m == 0xFFFFFFFFull) {
+        // short block, every coefficient is a candidate of both lists: stored in place
+        bool nan = false;
+        if (own) {
+            store_run(gat.cand_m + b * gat.cap_m + k0, d);
+            store_run(gat.cand_a + b * gat.cap_a + k0, d);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) nan |= d[i] != d[i];
+        }
+        if (nan) st->has_nan = 1;
+        if (lane == 0) {
+            const unsigned int cnt = (unsigned int)__popcll(owners) * NV;
+            atomicAdd(&st->n_m, cnt);
+            atomicAdd(&st->n_a, cnt);
+        }
+        return;
+    }
+    const float mhat = (float)st->mhat, alo = (float)st->alo, ahi = (float)st->ahi;
+    const bool tie_m = st->tie_m != 0, tie_a = st->tie_a != 0;
+    const uint32_t span = hi - lo;
+    unsigned int below_m = 0, below_a = 0, cm = 0, ca = 0;
+    unsigned int km = 0, ka = 0;                           // bit i: coefficient i is kept (NV <= 32)
+    bool nan = false;
+    static_assert(NV <= 32, "keep masks are 32 bits");
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float x = d[i];
+        nan |= x != x;
+        const uint32_t k = m1_key(x);
+        below_m += k < lo ? 1u : 0u;
+        const bool keep_m = (uint32_t)(k - lo) <= span;
+        const float a = fabsf(x - mhat);
+        below_a += a < alo ? 1u : 0u;
+        const bool keep_a = a >= alo && a <= ahi;
+        km |= keep_m ? 1u << i : 0u;
+        ka |= keep_a ? 1u << i : 0u;
+    }
+    if (!own) km = ka = below_m = below_a = 0, nan = false;
+    cm = __popc(km);
+    ca = __popc(ka);
+    // inclusive prefix sums over the lanes, both lists in one word (a list of a window holds fewer than 65 536 keys)
+    unsigned int both = cm | (ca << 16);
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        const unsigned int o = __shfl_up(both, dlt);
+        both += lane >= dlt ? o : 0u;
+    }
+    const unsigned int tot = __shfl(both, 63);
+    const unsigned int tm = tot & 0xFFFFu, ta = tot >> 16;
+    unsigned int base_m = 0, base_a = 0;
+    if (lane == 0) {
+        if (tm) base_m = atomicAdd(&st->n_m, tm);
+        if (ta) base_a = atomicAdd(&st->n_a, ta);
+    }
+    base_m = __shfl(base_m, 0);
+    base_a = __shfl(base_a, 0);
+    for (int dlt = 32; dlt >= 1; dlt >>= 1) {
+        below_m += __shfl_xor(below_m, dlt);
+        below_a += __shfl_xor(below_a, dlt);
+    }
+    if (lane == 0) {
+        if (below_m) atomicAdd(&st->below_m, (unsigned long long)below_m);
+        if (below_a) atomicAdd(&st->below_a, (unsigned long long)below_a);
+    }
+    if (nan) st->has_nan = 1;
+    if (ablate & 8192) return;                             // timing only
+    // The kept keys leave through the wave's LDS stage (compacted there, then written as consecutive elements of the
+    // list); a window with more of them than the stage holds writes them one by one.
+    auto emit = [&](unsigned int keep, unsigned int mine, unsigned int incl, unsigned int total, unsigned int base, float *stage,
+                    unsigned int stage_cap, float *dst, int64_t cap) {
+        if (total == 0) return;
+        unsigned int p = incl - mine;                       // the lane's first position among the window's kept keys
+        if (total <= stage_cap) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (keep >> i & 1u) stage[p++] = d[i];
+            wave_sync_lds();
+            for (unsigned int q = lane; q < total; q += 64)
+                if ((int64_t)base + q < cap) dst[(int64_t)base + q] = stage[q];     // beyond the capacity: seen by n_m > cap_m
+            wave_sync_lds();
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (keep >> i & 1u) {
+                    if ((int64_t)base + p < cap) dst[(int64_t)base + p] = d[i];
+                    ++p;
+                }
+        }
+    };
+    if (!tie_m) emit(km, cm, both & 0xFFFFu, tm, base_m, stage_m, GSTAGE_M, gat.cand_m + b * gat.cap_m, gat.cap_m);
+    if (!tie_a) emit(ka, ca, both >> 16, ta, base_a, stage_a, GSTAGE_A, gat.cand_a + b * gat.cap_a, gat.cap_a);
+}
+
 // One window per wave, four waves per workgroup.  STATS: the finest-band details of the clean lanes to d1_out and,
 // when top != null, their level-TL approximation to top.  APPLY: analysis, shrink, synthesis; the level-TL
 // approximation comes from `top` when use_top (the deep levels' result), else from the window's own analysis.
@@ -372,11 +479,11 @@ template <int F, int TL, int C, int MODE>
 __global__ __launch_bounds__(256) void k_wres(const float *__restrict__ x, float *__restrict__ y, BlockGeom g,
                                               TapsF<float, F> tp, const double *__restrict__ thresh, int thr_mode,
                                               int64_t *__restrict__ zeroed, float *__restrict__ d1_out, int64_t d1_stride,
-                                              float *__restrict__ top, int64_t top_stride, int use_top, int ablate) {
+                                              float *__restrict__ top, int64_t top_stride, int use_top, int ablate, WresGather gat) {
     typedef Wres<F, TL, C, MODE> K;
     typedef typename K::G G;
     constexpr int NV = MODE == MODE_APPLY ? C : C / 2;      // values a lane sends out through the stage
-    __shared__ __attribute__((aligned(16))) float stage[4 * Staged<NV>::SLOT];
+    __shared__ __attribute__((aligned(16))) float stage[MODE == MODE_GATHER ? 4 * (GSTAGE_M + GSTAGE_A) : 4 * Staged<NV>::SLOT];
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.z * 32768 + blockIdx.y;
     if (b >= g.n_blocks) return;
@@ -388,6 +495,7 @@ __global__ __launch_bounds__(256) void k_wres(const float *__restrict__ x, float
     // cover it whole.  Any other block: the windows that fit, the LDS tiles take its two ends.
     const bool ring = wres_ring(n, G::W, C);
     if (ring ? W0 >= n : W0 + G::W > n) return;
+    if (MODE == MODE_GATHER && !ring && top == nullptr) return;     // gathered by k_d1_gather_direct
     int64_t start = W0 + lane * C;                                                  // the lane's first sample
     bool clean = lane >= G::LV0 && lane < G::LV1;
     if (ring) {
@@ -406,6 +514,22 @@ __global__ __launch_bounds__(256) void k_wres(const float *__restrict__ x, float
     const float thr = MODE == MODE_APPLY ? (float)thresh[b] : 0.0f;
     int nz = K::template ana_all<1>(s, tp, thr, thr_mode);
 
+    if (MODE == MODE_GATHER) {
+        if (ring) {
+            float d[C / 2];
+#pragma unroll
+            for (int i = 0; i < C / 2; ++i) d[i] = K::at(s.dp[1], i);
+            float *gs = stage + wave * (GSTAGE_M + GSTAGE_A);
+            gather_details(d, clean, b, start >> 1, gat, lane, gs, gs + GSTAGE_M, ablate);
+        }
+        if (clean && top != nullptr) {
+            float a[C >> TL];
+#pragma unroll
+            for (int i = 0; i < (C >> TL); ++i) a[i] = K::at(s.ap, i);
+            store_run(top + b * top_stride + (start >> TL), a);
+        }
+        return;
+    }
     if (MODE == MODE_STATS) {
         {
             float d[C / 2];
@@ -479,7 +603,7 @@ static int launch_f_tl(Ctx *c, const float *x, float *y, const BlockGeom &g, int
     const TapsF<float, F> tp = tiles::make_taps_f<float, F>(wavelet);
     const int64_t by = g.n_blocks < 32768 ? g.n_blocks : 32768;
     ADN_LAUNCH_NAMED(MODE == MODE_APPLY ? "k_wres<APPLY>" : "k_wres<STATS>", (k_wres<F, TL, C, MODE>), dim3((unsigned)ceil_div(windows, 4), (unsigned)by, (unsigned)ceil_div(g.n_blocks, by)), dim3(256),
-               0, c->stream, x, y, g, tp, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, c->ablate);
+               0, c->stream, x, y, g, tp, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, c->ablate, WresGather{nullptr, nullptr, 0, nullptr, 0});
     return ADN_OK;
 }
 
@@ -495,7 +619,41 @@ static int launch_f(Ctx *c, int TL, const float *x, float *y, const BlockGeom &g
     }
 }
 
+template <int F, int TL, int C>
+static int launch_gather(Ctx *c, const float *x, const BlockGeom &g, int64_t max_frames, int wavelet, WresGather gat, float *top,
+                         int64_t top_stride, WresPlan *plan) {
+    typedef WresGeom<F, TL, C> G;
+    plan->window = G::W;
+    plan->advance = G::A;
+    plan->lead = G::LEAD;
+    plan->run = C;
+    if (max_frames < G::W) {
+        plan->window = 0;                                  // no block holds a window: nothing is gathered here
+        return ADN_OK;
+    }
+    const int64_t windows = ceil_div(max_frames, G::A);
+    const TapsF<float, F> tp = tiles::make_taps_f<float, F>(wavelet);
+    const int64_t by = g.n_blocks < 32768 ? g.n_blocks : 32768;
+    ADN_LAUNCH_NAMED("k_wres<GATHER>", (k_wres<F, TL, C, MODE_GATHER>), dim3((unsigned)ceil_div(windows, 4), (unsigned)by, (unsigned)ceil_div(g.n_blocks, by)),
+                     dim3(256), 0, c->stream, x, (float *)nullptr, g, tp, (const double *)nullptr, 0, (int64_t *)nullptr, (float *)nullptr,
+                     (int64_t)0, top, top_stride, 0, c->ablate, gat);
+    return ADN_OK;
+}
+
 }  // namespace wres
+
+int wres_gather(Ctx *c, int F, int TL, const float *x, const BlockGeom &g, int64_t max_frames, int wavelet, WresGather gat,
+                float *top, int64_t top_stride, WresPlan *plan) {
+    // (a gather of one level alone, without the approximation, was measured against the direct gather k_d1_gather_direct on
+    // 2560 blocks of 144 000 samples: 0.46 ms against 0.37 ms -- classifying costs both the same, and the direct kernel's
+    // loads are the better coalesced; so only the four-level form is built, for the blocks that need `top` anyway)
+    if (TL != 4) {
+        set_error("internal: the wave-resident gather is built for four levels");
+        return ADN_ERR_ARG;
+    }
+    if (F == 8) return wres::launch_gather<8, 4, wres::RunOf<8, 4>::C>(c, x, g, max_frames, wavelet, gat, top, top_stride, plan);
+    return wres::launch_gather<16, 4, wres::RunOf<16, 4>::C>(c, x, g, max_frames, wavelet, gat, top, top_stride, plan);
+}
 
 // Launches the wave-resident tiles of TL levels on every window that fits its block and reports, in *plan, how the
 // windows tile a block (window length, advance, first stored sample): the caller launches the LDS tiles on what is left.
