@@ -654,8 +654,16 @@ __global__ __launch_bounds__(256) void k_d1_gather_direct(const T *__restrict__ 
     const int64_t b = blockIdx.x / tiles_per_block;
     const int64_t frames = g.frames[b];
     if (skip.window > 0 && wres_ring(frames, skip.window, skip.run)) return;     // gathered by the wave-resident windows
-    const int64_t n = (frames + 1) >> 1;                    // coefficients of the block
-    const int64_t k0 = (blockIdx.x % tiles_per_block) * M1_TILE;
+    int64_t n = (frames + 1) >> 1;                          // coefficients of the block (of this tile's part of it, below)
+    int64_t k0 = (blockIdx.x % tiles_per_block) * M1_TILE;
+    if (skip.window > 0 && frames >= skip.window) {
+        // the windows have gathered the middle of the block: the first tile takes the coefficients before it, the
+        // second those after it (fewer than M1_TILE: less than a window of samples)
+        const int64_t tile = blockIdx.x % tiles_per_block;
+        if (tile >= 2) return;
+        if (tile == 0) n = skip.lead >> 1;
+        else k0 = wres_tail(frames, skip) >> 1;
+    }
     if (k0 >= n) return;
     const K lo = (K)st[b].lo_m, hi = (K)st[b].hi_m;
     if (lo > hi) return;
@@ -1178,9 +1186,11 @@ static int mono_mad_single_pass(Ctx *c, const T *d_in, const BlockGeom &g, int64
                 ADN_TRY(after_windows(skip));
             }
         }
-        if (tiles > 0)
-            ADN_LAUNCH((k_d1_gather_direct<T, F, D1_ADJ>), dim3((unsigned)(g.n_blocks * tiles)), dim3(256), 0, c->stream, d_in, g, gsrc, st,
-                               cand_m, cap_m, cand_a, cap_a, tiles, skip);
+        // (blocks with windows want two tiles, for their ends)
+        const int64_t gt = skip.window > 0 && tiles < 2 ? 2 : tiles;
+        if (gt > 0)
+            ADN_LAUNCH((k_d1_gather_direct<T, F, D1_ADJ>), dim3((unsigned)(g.n_blocks * gt)), dim3(256), 0, c->stream, d_in, g, gsrc, st,
+                               cand_m, cap_m, cand_a, cap_a, gt, skip);
         return ADN_OK;
     };
     return mad_single_pass<T>(c, d_in, g, max_count, src, "k_d1_sample", gather, d_sigma_out, d_thresh_out, thresh_ws);

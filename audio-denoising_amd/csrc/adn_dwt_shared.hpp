@@ -33,6 +33,11 @@ struct WresPlan {
     int window, advance, lead, run;
 };
 __host__ __device__ inline bool wres_ring(int64_t n, int window, int run) { return n >= window && n % run == 0; }
+// Any other block of n >= window samples: windows at 0, advance, ... while they fit, and one more that ends within a
+// run of the block's end (at the largest multiple of `run` that leaves it inside the block; it owns what the others have
+// not).  The LDS tiles take samples [0, lead) and [wres_tail(n, p), n).
+__host__ __device__ inline int64_t wres_last_window(int64_t n, const WresPlan &p) { return (n - p.window) / p.run * p.run; }
+__host__ __device__ inline int64_t wres_tail(int64_t n, const WresPlan &p) { return wres_last_window(n, p) + p.lead + p.advance; }
 
 struct M1State {                  // per block
     unsigned long long lo_m, hi_m;    // key bracket of the median (lo > hi: unusable)
@@ -129,9 +134,10 @@ int wres_tiles(Ctx *c, int F, int TL, int mode, const float *x, float *y, const 
                const double *thresh, int thr_mode, int64_t *zeroed, float *d1, int64_t d1_stride, float *top, int64_t top_stride,
                int use_top, WresPlan *plan);
 
-// The gather pass of the single-pass statistics (finest-band coefficients against the blocks' brackets) for every block
-// that the windows of TL levels cover whole (`*plan` says which: wres_ring(frames, plan->window, plan->run)); when
-// top != null the level-TL approximation of EVERY block's windows is written as by the statistics mode of wres_tiles.
+// The gather pass of the single-pass statistics (finest-band coefficients against the blocks' brackets) for the
+// coefficients the windows of TL levels own (`*plan` says which: all of a block with wres_ring(frames, plan->window,
+// plan->run), else those above samples [lead, n_windows advance + lead) of a block that holds a window); when
+// top != null the level-TL approximation of every window is written as by the statistics mode of wres_tiles.
 int wres_gather(Ctx *c, int F, int TL, const float *x, const BlockGeom &g, int64_t max_frames, int wavelet, WresGather gat,
                 float *top, int64_t top_stride, WresPlan *plan);
 

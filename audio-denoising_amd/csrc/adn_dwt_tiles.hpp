@@ -201,13 +201,13 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
         c1 = n1;
     } else {
         // the wave-resident tiles have the middle of the block: this kernel runs on the head [0, lead) and on the
-        // tail [n_windows advance + lead, n_lim)
+        // tail [wres_tail, n_lim)
         const int head_tiles = (wp.lead + S - 1) / S;
         if (tile < head_tiles) {
             n0 = tile * S;
             n1 = n0 + S < wp.lead ? n0 + S : wp.lead;
         } else {
-            n0 = n_windows * wp.advance + wp.lead + (tile - head_tiles) * S;
+            n0 = (int)wres_tail(n, wp) + (tile - head_tiles) * S;
             if (n0 >= n_lim) return;
             n1 = n0 + S < n_lim ? n0 + S : n_lim;
         }
@@ -574,7 +574,7 @@ static void launch_tile(Ctx *c, const T *x, T *y, const BlockGeom &g, int64_t ma
     if (wp.window > 0 && max_frames >= wp.window) {
         // blocks that hold a window: head and tail only; shorter blocks: all of them
         const int short_tiles = (int)ceil_div(wp.window + 1, S);
-        const int edge_tiles = (int)(ceil_div(wp.lead, S) + ceil_div(wp.window + wp.advance, S) + 1);
+        const int edge_tiles = (int)(ceil_div(wp.lead, S) + ceil_div(wp.window - wp.lead - wp.advance + wp.run + 2, S));
         tiles = short_tiles > edge_tiles ? short_tiles : edge_tiles;
     }
     const TapsF<T, F> tp = make_taps_f<T, F>(wavelet);

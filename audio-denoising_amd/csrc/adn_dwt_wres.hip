@@ -333,43 +333,40 @@ __device__ __forceinline__ void store_run(float *__restrict__ p, const float (&v
 }
 
 // The NV values every lane holds for consecutive positions (lane l: positions first + l NV ...) to dst, through the
-// wave's LDS slot so that a store instruction writes whole cache lines (eight lanes one 128-byte piece of a lane's
-// values) instead of sixteen bytes out of every lane's: R values of every lane at a time (NV / R passes), lane l's at
-// dword l (R + 4) of the slot (the pad keeps the 16-byte accesses of neighbouring lanes on different banks), then
-// 16-byte piece f = 64 k + lane of the pass by the k-th instruction.  Positions at or beyond `wrap` continue at 0
-// (windows that go round their block); lanes outside [lv0, lv1), and those whose first position is at or beyond
-// `stop`, hold nothing to keep.  dst + first must be 16-byte aligned.
+// wave's LDS slot so that a store instruction writes 1 KB of consecutive memory instead of sixteen bytes out of every
+// lane's values: OWN lanes at a time put their values at dword (l % OWN) (NV + 4) of the slot (the pad keeps the
+// 16-byte accesses of neighbouring lanes on different banks), then the k-th instruction writes 16-byte piece
+// f = 64 k + lane of those OWN NV values.  Positions at or beyond `wrap` continue at 0 (windows that go round their
+// block); lanes outside [lv0, lv1), and those whose first position is before `from` or not before `stop`, hold
+// nothing to keep.  dst + first must be 16-byte aligned.
 template <int NV>
 struct Staged {
-    static constexpr int R = NV < 32 ? NV : 32;
-    static constexpr int SLOT = 64 * (R + 4);              // floats per wave
+    static constexpr int OWN = NV >= 64 ? 32 : 64;
+    static constexpr int SLOT = OWN * (NV + 4);            // floats per wave
     static __device__ __forceinline__ void store(const float (&v)[NV], float *slot, float *__restrict__ dst, int64_t first,
-                                                 int64_t wrap, int64_t stop, int lv0, int lv1, int lane) {
-        float4 *mine = reinterpret_cast<float4 *>(slot + lane * (R + 4));
+                                                 int64_t wrap, int64_t from, int64_t stop, int lv0, int lv1, int lane) {
+        float4 *mine = reinterpret_cast<float4 *>(slot + (lane % OWN) * (NV + 4));
 #pragma unroll
-        for (int h = 0; h < NV / R; ++h) {
+        for (int h = 0; h < 64 / OWN; ++h) {
             if (h > 0) wave_sync_lds();
+            if (OWN == 64 || lane / OWN == h) {
 #pragma unroll
-            for (int k = 0; k < R / 4; ++k)
-                mine[k] = float4{v[h * R + 4 * k], v[h * R + 4 * k + 1], v[h * R + 4 * k + 2], v[h * R + 4 * k + 3]};
+                for (int k = 0; k < NV / 4; ++k) mine[k] = float4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+            }
             wave_sync_lds();
 #pragma unroll
-            for (int k = 0; k < R / 4; ++k) {
-                const int f = 64 * k + lane, owner = f / (R / 4), within = f % (R / 4);
-                const float4 q = *reinterpret_cast<const float4 *>(slot + owner * (R + 4) + 4 * within);
+            for (int k = 0; k < OWN * NV / 256; ++k) {
+                const int f = 64 * k + lane, o = f / (NV / 4), within = f % (NV / 4), owner = OWN * h + o;
+                const float4 q = *reinterpret_cast<const float4 *>(slot + o * (NV + 4) + 4 * within);
                 const int64_t run = first + (int64_t)owner * NV;
-                int64_t at = run + h * R + 4 * within;
+                int64_t at = run + 4 * within;
                 at = at >= wrap ? at - wrap : at;
-                if (owner >= lv0 && owner < lv1 && run < stop) *reinterpret_cast<float4 *>(dst + at) = q;
+                if (owner >= lv0 && owner < lv1 && run >= from && run < stop) *reinterpret_cast<float4 *>(dst + at) = q;
             }
         }
     }
 };
 
-// The gather pass of the single-pass threshold statistics (adn_dwt_mad1p.hpp, k_d1_gather_direct) for the NV finest
-// details a lane holds (coefficients k0 .. k0 + NV - 1 of block b; `own`: they are this wave's to count): keys below
-// each bracket counted, keys inside appended to the block's candidate lists -- one returning atomic per list and wave,
-// positions from a prefix sum over the lanes -- keys of a bracket that is one value only counted.
 static constexpr int GSTAGE_M = 512, GSTAGE_A = 1024;    // candidates of a window that are written out through LDS, per list
 template <int NV>
 __device__ __forceinline__ void gather_details(const float (&d)[NV], bool own, int64_t b, int64_t k0, const WresGather &gat, int lane,
@@ -379,7 +376,7 @@ __device__ __forceinline__ void gather_details(const float (&d)[NV], bool own, i
     if (st->lo_m > st->hi_m) return;                       // no usable bracket: the block goes to the exact fallback
     const unsigned long long owners = __ballot(own);
     if (owners == 0) return;
-    if (st->lo_m == 0 && st->hi_m == 0xFFFFFFFFull) {
+    if (lo == 0 && hi == 0xFFFFFFFFu) {
         // short block, every coefficient is a candidate of both lists: stored in place
         bool nan = false;
         if (own) {
@@ -489,20 +486,30 @@ __global__ __launch_bounds__(256) void k_wres(const float *__restrict__ x, float
     if (b >= g.n_blocks) return;
     const int64_t n = g.frames[b];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t W0 = ((int64_t)blockIdx.x * 4 + wave) * G::A;                    // first sample of the window
+    const int64_t wi = (int64_t)blockIdx.x * 4 + wave;
+    int64_t W0 = wi * G::A;                                                        // first sample of the window
     // A block whose length is a multiple of the lanes' run is periodic at every level without a repeated last sample:
     // its windows go round the block (the last ones wrap to its start, a lane's run never straddles the end) and
-    // cover it whole.  Any other block: the windows that fit, the LDS tiles take its two ends.
+    // cover it whole.  Any other block: the windows that fit and one more that ends within a run of the block's end;
+    // the LDS tiles take what is left at the two ends.
     const bool ring = wres_ring(n, G::W, C);
-    if (ring ? W0 >= n : W0 + G::W > n) return;
-    if (MODE == MODE_GATHER && !ring && top == nullptr) return;     // gathered by k_d1_gather_direct
-    int64_t start = W0 + lane * C;                                                  // the lane's first sample
-    bool clean = lane >= G::LV0 && lane < G::LV1;
+    int64_t own_from = 0, own_stop = INT64_MAX;           // first samples of the runs this window owns lie in [own_from, own_stop)
     if (ring) {
-        start = start >= n ? start - n : start;
-        // the last window of the ring stops where the first one's clean lanes begin
-        clean = clean && W0 + (int64_t)(lane - G::LV0) * C < n;
+        if (W0 >= n) return;
+        own_stop = n + (int64_t)G::LV0 * C;               // the last window stops where the first one's clean lanes begin
+    } else {
+        if (n < G::W) return;
+        const int64_t regular = (n - G::W) / G::A + 1;
+        if (wi > regular) return;
+        if (wi == regular) {
+            W0 = (n - G::W) / C * C;
+            own_from = regular * G::A + G::LEAD;
+            if (W0 + (int64_t)G::LV1 * C <= own_from) return;
+        }
     }
+    int64_t start = W0 + lane * C;                                                  // the lane's first sample
+    const bool clean = lane >= G::LV0 && lane < G::LV1 && start >= own_from && start < own_stop;
+    if (ring) start = start >= n ? start - n : start;
 
     typename K::St s;
     {
@@ -515,7 +522,7 @@ __global__ __launch_bounds__(256) void k_wres(const float *__restrict__ x, float
     int nz = K::template ana_all<1>(s, tp, thr, thr_mode);
 
     if (MODE == MODE_GATHER) {
-        if (ring) {
+        {
             float d[C / 2];
 #pragma unroll
             for (int i = 0; i < C / 2; ++i) d[i] = K::at(s.dp[1], i);
@@ -537,8 +544,8 @@ __global__ __launch_bounds__(256) void k_wres(const float *__restrict__ x, float
             for (int i = 0; i < C / 2; ++i) d[i] = K::at(s.dp[1], i);
             float *db = d1_out + b * d1_stride;
             if ((reinterpret_cast<uintptr_t>(db) & 15) == 0)
-                Staged<C / 2>::store(d, stage + wave * Staged<C / 2>::SLOT, db, W0 >> 1, ring ? n >> 1 : INT64_MAX,
-                                     ring ? (n >> 1) + (int64_t)G::LV0 * (C / 2) : INT64_MAX, G::LV0, G::LV1, lane);
+                Staged<C / 2>::store(d, stage + wave * Staged<C / 2>::SLOT, db, W0 >> 1, ring ? n >> 1 : INT64_MAX, own_from >> 1,
+                                     ring ? own_stop >> 1 : INT64_MAX, G::LV0, G::LV1, lane);
             else if (clean)
                 store_run(db + (start >> 1), d);
         }
@@ -579,8 +586,7 @@ __global__ __launch_bounds__(256) void k_wres(const float *__restrict__ x, float
     if (ablate & 8192) return;                             // timing only
     float *yb = y + g.out_off[b];
     if ((reinterpret_cast<uintptr_t>(yb) & 15) == 0)
-        Staged<C>::store(v, stage + wave * Staged<C>::SLOT, yb, W0, ring ? n : INT64_MAX, ring ? n + (int64_t)G::LV0 * C : INT64_MAX,
-                         G::LV0, G::LV1, lane);
+        Staged<C>::store(v, stage + wave * Staged<C>::SLOT, yb, W0, ring ? n : INT64_MAX, own_from, own_stop, G::LV0, G::LV1, lane);
     else if (clean)
         store_run(yb + start, v);
 }
@@ -599,7 +605,7 @@ static int launch_f_tl(Ctx *c, const float *x, float *y, const BlockGeom &g, int
     plan->lead = G::LEAD;
     plan->run = C;
     if (max_frames < G::W) return ADN_OK;                  // no block holds a window
-    const int64_t windows = ceil_div(max_frames, G::A);    // of a ring; a block with LDS tiles at its ends has fewer
+    const int64_t windows = ceil_div(max_frames, G::A) + 1;    // of a ring; a block with LDS tiles at its ends has no more
     const TapsF<float, F> tp = tiles::make_taps_f<float, F>(wavelet);
     const int64_t by = g.n_blocks < 32768 ? g.n_blocks : 32768;
     ADN_LAUNCH_NAMED(MODE == MODE_APPLY ? "k_wres<APPLY>" : "k_wres<STATS>", (k_wres<F, TL, C, MODE>), dim3((unsigned)ceil_div(windows, 4), (unsigned)by, (unsigned)ceil_div(g.n_blocks, by)), dim3(256),
@@ -631,7 +637,7 @@ static int launch_gather(Ctx *c, const float *x, const BlockGeom &g, int64_t max
         plan->window = 0;                                  // no block holds a window: nothing is gathered here
         return ADN_OK;
     }
-    const int64_t windows = ceil_div(max_frames, G::A);
+    const int64_t windows = ceil_div(max_frames, G::A) + 1;
     const TapsF<float, F> tp = tiles::make_taps_f<float, F>(wavelet);
     const int64_t by = g.n_blocks < 32768 ? g.n_blocks : 32768;
     ADN_LAUNCH_NAMED("k_wres<GATHER>", (k_wres<F, TL, C, MODE_GATHER>), dim3((unsigned)ceil_div(windows, 4), (unsigned)by, (unsigned)ceil_div(g.n_blocks, by)),

@@ -3,7 +3,8 @@ import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "audio-denoising_amd"))
 from adn_hip import get_engine
 e = get_engine(0)
-SR, clips, n = 48000, 256, 30 * 48000
+SR = int(sys.argv[1]) if len(sys.argv) > 1 else 48000
+clips, n = 256, 30 * SR
 x = torch.randn(clips * n, dtype=torch.float32, device="cuda") * 0.1
 bs = e.denoise_block_frames(SR, n)
 off = np.concatenate([c * n + np.arange(0, n, bs, dtype=np.int64) for c in range(clips)])
