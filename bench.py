@@ -332,6 +332,26 @@ def secondary_blocks(eng, args):
             "algorithmic_GBps": round(algb / el / 1e9, 1), "hbm_frac": round(algb / el / 1e9 / HBM_PEAK_GBS, 4)}
     out["mono_wavelet"] = {"workload": "%d x 30 s 48 kHz mono clips, 10 blocks of 144000 samples per clip "
                                        "(BASELINE.json config 3 shape), fp32" % clips, **mono}
+    # the same at 44.1 kHz: blocks of 132 300 samples are no multiple of the 16 / 64 samples a lane of the
+    # wave-resident tiles holds, so the block ends go to the LDS tiles (48 kHz blocks are covered by the windows alone)
+    sr2 = 44100
+    n2 = 30 * sr2
+    bs2 = eng.denoise_block_frames(sr2, n2)
+    off2 = np.concatenate([c * n2 + np.arange(0, n2, bs2, dtype=np.int64) for c in range(clips)])
+    d_off2, d_len2 = eng._i64(off2), eng._i64(np.full(off2.shape, bs2, dtype=np.int64))
+    x2, y2 = x[:clips * n2], y[:clips * n2]
+    mono2 = {}
+    for wavelet, level in (("db4", 2), ("db8", 8)):
+        def run2():
+            eng.wavelet_denoise(x2, d_off2, d_len2, y2, d_off2, n_ch=1, wavelet=wavelet, level=level, max_frames=bs2)
+        run2()
+        el = timed_steps(run2, 5, sync) / 5
+        algb = 2 * 4 * clips * n2
+        mono2["%s_level%d" % (wavelet, level)] = {
+            "ms": round(1e3 * el, 4), "audio_sec_per_sec": clips * 30 / el,
+            "algorithmic_GBps": round(algb / el / 1e9, 1), "hbm_frac": round(algb / el / 1e9 / HBM_PEAK_GBS, 4)}
+    out["mono_wavelet_44k1"] = {"workload": "%d x 30 s 44.1 kHz mono clips, 10 blocks of %d samples per clip, fp32" % (clips, bs2),
+                                **mono2}
     return out
 
 
