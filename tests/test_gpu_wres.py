@@ -40,11 +40,22 @@ def test_wave_resident_tiles_equal_lds_tiles(wavelet, level, thr):
     off = np.concatenate([[0], np.cumsum(LENS + 7)[:-1]]).astype(np.int64)     # block starts at odd element offsets too
     total = int(off[-1] + LENS[-1] + 7)
     x = torch.randn(total, dtype=torch.float32, device="cuda:0", generator=gen) * 0.1
+    # digital silence (0 / 0 in the soft threshold), a quantised quiet block (tied statistics), one NaN, one infinity
+    for blk, kind in ((6, "zero"), (9, "zero"), (15, "quant"), (19, "quant"), (16, "nan"), (7, "inf")):
+        o, n = int(off[blk]), int(LENS[blk])
+        if kind == "zero":
+            x[o:o + n] = 0.0
+        elif kind == "quant":
+            x[o:o + n] = torch.round(x[o:o + n] * 40.0) / 32768.0
+        elif kind == "nan":
+            x[o + n // 2] = float("nan")
+        else:
+            x[o + n // 3] = float("inf")
     y_w, st_w = _run(e, x, off, LENS, 0, wavelet=wavelet, level=level, thr_mode=thr)
     y_l, st_l = _run(e, x, off, LENS, 4096, wavelet=wavelet, level=level, thr_mode=thr)
     assert np.array_equal(y_w.view(np.uint32), y_l.view(np.uint32))
     for a, b in zip(st_w, st_l):
-        assert np.array_equal(a, b)
+        assert np.array_equal(a, b, equal_nan=True)
     # elements between the blocks are nobody's to write
     gaps = np.ones(total, dtype=bool)
     for o, n in zip(off, LENS):
