@@ -21,5 +21,5 @@ for wavelet, level in (("db4", 2), ("db8", 8)):
         kt = e.kernel_times()
         e.kernel_timing(False)
         tot = sum(v["total_ms"] for v in kt.values()) / 3
-        print(wavelet, level, "ablate", ab, "total %.3f" % tot, {k[:26]: round(v["total_ms"] / 3, 3) for k, v in kt.items() if v["total_ms"] / 3 > 0.03}, flush=True)
+        print(wavelet, level, "ablate", ab, "total %.3f" % tot, {k[:26]: round(v["total_ms"] / 3, 3) for k, v in kt.items() if v["total_ms"] / 3 > 0.002}, flush=True)
 e.lib.adn_set_option(e._h, 2, 0)
