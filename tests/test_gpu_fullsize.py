@@ -331,3 +331,93 @@ def test_config4_full_size_file_shards():
         check32(host(yb_k), yb_or)
         want_c, _ = orc.wiener(host(yb_k).astype(np.float64), SR)
         check32(host(first[k]), want_c)
+
+
+@pytest.mark.timeout(600)
+def test_config5_full_size_time_chunks():
+    """BASELINE config 5 at its stated size: ONE 24 h, 96 kHz recording (8 294 400 000 samples, binary64, 66 GB) cut into
+    8 time chunks, all on this GPU in lock step (the code path of one chunk per rank, the all-reduce replaced by a sum
+    over the list).  Wavelet stage: the first and the last 10 % block (829 440 000 samples each) in 8 chunks against the
+    one-call result of the block, bit for bit, the block's sigma against the oracle's MAD of the whole finest band,
+    windows round a seam against the oracle.  Spectral subtraction: the whole recording in 8 chunks against the one-call
+    result, bit for bit, windows round the seams against the oracle.  (The Wiener stage of this recording cannot be
+    rehearsed on one GPU: its power matrix alone is 133 GB in binary64 -- one rank's share is 16.6 GB.)"""
+    from adn_hip import chunked as ck
+    e = engine()
+    sr, K = 96000, 8
+    n = 24 * 3600 * sr
+    x = torch.empty(n, dtype=torch.float64, device="cuda:0")
+    step = 1 << 28
+    for s in range(0, n, step):
+        m = min(step, n - s)
+        e.synth_noisy_speech(m, sr, seed=42, stream=7, start=s, out=x[s:s + m])
+    bs = e.denoise_block_frames(sr, n)
+    assert bs == 829440000 and n == 10 * bs
+    red = ck.LocalReducer()
+    g = orc.filters("db4")[1]
+    for b in (0, 9):
+        blk = x[b * bs:(b + 1) * bs]
+        out = torch.empty_like(blk)
+        sigma1, thresh1, _ = e.wavelet_denoise(blk, e._i64([0]), e._i64([bs]), out, e._i64([0]), want_stats=True, max_frames=bs)
+        owned, halo = ck.plan_wavelet_chunks(bs, K, 2, 8)
+        bufs = [ck.wavelet_chunk_buffer(blk, a, c, halo) for a, c in owned]
+        lens = [c - a for a, c in owned]
+        sigma, thresh = ck.wavelet_block_threshold(e, bufs, lens, halo, bs, "db4", red)
+        assert float(sigma[0]) == float(sigma1[0])
+        assert abs(float(thresh[0]) - float(thresh1[0])) <= 4e-16 * float(thresh1[0])
+        parts = ck.wavelet_block_apply(e, bufs, lens, halo, thresh1.to(torch.float64), "db4", 2)
+        pos = 0
+        for p in parts:
+            assert torch.equal(p, out[pos:pos + p.numel()])
+            pos += p.numel()
+        assert pos == bs
+        del bufs, parts
+        if b == 0:
+            # the oracle's MAD of the block's whole finest band, formed piece by piece (a coefficient needs the 8
+            # samples under its taps: pieces overlap by a margin and keep their interiors)
+            xh = host(blk)
+            piece, margin, cd = 1 << 26, 64, []
+            for s in range(0, bs, piece):
+                a, c = max(s - margin, 0), min(s + piece + margin, bs)
+                d = orc.dwt_per(xh[a:c], "db4")[1]
+                cd.append(d[(s - a) // 2:(s - a) // 2 + (min(s + piece, bs) - s) // 2].copy())
+            # the first and last coefficients of the block wrap round it (periodization)
+            cd = np.concatenate(cd)
+            edge = orc.dwt_per(np.concatenate([xh[-64:], xh[:64]]), "db4")[1]
+            cd[:4] = edge[32:36]
+            cd[-4:] = edge[28:32]
+            assert abs(orc.mad(cd) - float(sigma1[0])) <= 1e-12
+            del cd
+            # windows round the first seam and at the block's end, with the block's threshold
+            t = float(thresh1[0])
+            for w0 in (owned[1][0] - 8192, bs - 16384):
+                xw = xh[w0:w0 + 16384]
+                co = orc.wavedec(xw, "db4", 2)
+                yw = orc.waverec([co[0]] + [orc.threshold(c, t, "soft") for c in co[1:]], "db4")
+                check64(host(out[w0 + 256:w0 + 16384 - 256]), yw[256:-256])
+            del xh
+        del out
+    torch.cuda.empty_cache()
+
+    # ---- spectral subtraction of the whole recording
+    noise = e.synth_noisy_speech(5 * sr, sr, stream=6).to(torch.float64)
+    prof = e.noise_psd(noise, [5 * sr])[0]
+    y1, l1 = e.spectral_subtract(x, [n], prof)
+    assert int(l1[0]) == y1.numel()
+    hops, frames = ck.plan_stft_chunks(n, K)
+    assert frames > 16000000
+    ph = host(prof).astype(np.float64)
+    pos = 0
+    for i, (h0, h1) in enumerate(hops):
+        s0, s1, keep = ck.stft_chunk_window(h0, h1, frames, n)
+        piece = ck.spectral_subtract_chunk(e, x[s0:s1], keep, (h1 - h0) * 512, prof)
+        assert torch.equal(piece, y1[pos:pos + piece.numel()])
+        if i > 0:
+            # oracle on a window round the seam: frames well inside the window see the same samples as in the file
+            s = h0 * 512
+            w0, w1 = s - 20480, s + 20480
+            want = orc.spectral_subtract(host(x[w0:w1]).astype(np.float64), ph)
+            check64(host(y1[s - 8192:s + 8192]), want[s - 8192 - w0:s + 8192 - w0])
+        pos += piece.numel()
+        del piece
+    assert pos == y1.numel()
