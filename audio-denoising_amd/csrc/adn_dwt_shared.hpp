@@ -133,6 +133,9 @@ __device__ __forceinline__ Pk<double>::type pk_fma_half(int half, Pk<double>::ty
 int wres_tiles(Ctx *c, int F, int TL, int mode, const float *x, float *y, const BlockGeom &g, int64_t max_frames, int wavelet,
                const double *thresh, int thr_mode, int64_t *zeroed, float *d1, int64_t d1_stride, float *top, int64_t top_stride,
                int use_top, WresPlan *plan);
+int wres_tiles(Ctx *c, int F, int TL, int mode, const double *x, double *y, const BlockGeom &g, int64_t max_frames, int wavelet,
+               const double *thresh, int thr_mode, int64_t *zeroed, double *d1, int64_t d1_stride, double *top, int64_t top_stride,
+               int use_top, WresPlan *plan);
 
 // The gather pass of the single-pass statistics (finest-band coefficients against the blocks' brackets) for the
 // coefficients the windows of TL levels own (`*plan` says which: all of a block with wres_ring(frames, plan->window,

@@ -592,7 +592,7 @@ static void launch_tile_tl(Ctx *c, int TL, const T *x, T *y, const BlockGeom &g,
     // (given: the windows have been launched by the caller)
     WresPlan wp{0, 0, 0, 1};
     if (given != nullptr) wp = *given;
-    else if constexpr (sizeof(T) == 4) {
+    else {
         if (!(c->ablate & 4096))
             wres_tiles(c, F, TL < 1 ? 1 : (TL > 4 ? 4 : TL), MODE, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top,
                        top_stride, use_top, &wp);

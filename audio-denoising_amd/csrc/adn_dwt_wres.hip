@@ -32,7 +32,6 @@ using tiles::MODE_APPLY;
 using tiles::MODE_STATS;
 enum { MODE_GATHER = 2 };       // statistics mode with the finest details classified against the blocks' brackets instead of stored
 using tiles::TapsF;
-typedef tiles::Pk<float>::type P;
 
 // lane l receives lane l - 1's value (lane 0: zero)
 __device__ __forceinline__ float lane_prev(float v) {
@@ -41,6 +40,19 @@ __device__ __forceinline__ float lane_prev(float v) {
 // lane l receives lane l + 1's value (lane 63: zero)
 __device__ __forceinline__ float lane_next(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));     // wave_shl:1
+}
+// the same for binary64: the two halves of the value
+__device__ __forceinline__ double lane_prev(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)u, 0x138, 0xf, 0xf, true);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(u >> 32), 0x138, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double lane_next(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)u, 0x130, 0xf, 0xf, true);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)(unsigned int)(u >> 32), 0x130, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
 // orders a wave's LDS writes before its own later reads (no other wave touches the slot)
@@ -51,6 +63,7 @@ __device__ __forceinline__ void wave_sync_lds() {
 }
 
 // acc + coef * (q.half, q.half)
+template <typename P>
 __device__ __forceinline__ P fma_half(int half, P coef, P q, P acc) { return tiles::pk_fma_half(half, coef, q, acc); }
 
 template <int F, int TL, int C>
@@ -79,9 +92,10 @@ struct WresGeom {
     static_assert(LV1 > LV0, "no clean lane");
 };
 
-template <int F, int TL, int C, int MODE>
+template <typename T, int F, int TL, int C, int MODE>
 struct Wres {
     typedef WresGeom<F, TL, C> G;
+    typedef typename tiles::Pk<T>::type P;
     static constexpr int Q = F / 4;
 
     struct St {
@@ -93,11 +107,11 @@ struct Wres {
         P ap[C / 4];               // (a_TL[2p], a_TL[2p+1])
     };
     // element i of an array packed two to a pair
-    static __device__ __forceinline__ float at(const P *v, int i) { return (i & 1) ? v[i >> 1].y : v[i >> 1].x; }
+    static __device__ __forceinline__ T at(const P *v, int i) { return (i & 1) ? v[i >> 1].y : v[i >> 1].x; }
 
     // ---- analysis of level L from level L - 1
     template <int L>
-    static __device__ __forceinline__ void ana(St &s, const TapsF<float, F> &tp) {
+    static __device__ __forceinline__ void ana(St &s, const TapsF<T, F> &tp) {
         constexpr int cs = C >> (L - 1), c = C >> L;
         if constexpr (L == 1) {
             // neighbours' samples, packed as they are held: Q pairs on either side (one sample more than needed)
@@ -109,7 +123,7 @@ struct Wres {
             }
 #pragma unroll
             for (int i = 0; i < c; ++i) {
-                P acc = {0.0f, 0.0f};
+                P acc = {(T)0, (T)0};
 #pragma unroll
                 for (int j = 0; j < F; ++j) {
                     const int idx = 2 * i + F / 2 - j;                    // sample relative to the lane's first
@@ -126,8 +140,8 @@ struct Wres {
             P hl[HV / 2], hr[HV / 2];
 #pragma unroll
             for (int sl = 0; sl < HV; ++sl) {
-                const float vl = sl >= 1 ? lane_prev(s.lev[L - 1][cs - HV + sl].x) : 0.0f;
-                const float vr = sl <= HV - 2 ? lane_next(s.lev[L - 1][sl].x) : 0.0f;
+                const T vl = sl >= 1 ? lane_prev(s.lev[L - 1][cs - HV + sl].x) : (T)0;
+                const T vr = sl <= HV - 2 ? lane_next(s.lev[L - 1][sl].x) : (T)0;
                 if (sl & 1) {
                     hl[sl >> 1].y = vl;
                     hr[sl >> 1].y = vr;
@@ -138,7 +152,7 @@ struct Wres {
             }
 #pragma unroll
             for (int i = 0; i < c; ++i) {
-                P acc = {0.0f, 0.0f};
+                P acc = {(T)0, (T)0};
 #pragma unroll
                 for (int j = 0; j < F; ++j) {
                     const int idx = 2 * i + F / 2 - j;
@@ -153,14 +167,14 @@ struct Wres {
     // ---- the details of level L, shrunk (KIND 1: soft, 2: hard, 0: as they are), into their packed array; returns
     // how many fall below the threshold
     template <int L, int KIND>
-    static __device__ __forceinline__ int pack(St &s, float thr) {
+    static __device__ __forceinline__ int pack(St &s, T thr) {
         constexpr int c = C >> L;
         int nz = 0;
 #pragma unroll
         for (int p = 0; p < c / 2; ++p) {
-            float d0 = s.lev[L][2 * p].y, d1 = s.lev[L][2 * p + 1].y;
+            T d0 = s.lev[L][2 * p].y, d1 = s.lev[L][2 * p + 1].y;
             if (KIND != 0) {
-                nz += (fabsf(d0) < thr ? 1 : 0) + (fabsf(d1) < thr ? 1 : 0);
+                nz += (fabs(d0) < thr ? 1 : 0) + (fabs(d1) < thr ? 1 : 0);
                 d0 = tiles::shrink_fast(d0, thr, KIND == 1 ? ADN_THR_SOFT : ADN_THR_HARD);
                 d1 = tiles::shrink_fast(d1, thr, KIND == 1 ? ADN_THR_SOFT : ADN_THR_HARD);
             }
@@ -174,7 +188,7 @@ struct Wres {
     }
     // thr_mode: ADN_THR_SOFT / ADN_THR_HARD, or -1 for the statistics pass (no shrinking)
     template <int L>
-    static __device__ __forceinline__ int ana_all(St &s, const TapsF<float, F> &tp, float thr, int thr_mode) {
+    static __device__ __forceinline__ int ana_all(St &s, const TapsF<T, F> &tp, T thr, int thr_mode) {
         if constexpr (L <= TL) {
             ana<L>(s, tp);
             int nz;
@@ -191,23 +205,23 @@ struct Wres {
     // (positions 1 .. c of the lane's run, two to a pair) -- unused for L == TL, whose approximation is ap.
     // rout[m] = (position 2m + 1, position 2m + 2) of level L - 1.
     template <int L>
-    static __device__ __forceinline__ void syn(const St &s, const TapsF<float, F> &tp, const P (&rin)[C / 2], P (&rout)[C / 2]) {
+    static __device__ __forceinline__ void syn(const St &s, const TapsF<T, F> &tp, const P (&rin)[C / 2], P (&rout)[C / 2]) {
         constexpr int c = C >> L;
         // details: slot idx + Q on the left (idx = -Q+1 .. -1), slot idx - c on the right (idx = c .. c + Q - 1)
         P dl[Q / 2], dr[Q / 2], al[Q / 2], ar[Q / 2];
 #pragma unroll
         for (int sl = 0; sl < Q; ++sl) {
-            const float vl = sl >= 1 ? lane_prev(at(s.dp[L], c - Q + sl)) : 0.0f;
-            const float vr = lane_next(at(s.dp[L], sl));
-            float wl, wr;
+            const T vl = sl >= 1 ? lane_prev(at(s.dp[L], c - Q + sl)) : (T)0;
+            const T vr = lane_next(at(s.dp[L], sl));
+            T wl, wr;
             if constexpr (L == TL) {
-                wl = sl >= 1 ? lane_prev(at(s.ap, c - Q + sl)) : 0.0f;
+                wl = sl >= 1 ? lane_prev(at(s.ap, c - Q + sl)) : (T)0;
                 wr = lane_next(at(s.ap, sl));
             } else {
                 // approximation at positions -Q+1 .. 0 (slot pos + Q - 1): the left lane's positions c-Q+1 .. c;
                 // at positions c+1 .. c+Q-1 (slot pos - c - 1): the right lane's positions 1 .. Q-1
                 wl = lane_prev(at(rin, c - Q + sl));         // held index = position - 1
-                wr = sl <= Q - 2 ? lane_next(at(rin, sl)) : 0.0f;
+                wr = sl <= Q - 2 ? lane_next(at(rin, sl)) : (T)0;
             }
             if (sl & 1) {
                 dl[sl >> 1].y = vl;
@@ -223,7 +237,7 @@ struct Wres {
         }
 #pragma unroll
         for (int m = 0; m < c; ++m) {
-            P acc = {0.0f, 0.0f};
+            P acc = {(T)0, (T)0};
 #pragma unroll
             for (int q = 0; q < F / 2; ++q) {
                 const int idx = m + Q - q;                     // coefficient relative to the lane's first
@@ -250,9 +264,9 @@ struct Wres {
     // The two results take neighbouring coefficients, so an operand is a pair (c[j], c[j+1]): every other one is a pair
     // as held, the rest are put together from two registers; one level pays that so that a lane's samples leave at
     // 16-byte aligned addresses.
-    static __device__ __forceinline__ void syn_last(const St &s, const TapsF<float, F> &tp, const P (&rin)[C / 2], P (&rout)[C / 2]) {
+    static __device__ __forceinline__ void syn_last(const St &s, const TapsF<T, F> &tp, const P (&rin)[C / 2], P (&rout)[C / 2]) {
         constexpr int c = C >> 1;
-        float av[c + 2 * Q], dv[c + 2 * Q];               // coefficients -Q .. c + Q - 1 at index + Q
+        T av[c + 2 * Q], dv[c + 2 * Q];               // coefficients -Q .. c + Q - 1 at index + Q
 #pragma unroll
         for (int j = 0; j < c; ++j) dv[j + Q] = at(s.dp[1], j);
 #pragma unroll
@@ -279,7 +293,7 @@ struct Wres {
         }
 #pragma unroll
         for (int m = 0; m < c; ++m) {
-            P acc = {0.0f, 0.0f};
+            P acc = {(T)0, (T)0};
 #pragma unroll
             for (int q = 0; q < F / 2; ++q) {
                 const int j = m + Q - 1 - q + Q;           // index of the pair's first coefficient in av / dv
@@ -290,7 +304,7 @@ struct Wres {
         }
     }
     template <int L>
-    static __device__ __forceinline__ void syn_all(const St &s, const TapsF<float, F> &tp, const P (&rin)[C / 2], P (&rout)[C / 2]) {
+    static __device__ __forceinline__ void syn_all(const St &s, const TapsF<T, F> &tp, const P (&rin)[C / 2], P (&rout)[C / 2]) {
         if constexpr (L == 1) {
             syn_last(s, tp, rin, rout);
         } else {
@@ -301,30 +315,39 @@ struct Wres {
     }
 };
 
-template <int N>
-__device__ __forceinline__ void load_run(float (&v)[N], const float *__restrict__ p) {
-    if constexpr (N % 4 == 0) {
+// 16-byte pieces of T
+template <typename T> struct PieceOf;
+template <> struct PieceOf<float> { typedef float type __attribute__((ext_vector_type(4))); static constexpr int VW = 4; };
+template <> struct PieceOf<double> { typedef double type __attribute__((ext_vector_type(2))); static constexpr int VW = 2; };
+
+template <typename T, int N>
+__device__ __forceinline__ void load_run(T (&v)[N], const T *__restrict__ p) {
+    typedef typename PieceOf<T>::type V;
+    constexpr int VW = PieceOf<T>::VW;
+    if constexpr (N % VW == 0) {
 #pragma unroll
-        for (int i = 0; i < N / 4; ++i) {
-            float4 q;
-            __builtin_memcpy(&q, p + 4 * i, 16);             // 4-byte alignment is all the address has
-            v[4 * i] = q.x;
-            v[4 * i + 1] = q.y;
-            v[4 * i + 2] = q.z;
-            v[4 * i + 3] = q.w;
+        for (int i = 0; i < N / VW; ++i) {
+            V q;
+            __builtin_memcpy(&q, p + VW * i, 16);            // the element's alignment is all the address has
+#pragma unroll
+            for (int e = 0; e < VW; ++e) v[VW * i + e] = q[e];
         }
     } else {
 #pragma unroll
         for (int i = 0; i < N; ++i) v[i] = p[i];
     }
 }
-template <int N>
-__device__ __forceinline__ void store_run(float *__restrict__ p, const float (&v)[N]) {
-    if constexpr (N % 4 == 0) {
+template <typename T, int N>
+__device__ __forceinline__ void store_run(T *__restrict__ p, const T (&v)[N]) {
+    typedef typename PieceOf<T>::type V;
+    constexpr int VW = PieceOf<T>::VW;
+    if constexpr (N % VW == 0) {
 #pragma unroll
-        for (int i = 0; i < N / 4; ++i) {
-            const float4 q = {v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
-            __builtin_memcpy(p + 4 * i, &q, 16);
+        for (int i = 0; i < N / VW; ++i) {
+            V q;
+#pragma unroll
+            for (int e = 0; e < VW; ++e) q[e] = v[VW * i + e];
+            __builtin_memcpy(p + VW * i, &q, 16);
         }
     } else {
 #pragma unroll
@@ -334,34 +357,41 @@ __device__ __forceinline__ void store_run(float *__restrict__ p, const float (&v
 
 // The NV values every lane holds for consecutive positions (lane l: positions first + l NV ...) to dst, through the
 // wave's LDS slot so that a store instruction writes 1 KB of consecutive memory instead of sixteen bytes out of every
-// lane's values: OWN lanes at a time put their values at dword (l % OWN) (NV + 4) of the slot (the pad keeps the
-// 16-byte accesses of neighbouring lanes on different banks), then the k-th instruction writes 16-byte piece
+// lane's values: OWN lanes at a time put their values at element (l % OWN) (NV + VW) of the slot (the 16-byte pad keeps
+// the 16-byte accesses of neighbouring lanes on different banks), then the k-th instruction writes 16-byte piece
 // f = 64 k + lane of those OWN NV values.  Positions at or beyond `wrap` continue at 0 (windows that go round their
 // block); lanes outside [lv0, lv1), and those whose first position is before `from` or not before `stop`, hold
 // nothing to keep.  dst + first must be 16-byte aligned.
-template <int NV>
+template <typename T, int NV>
 struct Staged {
-    static constexpr int OWN = NV >= 64 ? 32 : 64;
-    static constexpr int SLOT = OWN * (NV + 4);            // floats per wave
-    static __device__ __forceinline__ void store(const float (&v)[NV], float *slot, float *__restrict__ dst, int64_t first,
+    typedef typename PieceOf<T>::type V;
+    static constexpr int VW = PieceOf<T>::VW;
+    static constexpr int OWN = NV * (int)sizeof(T) >= 256 ? 32 : 64;
+    static constexpr int SLOT = OWN * (NV + VW);           // elements per wave
+    static __device__ __forceinline__ void store(const T (&v)[NV], T *slot, T *__restrict__ dst, int64_t first,
                                                  int64_t wrap, int64_t from, int64_t stop, int lv0, int lv1, int lane) {
-        float4 *mine = reinterpret_cast<float4 *>(slot + (lane % OWN) * (NV + 4));
+        V *mine = reinterpret_cast<V *>(slot + (lane % OWN) * (NV + VW));
 #pragma unroll
         for (int h = 0; h < 64 / OWN; ++h) {
             if (h > 0) wave_sync_lds();
             if (OWN == 64 || lane / OWN == h) {
 #pragma unroll
-                for (int k = 0; k < NV / 4; ++k) mine[k] = float4{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+                for (int k = 0; k < NV / VW; ++k) {
+                    V q;
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) q[e] = v[VW * k + e];
+                    mine[k] = q;
+                }
             }
             wave_sync_lds();
 #pragma unroll
-            for (int k = 0; k < OWN * NV / 256; ++k) {
-                const int f = 64 * k + lane, o = f / (NV / 4), within = f % (NV / 4), owner = OWN * h + o;
-                const float4 q = *reinterpret_cast<const float4 *>(slot + o * (NV + 4) + 4 * within);
+            for (int k = 0; k < OWN * (NV / VW) / 64; ++k) {
+                const int f = 64 * k + lane, o = f / (NV / VW), within = f % (NV / VW), owner = OWN * h + o;
+                const V q = *reinterpret_cast<const V *>(slot + o * (NV + VW) + VW * within);
                 const int64_t run = first + (int64_t)owner * NV;
-                int64_t at = run + 4 * within;
+                int64_t at = run + VW * within;
                 at = at >= wrap ? at - wrap : at;
-                if (owner >= lv0 && owner < lv1 && run >= from && run < stop) *reinterpret_cast<float4 *>(dst + at) = q;
+                if (owner >= lv0 && owner < lv1 && run >= from && run < stop) *reinterpret_cast<V *>(dst + at) = q;
             }
         }
     }
@@ -472,15 +502,16 @@ __device__ __forceinline__ void gather_details(const float (&d)[NV], bool own, i
 // One window per wave, four waves per workgroup.  STATS: the finest-band details of the clean lanes to d1_out and,
 // when top != null, their level-TL approximation to top.  APPLY: analysis, shrink, synthesis; the level-TL
 // approximation comes from `top` when use_top (the deep levels' result), else from the window's own analysis.
-template <int F, int TL, int C, int MODE>
-__global__ __launch_bounds__(256) void k_wres(const float *__restrict__ x, float *__restrict__ y, BlockGeom g,
-                                              TapsF<float, F> tp, const double *__restrict__ thresh, int thr_mode,
-                                              int64_t *__restrict__ zeroed, float *__restrict__ d1_out, int64_t d1_stride,
-                                              float *__restrict__ top, int64_t top_stride, int use_top, int ablate, WresGather gat) {
-    typedef Wres<F, TL, C, MODE> K;
+template <typename T, int F, int TL, int C, int MODE>
+__global__ __launch_bounds__(256) void k_wres(const T *__restrict__ x, T *__restrict__ y, BlockGeom g,
+                                              TapsF<T, F> tp, const double *__restrict__ thresh, int thr_mode,
+                                              int64_t *__restrict__ zeroed, T *__restrict__ d1_out, int64_t d1_stride,
+                                              T *__restrict__ top, int64_t top_stride, int use_top, int ablate, WresGather gat) {
+    typedef Wres<T, F, TL, C, MODE> K;
     typedef typename K::G G;
+    typedef typename K::P P;
     constexpr int NV = MODE == MODE_APPLY ? C : C / 2;      // values a lane sends out through the stage
-    __shared__ __attribute__((aligned(16))) float stage[MODE == MODE_GATHER ? 4 * (GSTAGE_M + GSTAGE_A) : 4 * Staged<NV>::SLOT];
+    __shared__ __attribute__((aligned(16))) T stage[MODE == MODE_GATHER ? 4 * (GSTAGE_M + GSTAGE_A) : 4 * Staged<T, NV>::SLOT];
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.z * 32768 + blockIdx.y;
     if (b >= g.n_blocks) return;
@@ -513,24 +544,26 @@ __global__ __launch_bounds__(256) void k_wres(const float *__restrict__ x, float
 
     typename K::St s;
     {
-        float v[C];
+        T v[C];
         load_run(v, x + g.in_off[b] + start);
 #pragma unroll
         for (int p = 0; p < C / 2; ++p) s.s0[p] = P{v[2 * p], v[2 * p + 1]};
     }
-    const float thr = MODE == MODE_APPLY ? (float)thresh[b] : 0.0f;
+    const T thr = MODE == MODE_APPLY ? (T)thresh[b] : (T)0;
     int nz = K::template ana_all<1>(s, tp, thr, thr_mode);
 
     if (MODE == MODE_GATHER) {
         {
-            float d[C / 2];
+            T d[C / 2];
 #pragma unroll
             for (int i = 0; i < C / 2; ++i) d[i] = K::at(s.dp[1], i);
-            float *gs = stage + wave * (GSTAGE_M + GSTAGE_A);
-            gather_details(d, clean, b, start >> 1, gat, lane, gs, gs + GSTAGE_M, ablate);
+            if constexpr (sizeof(T) == 4) {
+                float *gs = stage + wave * (GSTAGE_M + GSTAGE_A);
+                gather_details(d, clean, b, start >> 1, gat, lane, gs, gs + GSTAGE_M, ablate);
+            }
         }
         if (clean && top != nullptr) {
-            float a[C >> TL];
+            T a[C >> TL];
 #pragma unroll
             for (int i = 0; i < (C >> TL); ++i) a[i] = K::at(s.ap, i);
             store_run(top + b * top_stride + (start >> TL), a);
@@ -539,19 +572,19 @@ __global__ __launch_bounds__(256) void k_wres(const float *__restrict__ x, float
     }
     if (MODE == MODE_STATS) {
         {
-            float d[C / 2];
+            T d[C / 2];
 #pragma unroll
             for (int i = 0; i < C / 2; ++i) d[i] = K::at(s.dp[1], i);
-            float *db = d1_out + b * d1_stride;
+            T *db = d1_out + b * d1_stride;
             if ((reinterpret_cast<uintptr_t>(db) & 15) == 0)
-                Staged<C / 2>::store(d, stage + wave * Staged<C / 2>::SLOT, db, W0 >> 1, ring ? n >> 1 : INT64_MAX, own_from >> 1,
+                Staged<T, C / 2>::store(d, stage + wave * Staged<T, C / 2>::SLOT, db, W0 >> 1, ring ? n >> 1 : INT64_MAX, own_from >> 1,
                                      ring ? own_stop >> 1 : INT64_MAX, G::LV0, G::LV1, lane);
             else if (clean)
                 store_run(db + (start >> 1), d);
         }
         if (!clean) return;
         if (top != nullptr) {
-            float a[C >> TL];
+            T a[C >> TL];
 #pragma unroll
             for (int i = 0; i < (C >> TL); ++i) a[i] = K::at(s.ap, i);
             store_run(top + b * top_stride + (start >> TL), a);
@@ -565,7 +598,7 @@ __global__ __launch_bounds__(256) void k_wres(const float *__restrict__ x, float
         if (lane == 0 && nz) atomicAdd((unsigned long long *)&zeroed[b], (unsigned long long)nz);
     }
     if (use_top) {
-        float a[C >> TL];
+        T a[C >> TL];
         load_run(a, top + b * top_stride + (start >> TL));
 #pragma unroll
         for (int p = 0; p < (C >> TL) / 2; ++p) s.ap[p] = P{a[2 * p], a[2 * p + 1]};
@@ -574,55 +607,78 @@ __global__ __launch_bounds__(256) void k_wres(const float *__restrict__ x, float
     {
         P none[C / 2];
 #pragma unroll
-        for (int i = 0; i < C / 2; ++i) none[i] = P{0.0f, 0.0f};
+        for (int i = 0; i < C / 2; ++i) none[i] = P{(T)0, (T)0};
         K::template syn_all<TL>(s, tp, none, out);
     }
-    float v[C];
+    T v[C];
 #pragma unroll
     for (int p = 0; p < C / 2; ++p) {
         v[2 * p] = out[p].x;
         v[2 * p + 1] = out[p].y;
     }
     if (ablate & 8192) return;                             // timing only
-    float *yb = y + g.out_off[b];
+    T *yb = y + g.out_off[b];
     if ((reinterpret_cast<uintptr_t>(yb) & 15) == 0)
-        Staged<C>::store(v, stage + wave * Staged<C>::SLOT, yb, W0, ring ? n : INT64_MAX, own_from, own_stop, G::LV0, G::LV1, lane);
+        Staged<T, C>::store(v, stage + wave * Staged<T, C>::SLOT, yb, W0, ring ? n : INT64_MAX, own_from, own_stop, G::LV0, G::LV1, lane);
     else if (clean)
         store_run(yb + start, v);
 }
 
-// samples per lane: the smallest run whose halos come from the adjacent lanes only, but at least sixteen
-template <int F, int TL> struct RunOf { static constexpr int C = F * (1 << TL) / 4 < 16 ? 16 : F * (1 << TL) / 4; };
+// samples per lane: the smallest run whose halos come from the adjacent lanes only, but at least sixteen; binary64
+// holds sixteen at most (0: no wave-resident form of this transform, the LDS tiles take the whole block)
+template <typename T, int F, int TL> struct RunOf {
+    static constexpr int NEED = F * (1 << TL) / 4;
+    static constexpr int C = sizeof(T) == 8 ? (NEED <= 16 ? 16 : 0) : (NEED < 16 ? 16 : NEED);
+};
 
-template <int F, int TL, int MODE>
-static int launch_f_tl(Ctx *c, const float *x, float *y, const BlockGeom &g, int64_t max_frames, int wavelet, const double *thresh,
-                       int thr_mode, int64_t *zeroed, float *d1, int64_t d1_stride, float *top, int64_t top_stride, int use_top,
+template <typename T, int F, int TL, int MODE>
+static int launch_f_tl(Ctx *c, const T *x, T *y, const BlockGeom &g, int64_t max_frames, int wavelet, const double *thresh,
+                       int thr_mode, int64_t *zeroed, T *d1, int64_t d1_stride, T *top, int64_t top_stride, int use_top,
                        WresPlan *plan) {
-    constexpr int C = RunOf<F, TL>::C;
-    typedef WresGeom<F, TL, C> G;
-    plan->window = G::W;
-    plan->advance = G::A;
-    plan->lead = G::LEAD;
-    plan->run = C;
-    if (max_frames < G::W) return ADN_OK;                  // no block holds a window
-    const int64_t windows = ceil_div(max_frames, G::A) + 1;    // of a ring; a block with LDS tiles at its ends has no more
-    const TapsF<float, F> tp = tiles::make_taps_f<float, F>(wavelet);
-    const int64_t by = g.n_blocks < 32768 ? g.n_blocks : 32768;
-    ADN_LAUNCH_NAMED(MODE == MODE_APPLY ? "k_wres<APPLY>" : "k_wres<STATS>", (k_wres<F, TL, C, MODE>), dim3((unsigned)ceil_div(windows, 4), (unsigned)by, (unsigned)ceil_div(g.n_blocks, by)), dim3(256),
-               0, c->stream, x, y, g, tp, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, c->ablate, WresGather{nullptr, nullptr, 0, nullptr, 0});
-    return ADN_OK;
+    constexpr int C = RunOf<T, F, TL>::C;
+    if constexpr (C == 0) {
+        plan->window = 0;
+        return ADN_OK;
+    } else {
+        typedef WresGeom<F, TL, C> G;
+        plan->window = G::W;
+        plan->advance = G::A;
+        plan->lead = G::LEAD;
+        plan->run = C;
+        if (max_frames < G::W) return ADN_OK;                  // no block holds a window
+        const int64_t windows = ceil_div(max_frames, G::A) + 1;    // of a ring; a block with LDS tiles at its ends has no more
+        const TapsF<T, F> tp = tiles::make_taps_f<T, F>(wavelet);
+        const int64_t by = g.n_blocks < 32768 ? g.n_blocks : 32768;
+        ADN_LAUNCH_NAMED(MODE == MODE_APPLY ? "k_wres<APPLY>" : "k_wres<STATS>", (k_wres<T, F, TL, C, MODE>), dim3((unsigned)ceil_div(windows, 4), (unsigned)by, (unsigned)ceil_div(g.n_blocks, by)), dim3(256),
+                   0, c->stream, x, y, g, tp, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, c->ablate, WresGather{nullptr, nullptr, 0, nullptr, 0});
+        return ADN_OK;
+    }
 }
 
-template <int F, int MODE>
-static int launch_f(Ctx *c, int TL, const float *x, float *y, const BlockGeom &g, int64_t max_frames, int wavelet, const double *thresh,
-                    int thr_mode, int64_t *zeroed, float *d1, int64_t d1_stride, float *top, int64_t top_stride, int use_top,
+template <typename T, int F, int MODE>
+static int launch_f(Ctx *c, int TL, const T *x, T *y, const BlockGeom &g, int64_t max_frames, int wavelet, const double *thresh,
+                    int thr_mode, int64_t *zeroed, T *d1, int64_t d1_stride, T *top, int64_t top_stride, int use_top,
                     WresPlan *plan) {
     switch (TL) {
-        case 1: return launch_f_tl<F, 1, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
-        case 2: return launch_f_tl<F, 2, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
-        case 3: return launch_f_tl<F, 3, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
-        default: return launch_f_tl<F, 4, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
+        case 1: return launch_f_tl<T, F, 1, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
+        case 2: return launch_f_tl<T, F, 2, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
+        case 3: return launch_f_tl<T, F, 3, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
+        default: return launch_f_tl<T, F, 4, MODE>(c, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
     }
+}
+
+template <typename T>
+static int tiles_t(Ctx *c, int F, int TL, int mode, const T *x, T *y, const BlockGeom &g, int64_t max_frames, int wavelet,
+                   const double *thresh, int thr_mode, int64_t *zeroed, T *d1, int64_t d1_stride, T *top, int64_t top_stride,
+                   int use_top, WresPlan *plan) {
+    if (F == 8) {
+        if (mode == tiles::MODE_STATS)
+            return launch_f<T, 8, tiles::MODE_STATS>(c, TL, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
+        return launch_f<T, 8, tiles::MODE_APPLY>(c, TL, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
+    }
+    if (mode == tiles::MODE_STATS)
+        return launch_f<T, 16, tiles::MODE_STATS>(c, TL, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
+    return launch_f<T, 16, tiles::MODE_APPLY>(c, TL, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
 }
 
 template <int F, int TL, int C>
@@ -640,7 +696,7 @@ static int launch_gather(Ctx *c, const float *x, const BlockGeom &g, int64_t max
     const int64_t windows = ceil_div(max_frames, G::A) + 1;
     const TapsF<float, F> tp = tiles::make_taps_f<float, F>(wavelet);
     const int64_t by = g.n_blocks < 32768 ? g.n_blocks : 32768;
-    ADN_LAUNCH_NAMED("k_wres<GATHER>", (k_wres<F, TL, C, MODE_GATHER>), dim3((unsigned)ceil_div(windows, 4), (unsigned)by, (unsigned)ceil_div(g.n_blocks, by)),
+    ADN_LAUNCH_NAMED("k_wres<GATHER>", (k_wres<float, F, TL, C, MODE_GATHER>), dim3((unsigned)ceil_div(windows, 4), (unsigned)by, (unsigned)ceil_div(g.n_blocks, by)),
                      dim3(256), 0, c->stream, x, (float *)nullptr, g, tp, (const double *)nullptr, 0, (int64_t *)nullptr, (float *)nullptr,
                      (int64_t)0, top, top_stride, 0, c->ablate, gat);
     return ADN_OK;
@@ -657,23 +713,22 @@ int wres_gather(Ctx *c, int F, int TL, const float *x, const BlockGeom &g, int64
         set_error("internal: the wave-resident gather is built for four levels");
         return ADN_ERR_ARG;
     }
-    if (F == 8) return wres::launch_gather<8, 4, wres::RunOf<8, 4>::C>(c, x, g, max_frames, wavelet, gat, top, top_stride, plan);
-    return wres::launch_gather<16, 4, wres::RunOf<16, 4>::C>(c, x, g, max_frames, wavelet, gat, top, top_stride, plan);
+    if (F == 8) return wres::launch_gather<8, 4, wres::RunOf<float, 8, 4>::C>(c, x, g, max_frames, wavelet, gat, top, top_stride, plan);
+    return wres::launch_gather<16, 4, wres::RunOf<float, 16, 4>::C>(c, x, g, max_frames, wavelet, gat, top, top_stride, plan);
 }
 
 // Launches the wave-resident tiles of TL levels on every window that fits its block and reports, in *plan, how the
 // windows tile a block (window length, advance, first stored sample): the caller launches the LDS tiles on what is left.
+// plan->window == 0: this transform has no wave-resident form in this precision.
 int wres_tiles(Ctx *c, int F, int TL, int mode, const float *x, float *y, const BlockGeom &g, int64_t max_frames, int wavelet,
                const double *thresh, int thr_mode, int64_t *zeroed, float *d1, int64_t d1_stride, float *top, int64_t top_stride,
                int use_top, WresPlan *plan) {
-    if (F == 8) {
-        if (mode == tiles::MODE_STATS)
-            return wres::launch_f<8, tiles::MODE_STATS>(c, TL, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
-        return wres::launch_f<8, tiles::MODE_APPLY>(c, TL, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
-    }
-    if (mode == tiles::MODE_STATS)
-        return wres::launch_f<16, tiles::MODE_STATS>(c, TL, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
-    return wres::launch_f<16, tiles::MODE_APPLY>(c, TL, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
+    return wres::tiles_t<float>(c, F, TL, mode, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
+}
+int wres_tiles(Ctx *c, int F, int TL, int mode, const double *x, double *y, const BlockGeom &g, int64_t max_frames, int wavelet,
+               const double *thresh, int thr_mode, int64_t *zeroed, double *d1, int64_t d1_stride, double *top, int64_t top_stride,
+               int use_top, WresPlan *plan) {
+    return wres::tiles_t<double>(c, F, TL, mode, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
 }
 
 }  // namespace adn

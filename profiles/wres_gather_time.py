@@ -5,13 +5,14 @@ from adn_hip import get_engine
 e = get_engine(0)
 SR = int(sys.argv[1]) if len(sys.argv) > 1 else 48000
 clips, n = 256, 30 * SR
-x = torch.randn(clips * n, dtype=torch.float32, device="cuda") * 0.1
+dt = torch.float64 if len(sys.argv) > 2 and sys.argv[2] == "f64" else torch.float32
+x = torch.randn(clips * n, dtype=dt, device="cuda") * 0.1
 bs = e.denoise_block_frames(SR, n)
 off = np.concatenate([c * n + np.arange(0, n, bs, dtype=np.int64) for c in range(clips)])
 d_off, d_len = e._i64(off), e._i64(np.full(off.shape, bs, dtype=np.int64))
 y = torch.empty_like(x)
 for wavelet, level in (("db4", 2), ("db8", 8)):
-    for ab in (0, 8192, 4096):
+    for ab in (0, 4096):
         e.lib.adn_set_option(e._h, 2, ab)
         run = lambda: e.wavelet_denoise(x, d_off, d_len, y, d_off, n_ch=1, wavelet=wavelet, level=level, max_frames=bs)
         run(); torch.cuda.synchronize()

@@ -1,4 +1,4 @@
-"""GPU parity of the wave-resident wavelet tiles (binary32 mono blocks, the middle of every block that holds a
+"""GPU parity of the wave-resident wavelet tiles (mono blocks, the middle of every block that holds a
 window of 1024 ... 4096 samples; blocks whose length is a multiple of the lanes' run are covered whole).  Against the
 LDS tiles alone (diagnostic option bit 4096 switches the wave-resident tiles off): bit for bit, outputs and block
 statistics.  Against the oracle: fp32 tolerance of the wavelet path (1e-4 max-abs, >= 90 dB SNR of the difference)."""
@@ -8,7 +8,7 @@ import torch
 
 import adn_oracle as orc
 import synth
-from gpu_util import engine, dev, host, check32
+from gpu_util import engine, dev, host, check32, check64
 
 pytestmark = pytest.mark.gpu
 
@@ -31,15 +31,20 @@ def _run(e, x, off, lens, ablate, **kw):
 
 
 @pytest.mark.timeout(300)
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
 @pytest.mark.parametrize("wavelet,level,thr", [("db4", 2, "soft"), ("db4", 1, "hard"), ("db4", 3, "soft"), ("db4", 4, "soft"),
                                                ("db8", 1, "soft"), ("db8", 2, "hard"), ("db8", 3, "soft"), ("db8", 4, "soft"),
                                                ("db8", 8, "soft"), ("db4", 6, "hard")])
-def test_wave_resident_tiles_equal_lds_tiles(wavelet, level, thr):
+def test_wave_resident_tiles_equal_lds_tiles(wavelet, level, thr, dtype):
+    """(binary64 has the wave-resident form up to three levels of db4 and two of db8; the other cases compare the
+    LDS tiles with themselves.)"""
     e = engine()
+    dt = torch.float32 if dtype == "f32" else torch.float64
+    ut = np.uint32 if dtype == "f32" else np.uint64
     gen = torch.Generator(device="cuda:0").manual_seed(5)
     off = np.concatenate([[0], np.cumsum(LENS + 7)[:-1]]).astype(np.int64)     # block starts at odd element offsets too
     total = int(off[-1] + LENS[-1] + 7)
-    x = torch.randn(total, dtype=torch.float32, device="cuda:0", generator=gen) * 0.1
+    x = torch.randn(total, dtype=dt, device="cuda:0", generator=gen) * 0.1
     # digital silence (0 / 0 in the soft threshold), a quantised quiet block (tied statistics), one NaN, one infinity
     for blk, kind in ((6, "zero"), (9, "zero"), (15, "quant"), (19, "quant"), (16, "nan"), (7, "inf")):
         o, n = int(off[blk]), int(LENS[blk])
@@ -53,7 +58,7 @@ def test_wave_resident_tiles_equal_lds_tiles(wavelet, level, thr):
             x[o + n // 3] = float("inf")
     y_w, st_w = _run(e, x, off, LENS, 0, wavelet=wavelet, level=level, thr_mode=thr)
     y_l, st_l = _run(e, x, off, LENS, 4096, wavelet=wavelet, level=level, thr_mode=thr)
-    assert np.array_equal(y_w.view(np.uint32), y_l.view(np.uint32))
+    assert np.array_equal(y_w.view(ut), y_l.view(ut))
     for a, b in zip(st_w, st_l):
         assert np.array_equal(a, b, equal_nan=True)
     # elements between the blocks are nobody's to write
@@ -61,6 +66,23 @@ def test_wave_resident_tiles_equal_lds_tiles(wavelet, level, thr):
     for o, n in zip(off, LENS):
         gaps[o:o + n + (n & 1)] = False
     assert np.all(y_w[gaps] == 7.0)
+
+
+@pytest.mark.timeout(300)
+def test_wave_resident_tiles_binary64_against_oracle():
+    """db4 level 2 (the reference's default transform) in the reference's precision: ring and end-tile block lengths."""
+    e = engine()
+    lens = np.array([12352, 9001, 8192, 20000], dtype=np.int64)
+    off = (np.concatenate([[0], np.cumsum(lens)[:-1]]) + 3) // 4 * 4
+    total = int(off[-1] + lens[-1] + 4)
+    x64 = np.zeros(total)
+    for i, (o, n) in enumerate(zip(off, lens)):
+        x64[o:o + n] = synth.noisy_speech(int(n), 48000, 42, 4200 + i)
+    y, (sigma, thresh, zeroed) = _run(e, dev(x64, torch.float64), off, lens, 0, wavelet="db4", level=2, thr_mode="soft")
+    for i, (o, n) in enumerate(zip(off, lens)):
+        want, s_or, t_or = orc.denoise_block(x64[o:o + n], "db4", 2, "soft")
+        assert abs(sigma[i] - s_or) <= 1e-12 and abs(thresh[i] - t_or) <= 1e-12
+        check64(y[o:o + n], want[:n])
 
 
 @pytest.mark.timeout(300)
