@@ -617,6 +617,8 @@ void k_apply_wave(ApplyArgs<R> a) {
     // binary64 SUBTRACT: four waves' exchange buffers and parked spectra fill the LDS of a CU to the last byte when
     // the parked spectrum takes exactly its 1025 slots and the signal's noise row is read from memory instead
     constexpr bool ROW_IN_LDS = !(sizeof(R) == 8 && MODE == APPLY_SUBTRACT);
+    // a finished hop waits for the next step's loads to be out before it is stored (binary32 GAIN stores it at once)
+    constexpr bool DEFER = !(sizeof(R) == 4 && MODE == APPLY_GAIN);
     constexpr int SLOT = MODE == APPLY_SUBTRACT ? (sizeof(R) == 8 ? 1025 : PARK) : 0;   // complex slots per wave beside the exchange buffer
     const Tables<R> &tb = a.tb;
     C *bufs = reinterpret_cast<C *>(smem);                                          // [W][WBUF] exchange
@@ -793,7 +795,7 @@ void k_apply_wave(ApplyArgs<R> a) {
         // then allows exactly those four stores to be outstanding; any branch between the loads and
         // their first use makes the compiler's wait conservative (it would wait for the stores too).
         const bool pend_fast = pend_j >= 3 && pend_j <= Tn - 1 && y_vec && ps == nullptr;
-        {
+        if constexpr (DEFER) {
             const R lim = a.no_clip ? (R)__builtin_inf() : (R)1.0;
             // a hop that is not stored here goes to a scratch line instead (unconditional stores)
             R *yp0 = pend_fast ? ys + ((int64_t)(pend_j - 2) * H + 2 * mlane) : a.dummy + 2 * mlane;
@@ -1006,7 +1008,24 @@ void k_apply_wave(ApplyArgs<R> a) {
                 acc1[cc] = acc2[cc] + q2;
                 acc2[cc] = q3;
             }
-            if (t >= ja) pend_j = t;                       // stored by the next step, after its loads are out
+            if (DEFER) {
+                if (t >= ja) pend_j = t;                   // stored by the next step, after its loads are out
+            } else if (t >= ja) {
+                // stored at once: the eight registers of a pending hop are what this instantiation lacks
+                if (t >= 3 && t <= Tn - 1 && y_vec && ps == nullptr) {
+                    const R lim = a.no_clip ? (R)__builtin_inf() : (R)1.0;
+                    R *yp0 = ys + ((int64_t)(t - 2) * H + 2 * mlane);
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        C o = pend[cc] * nv[mlane + 16 * cc];
+                        o.x = o.x < -lim ? -lim : (o.x > lim ? lim : o.x);
+                        o.y = o.y < -lim ? -lim : (o.y > lim ? lim : o.y);
+                        __builtin_nontemporal_store(o, reinterpret_cast<C *>(yp0 + 32 * cc));
+                    }
+                } else {
+                    emit(t, pend, mlane);
+                }
+            }
         }
         tick(6);
     }
