@@ -61,6 +61,11 @@ def test_wave_resident_tiles_equal_lds_tiles(wavelet, level, thr, dtype):
     assert np.array_equal(y_w.view(ut), y_l.view(ut))
     for a, b in zip(st_w, st_l):
         assert np.array_equal(a, b, equal_nan=True)
+    # and the LDS tiles with the statistics in two passes (finest band in memory, two selections on it)
+    y_2, st_2 = _run(e, x, off, LENS, 4096 | 512, wavelet=wavelet, level=level, thr_mode=thr)
+    assert np.array_equal(y_w.view(ut), y_2.view(ut))
+    for a, b in zip(st_w, st_2):
+        assert np.array_equal(a, b, equal_nan=True)
     # elements between the blocks are nobody's to write
     gaps = np.ones(total, dtype=bool)
     for o, n in zip(off, LENS):
