@@ -1,20 +1,23 @@
-// Wave-resident tiles of the mono (time-axis, periodization) VisuShrink block denoiser, binary32.
+// Wave-resident tiles of the mono (time-axis, periodization) VisuShrink block denoiser (binary32: every transform of
+// up to four levels; binary64: those whose halos fit runs of sixteen samples per lane).
 //
 // pywt.wavedec (denoise.py:77), pywt.threshold (denoise.py:84) and pywt.waverec (denoise.py:87) of up to four
-// levels for the part of a block that lies away from its ends.  One wavefront owns a window of 64 * C consecutive
-// samples; lane l holds samples [l C, (l + 1) C) and every coefficient of every level that sits above them, all in
-// registers.  There is no LDS array, no barrier and no loop: the code of a tile is one straight line of two-wide
-// fused multiply-adds whose operands are selected at compile time, and what a lane needs from beyond its own run
-// (F / 2 - 1 values on either side for an analysis level, F / 4 for a synthesis level) comes from the two
-// neighbouring lanes through whole-wave shifts.
+// levels for the part of a block that lies away from its ends (all of it, when its length is a multiple of a lane's
+// run).  One wavefront owns a window of 64 * C consecutive samples; lane l holds samples [l C, (l + 1) C) and every
+// coefficient of every level that sits above them, all in registers.  There is no LDS array, no barrier and no loop:
+// the code of a tile is one straight line of two-wide fused multiply-adds whose operands are selected at compile
+// time, and what a lane needs from beyond its own run (F / 2 - 1 values on either side for an analysis level, F / 4
+// for a synthesis level) comes from the two neighbouring lanes through whole-wave shifts.
 //
 // Lane 0 has no left neighbour and lane 63 no right one: what they receive instead is wrong, and the error spreads
 // by the filter length per level.  CONE is the number of output samples at either end of the window that can be
 // affected; lanes [LV0, LV1) are clean in full and are the ones that store.  Successive windows of a block advance
-// by A = (LV1 - LV0) C samples, so the clean lanes tile the block; the head and the tail of a block (and blocks
-// shorter than a window, and every wrapped or odd-length case) are left to the LDS tile kernel k_tile, which is
-// launched on those ranges only.  Results are bit-identical to k_tile's: the same products are added in the same
-// order (tap 0 first in the analysis, pywt's order in the synthesis).
+// by A = (LV1 - LV0) C samples, so the clean lanes tile the block.  A block whose length is a multiple of C is
+// periodic at every level without pywt's repeated last sample: its windows go round it.  Any other block gets the
+// windows that fit and one more that ends within a run of its end; its head and tail (less than a window in all),
+// and blocks shorter than a window, are left to the LDS tile kernel k_tile, which is launched on those ranges only.
+// Results are bit-identical to k_tile's: the same products are added in the same order (tap 0 first in the analysis,
+// pywt's order in the synthesis).
 //
 // Index rules (periodization, away from the ends; N even or odd makes no difference there):
 //   analysis   a_l[k], d_l[k] = sum_j (h[j], g[j]) * a_{l-1}[2k + F/2 - j],               j = 0 .. F-1
