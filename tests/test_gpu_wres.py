@@ -116,3 +116,24 @@ def test_wave_resident_tiles_against_oracle(wavelet, level, thr):
             z_or = int(sum(np.sum(np.abs(b) < t_or) for b in bands[1:]))
             assert abs(int(zeroed[i]) - z_or) <= 4
             assert np.mean(np.abs(got - want[:n]) > 1e-4) <= 1e-3
+
+
+@pytest.mark.timeout(300)
+def test_wave_resident_tiles_many_blocks():
+    """More blocks than one grid dimension holds (40 000 > 32 768: the block index comes from two grid dimensions)."""
+    e = engine()
+    nb, n = 40000, 1040                                   # 65 runs of 16 samples: the windows go round the block
+    gen = torch.Generator(device="cuda:0").manual_seed(11)
+    x = torch.randn(nb * n, dtype=torch.float32, device="cuda:0", generator=gen) * 0.1
+    off = np.arange(nb, dtype=np.int64) * n
+    lens = np.full(nb, n, dtype=np.int64)
+    y_w, st_w = _run(e, x, off, lens, 0, wavelet="db4", level=2, thr_mode="soft")
+    y_l, st_l = _run(e, x, off, lens, 4096, wavelet="db4", level=2, thr_mode="soft")
+    assert np.array_equal(y_w.view(np.uint32), y_l.view(np.uint32))
+    for a, b in zip(st_w, st_l):
+        assert np.array_equal(a, b)
+    xh = host(x)
+    for b in (0, 32767, 32768, nb - 1):
+        want, s_or, _ = orc.denoise_block(xh[b * n:(b + 1) * n].astype(np.float64), "db4", 2, "soft")
+        assert abs(st_w[0][b] - s_or) <= 1e-6 * max(1.0, abs(s_or))
+        check32(y_w[b * n:(b + 1) * n], want)
