@@ -1,5 +1,5 @@
 // Wave-resident tiles of the mono (time-axis, periodization) VisuShrink block denoiser (binary32: every transform of
-// up to four levels; binary64: those whose halos fit runs of sixteen samples per lane).
+// up to four levels; binary64: those whose halos fit runs of at most 32 samples per lane).
 //
 // pywt.wavedec (denoise.py:77), pywt.threshold (denoise.py:84) and pywt.waverec (denoise.py:87) of up to four
 // levels for the part of a block that lies away from its ends (all of it, when its length is a multiple of a lane's
@@ -628,10 +628,10 @@ __global__ __launch_bounds__(256) void k_wres(const T *__restrict__ x, T *__rest
 }
 
 // samples per lane: the smallest run whose halos come from the adjacent lanes only, but at least sixteen; binary64
-// holds sixteen at most (0: no wave-resident form of this transform, the LDS tiles take the whole block)
+// holds 32 at most (0: no wave-resident form of this transform, the LDS tiles take the whole block)
 template <typename T, int F, int TL> struct RunOf {
     static constexpr int NEED = F * (1 << TL) / 4;
-    static constexpr int C = sizeof(T) == 8 ? (NEED <= 16 ? 16 : 0) : (NEED < 16 ? 16 : NEED);
+    static constexpr int C = sizeof(T) == 8 ? (NEED <= 16 ? 16 : (NEED <= 32 ? 32 : 0)) : (NEED < 16 ? 16 : NEED);
 };
 
 template <typename T, int F, int TL, int MODE>
