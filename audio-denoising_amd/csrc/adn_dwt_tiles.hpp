@@ -663,7 +663,9 @@ static int denoise_f(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_f
                                                  d1_stride, top, top_stride, 0, &wp);
                 return ADN_OK;
             };
-            if (!fused) ADN_TRY(rest_of_top(WresPlan{0, 0, 0, 1}));
+            if (!fused)      // the approximation alone, from the wave-resident windows where the precision has them
+                launch_tile_tl<T, F, MODE_STATS>(c, TL, d_in, (T *)nullptr, g, max_frames, wavelet, nullptr, thr_mode, nullptr, (T *)nullptr,
+                                                 d1_stride, top, top_stride, 0);
             if (small)
                 ADN_TRY((mono_mad_single_pass<T, F, S_SMALL>(c, d_in, g, max_frames, tp.g, d_sigma, d_thresh, &thresh, wavelet, fused ? TL : 0,
                                                              top, top_stride, rest_of_top)));

@@ -1,5 +1,5 @@
-// Wave-resident tiles of the mono (time-axis, periodization) VisuShrink block denoiser (binary32: every transform of
-// up to four levels; binary64: those whose halos fit runs of at most 32 samples per lane).
+// Wave-resident tiles of the mono (time-axis, periodization) VisuShrink block denoiser, both precisions, up to four
+// levels (deeper transforms run their first four levels here).
 //
 // pywt.wavedec (denoise.py:77), pywt.threshold (denoise.py:84) and pywt.waverec (denoise.py:87) of up to four
 // levels for the part of a block that lies away from its ends (all of it, when its length is a multiple of a lane's
@@ -7,7 +7,8 @@
 // coefficient of every level that sits above them, all in registers.  There is no LDS array, no barrier and no loop:
 // the code of a tile is one straight line of two-wide fused multiply-adds whose operands are selected at compile
 // time, and what a lane needs from beyond its own run (F / 2 - 1 values on either side for an analysis level, F / 4
-// for a synthesis level) comes from the two neighbouring lanes through whole-wave shifts.
+// for a synthesis level) comes from the neighbouring lanes through whole-wave shifts (the adjacent ones; binary64
+// holds 32 samples per lane at most, and sixteen taps at four levels then reach two lanes away at the deepest levels).
 //
 // Lane 0 has no left neighbour and lane 63 no right one: what they receive instead is wrong, and the error spreads
 // by the filter length per level.  CONE is the number of output samples at either end of the window that can be
@@ -91,7 +92,8 @@ struct WresGeom {
     static constexpr int LV1 = (W - CONE) / C;
     static constexpr int A = (LV1 - LV0) * C;
     static constexpr int LEAD = LV0 * C;                   // first sample a block's first window stores
-    static_assert(C % (1 << TL) == 0 && (C >> (TL - 1)) >= F / 2 && (C >> TL) >= F / 4, "halos come from the adjacent lanes only");
+    static_assert(C % (1 << TL) == 0 && 2 * (C >> (TL - 1)) >= F / 2 && 2 * (C >> TL) >= F / 4 && C >= F / 2,
+                  "halos come from the two lanes on either side at most");
     static_assert(LV1 > LV0, "no clean lane");
 };
 
@@ -111,6 +113,29 @@ struct Wres {
     };
     // element i of an array packed two to a pair
     static __device__ __forceinline__ T at(const P *v, int i) { return (i & 1) ? v[i >> 1].y : v[i >> 1].x; }
+    // the value of the lane d (1 or 2) lanes before / after this one
+    static __device__ __forceinline__ T before(T v, int d) {
+        v = lane_prev(v);
+        return d >= 2 ? lane_prev(v) : v;
+    }
+    static __device__ __forceinline__ T after(T v, int d) {
+        v = lane_next(v);
+        return d >= 2 ? lane_next(v) : v;
+    }
+    // Element idx of an array of c per lane that continues over the lanes (idx < 0: in a lane before, idx >= c: after).
+    // elem(e) returns this lane's element e.
+    template <typename Elem>
+    static __device__ __forceinline__ T across(int idx, int c, Elem elem) {
+        if (idx < 0) {
+            const int d = (-idx + c - 1) / c;
+            return before(elem(idx + d * c), d);
+        }
+        if (idx >= c) {
+            const int d = idx / c;
+            return after(elem(idx - d * c), d);
+        }
+        return elem(idx);
+    }
 
     // ---- analysis of level L from level L - 1
     template <int L>
@@ -141,10 +166,11 @@ struct Wres {
             // slot idx + F/2 on the left (idx = -F/2+1 .. -1), slot idx - cs on the right (idx = cs .. cs + F/2 - 2)
             constexpr int HV = F / 2;
             P hl[HV / 2], hr[HV / 2];
+            auto a_prev = [&](int e) { return s.lev[L - 1][e].x; };
 #pragma unroll
             for (int sl = 0; sl < HV; ++sl) {
-                const T vl = sl >= 1 ? lane_prev(s.lev[L - 1][cs - HV + sl].x) : (T)0;
-                const T vr = sl <= HV - 2 ? lane_next(s.lev[L - 1][sl].x) : (T)0;
+                const T vl = sl >= 1 ? across(sl - HV, cs, a_prev) : (T)0;
+                const T vr = sl <= HV - 2 ? across(cs + sl, cs, a_prev) : (T)0;
                 if (sl & 1) {
                     hl[sl >> 1].y = vl;
                     hr[sl >> 1].y = vr;
@@ -212,19 +238,22 @@ struct Wres {
         constexpr int c = C >> L;
         // details: slot idx + Q on the left (idx = -Q+1 .. -1), slot idx - c on the right (idx = c .. c + Q - 1)
         P dl[Q / 2], dr[Q / 2], al[Q / 2], ar[Q / 2];
+        auto d_own = [&](int e) { return at(s.dp[L], e); };
+        auto a_own = [&](int e) { return at(s.ap, e); };
+        auto r_own = [&](int e) { return at(rin, e); };        // held index = position - 1
 #pragma unroll
         for (int sl = 0; sl < Q; ++sl) {
-            const T vl = sl >= 1 ? lane_prev(at(s.dp[L], c - Q + sl)) : (T)0;
-            const T vr = lane_next(at(s.dp[L], sl));
+            const T vl = sl >= 1 ? across(sl - Q, c, d_own) : (T)0;
+            const T vr = across(c + sl, c, d_own);
             T wl, wr;
             if constexpr (L == TL) {
-                wl = sl >= 1 ? lane_prev(at(s.ap, c - Q + sl)) : (T)0;
-                wr = lane_next(at(s.ap, sl));
+                wl = sl >= 1 ? across(sl - Q, c, a_own) : (T)0;
+                wr = across(c + sl, c, a_own);
             } else {
-                // approximation at positions -Q+1 .. 0 (slot pos + Q - 1): the left lane's positions c-Q+1 .. c;
-                // at positions c+1 .. c+Q-1 (slot pos - c - 1): the right lane's positions 1 .. Q-1
-                wl = lane_prev(at(rin, c - Q + sl));         // held index = position - 1
-                wr = sl <= Q - 2 ? lane_next(at(rin, sl)) : (T)0;
+                // approximation at positions -Q+1 .. 0 (slot pos + Q - 1) and c+1 .. c+Q-1 (slot pos - c - 1); a lane
+                // holds positions 1 .. c, position p at index p - 1
+                wl = across(sl - Q, c, r_own);
+                wr = sl <= Q - 2 ? across(c + sl, c, r_own) : (T)0;
             }
             if (sl & 1) {
                 dl[sl >> 1].y = vl;
@@ -272,27 +301,30 @@ struct Wres {
         T av[c + 2 * Q], dv[c + 2 * Q];               // coefficients -Q .. c + Q - 1 at index + Q
 #pragma unroll
         for (int j = 0; j < c; ++j) dv[j + Q] = at(s.dp[1], j);
+        auto d_own = [&](int e) { return at(s.dp[1], e); };
 #pragma unroll
         for (int h = 0; h < Q; ++h) {
-            dv[h] = lane_prev(at(s.dp[1], c - Q + h));
-            dv[c + Q + h] = lane_next(at(s.dp[1], h));
+            dv[h] = across(h - Q, c, d_own);
+            dv[c + Q + h] = across(c + h, c, d_own);
         }
         if constexpr (TL == 1) {
+            auto a_own = [&](int e) { return at(s.ap, e); };
 #pragma unroll
             for (int j = 0; j < c; ++j) av[j + Q] = at(s.ap, j);
 #pragma unroll
             for (int h = 0; h < Q; ++h) {
-                av[h] = lane_prev(at(s.ap, c - Q + h));
-                av[c + Q + h] = lane_next(at(s.ap, h));
+                av[h] = across(h - Q, c, a_own);
+                av[c + Q + h] = across(c + h, c, a_own);
             }
         } else {
             // rin holds positions 1 .. c: position p is element p - 1
+            auto r_own = [&](int e) { return at(rin, e); };
 #pragma unroll
             for (int p = 1; p <= c; ++p) av[p + Q] = at(rin, p - 1);
 #pragma unroll
-            for (int h = 0; h <= Q; ++h) av[h] = lane_prev(at(rin, c - Q + h - 1));      // positions -Q .. 0: the left lane's c - Q .. c
+            for (int h = 0; h <= Q; ++h) av[h] = across(h - Q - 1, c, r_own);            // positions -Q .. 0
 #pragma unroll
-            for (int h = 1; h < Q; ++h) av[c + Q + h] = lane_next(at(rin, h - 1));      // positions c + 1 .. c + Q - 1: the right lane's 1 .. Q - 1
+            for (int h = 1; h < Q; ++h) av[c + Q + h] = across(c + h - 1, c, r_own);     // positions c + 1 .. c + Q - 1
         }
 #pragma unroll
         for (int m = 0; m < c; ++m) {
@@ -574,7 +606,7 @@ __global__ __launch_bounds__(256) void k_wres(const T *__restrict__ x, T *__rest
         return;
     }
     if (MODE == MODE_STATS) {
-        {
+        if (d1_out != nullptr) {
             T d[C / 2];
 #pragma unroll
             for (int i = 0; i < C / 2; ++i) d[i] = K::at(s.dp[1], i);
@@ -628,10 +660,10 @@ __global__ __launch_bounds__(256) void k_wres(const T *__restrict__ x, T *__rest
 }
 
 // samples per lane: the smallest run whose halos come from the adjacent lanes only, but at least sixteen; binary64
-// holds 32 at most (0: no wave-resident form of this transform, the LDS tiles take the whole block)
+// holds 32 at most (sixteen taps at four levels then reach two lanes away at the deepest levels)
 template <typename T, int F, int TL> struct RunOf {
     static constexpr int NEED = F * (1 << TL) / 4;
-    static constexpr int C = sizeof(T) == 8 ? (NEED <= 16 ? 16 : (NEED <= 32 ? 32 : 0)) : (NEED < 16 ? 16 : NEED);
+    static constexpr int C = sizeof(T) == 8 ? (NEED <= 16 ? 16 : 32) : (NEED < 16 ? 16 : NEED);
 };
 
 template <typename T, int F, int TL, int MODE>

@@ -36,8 +36,7 @@ def _run(e, x, off, lens, ablate, **kw):
                                                ("db8", 1, "soft"), ("db8", 2, "hard"), ("db8", 3, "soft"), ("db8", 4, "soft"),
                                                ("db8", 8, "soft"), ("db4", 6, "hard")])
 def test_wave_resident_tiles_equal_lds_tiles(wavelet, level, thr, dtype):
-    """(binary64 has the wave-resident form for db4 and up to three levels of db8; db8 level 4 and 8 compare the LDS
-    tiles with themselves there.)"""
+    """(binary64 db8 at four levels and beyond takes its deepest halos from two lanes away.)"""
     e = engine()
     dt = torch.float32 if dtype == "f32" else torch.float64
     ut = np.uint32 if dtype == "f32" else np.uint64
