@@ -1163,7 +1163,7 @@ template <typename T, int F, int S>
 static size_t mono_single_pass_ws_bytes(int64_t n_blocks, int64_t max_frames) {
     return m1_src_ws_bytes<T, SrcMono<T, F, S>>(n_blocks, (max_frames + 1) / 2);
 }
-// fused_TL > 0 (binary32): the gather pass is the wave-resident windows of fused_TL levels, which also write the level
+// fused_TL > 0: the gather pass is the wave-resident windows of fused_TL levels, which also write the level
 // approximation of every window to `top`; after_windows(plan) then launches whatever covers the rest of `top`, and the
 // direct gather takes the blocks the windows do not cover whole.
 template <typename T, int F, int S, typename After>
@@ -1177,9 +1177,9 @@ static int mono_mad_single_pass(Ctx *c, const T *d_in, const BlockGeom &g, int64
     SrcMono<T, F, 0> gsrc;
     for (int j = 0; j < F; ++j) src.g[j] = gsrc.g[j] = taps_g[j];
     auto gather = [&](M1State *st, T *cand_m, int64_t cap_m, T *cand_a, int64_t cap_a) -> int {
-        // binary32: blocks that the wave-resident windows cover whole are gathered by them, the rest here
+        // coefficients that the wave-resident windows own are gathered by them, the rest here
         WresPlan skip{0, 0, 0, 1};
-        if constexpr (sizeof(T) == 4) {
+        {
             if (fused_TL > 0) {
                 ADN_TRY(wres_gather(c, F, fused_TL, d_in, g, max_frames, wavelet, WresGather{st, cand_m, cap_m, cand_a, cap_a}, top,
                                     top_stride, &skip));

@@ -56,12 +56,13 @@ __device__ __forceinline__ typename KeyT<T>::type m1_key(T x) {
     return x != x ? ~(K)0 : key_of(x);
 }
 
-// Where the single-pass statistics keep a batch's states and candidate lists (see adn_dwt_mad1p.hpp)
+// Where the single-pass statistics keep a batch's states and candidate lists (see adn_dwt_mad1p.hpp); the lists hold
+// values of the batch's precision
 struct WresGather {
     M1State *st;
-    float *cand_m;
+    void *cand_m;
     int64_t cap_m;
-    float *cand_a;
+    void *cand_a;
     int64_t cap_a;
 };
 
@@ -143,5 +144,7 @@ int wres_tiles(Ctx *c, int F, int TL, int mode, const double *x, double *y, cons
 // top != null the level-TL approximation of every window is written as by the statistics mode of wres_tiles.
 int wres_gather(Ctx *c, int F, int TL, const float *x, const BlockGeom &g, int64_t max_frames, int wavelet, WresGather gat,
                 float *top, int64_t top_stride, WresPlan *plan);
+int wres_gather(Ctx *c, int F, int TL, const double *x, const BlockGeom &g, int64_t max_frames, int wavelet, WresGather gat,
+                double *top, int64_t top_stride, WresPlan *plan);
 
 }  // namespace adn

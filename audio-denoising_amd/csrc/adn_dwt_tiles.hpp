@@ -644,12 +644,11 @@ static int denoise_f(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_f
     // small bracket sample keeps the per-block sampling cheap; its longer candidate lists must fit LDS.
     constexpr int S_SMALL = 4096, S_LARGE = 16384;
     auto no_windows = [](const WresPlan &) -> int { return ADN_OK; };
-    // Deeper transforms, binary32: the same statistics, their gather pass fused into the wave-resident windows that
+    // Deeper transforms: the same statistics, their gather pass fused into the wave-resident windows that
     // write the level-TL approximation for the deep levels (no finest band in memory, one pass over the samples for
     // both); the LDS tiles write the approximation of what the windows leave, the direct gather takes those blocks.
-    // (binary64: the same statistics with the direct gather, and the tiles' statistics pass writes the approximation only)
-    const bool fused = sizeof(T) == 4 && !(c->ablate & 4096);
-    if (deep && (fused || sizeof(T) == 8) && !d_thresh_given && !(c->ablate & 512) && max_frames >= 4096) {
+    const bool fused = !(c->ablate & 4096);
+    if (deep && fused && !d_thresh_given && !(c->ablate & 512) && max_frames >= 4096) {
         const bool small = mono_single_pass_applicable<T, F, S_SMALL>(c, 0, max_frames);
         const bool large = !small && mono_single_pass_applicable<T, F, S_LARGE>(c, g.n_blocks, max_frames);
         if (small || large) {
@@ -663,15 +662,12 @@ static int denoise_f(Ctx *c, const T *d_in, T *d_out, BlockGeom g, int64_t max_f
                                                  d1_stride, top, top_stride, 0, &wp);
                 return ADN_OK;
             };
-            if (!fused)      // the approximation alone, from the wave-resident windows where the precision has them
-                launch_tile_tl<T, F, MODE_STATS>(c, TL, d_in, (T *)nullptr, g, max_frames, wavelet, nullptr, thr_mode, nullptr, (T *)nullptr,
-                                                 d1_stride, top, top_stride, 0);
             if (small)
-                ADN_TRY((mono_mad_single_pass<T, F, S_SMALL>(c, d_in, g, max_frames, tp.g, d_sigma, d_thresh, &thresh, wavelet, fused ? TL : 0,
-                                                             top, top_stride, rest_of_top)));
+                ADN_TRY((mono_mad_single_pass<T, F, S_SMALL>(c, d_in, g, max_frames, tp.g, d_sigma, d_thresh, &thresh, wavelet, TL, top,
+                                                             top_stride, rest_of_top)));
             else
-                ADN_TRY((mono_mad_single_pass<T, F, S_LARGE>(c, d_in, g, max_frames, tp.g, d_sigma, d_thresh, &thresh, wavelet, fused ? TL : 0,
-                                                             top, top_stride, rest_of_top)));
+                ADN_TRY((mono_mad_single_pass<T, F, S_LARGE>(c, d_in, g, max_frames, tp.g, d_sigma, d_thresh, &thresh, wavelet, TL, top,
+                                                             top_stride, rest_of_top)));
             if (deep_lds > 48 * 1024)
                 ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_deep<T, F>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)deep_lds));

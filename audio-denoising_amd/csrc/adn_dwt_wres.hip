@@ -433,20 +433,22 @@ struct Staged {
 };
 
 static constexpr int GSTAGE_M = 512, GSTAGE_A = 1024;    // candidates of a window that are written out through LDS, per list
-template <int NV>
-__device__ __forceinline__ void gather_details(const float (&d)[NV], bool own, int64_t b, int64_t k0, const WresGather &gat, int lane,
-                                               float *stage_m, float *stage_a, int ablate) {
+template <typename T, int NV>
+__device__ __forceinline__ void gather_details(const T (&d)[NV], bool own, int64_t b, int64_t k0, const WresGather &gat, int lane,
+                                               T *stage_m, T *stage_a, int ablate) {
+    using K = typename KeyT<T>::type;
     M1State *st = gat.st + b;
-    const uint32_t lo = (uint32_t)st->lo_m, hi = (uint32_t)st->hi_m;
+    T *const cand_m = static_cast<T *>(gat.cand_m), *const cand_a = static_cast<T *>(gat.cand_a);
+    const K lo = (K)st->lo_m, hi = (K)st->hi_m;
     if (st->lo_m > st->hi_m) return;                       // no usable bracket: the block goes to the exact fallback
     const unsigned long long owners = __ballot(own);
     if (owners == 0) return;
-    if (lo == 0 && hi == 0xFFFFFFFFu) {
+    if (lo == 0 && hi == ~(K)0) {
         // short block, every coefficient is a candidate of both lists: stored in place
         bool nan = false;
         if (own) {
-            store_run(gat.cand_m + b * gat.cap_m + k0, d);
-            store_run(gat.cand_a + b * gat.cap_a + k0, d);
+            store_run(cand_m + b * gat.cap_m + k0, d);
+            store_run(cand_a + b * gat.cap_a + k0, d);
 #pragma unroll
             for (int i = 0; i < NV; ++i) nan |= d[i] != d[i];
         }
@@ -458,21 +460,21 @@ __device__ __forceinline__ void gather_details(const float (&d)[NV], bool own, i
         }
         return;
     }
-    const float mhat = (float)st->mhat, alo = (float)st->alo, ahi = (float)st->ahi;
+    const T mhat = (T)st->mhat, alo = (T)st->alo, ahi = (T)st->ahi;
     const bool tie_m = st->tie_m != 0, tie_a = st->tie_a != 0;
-    const uint32_t span = hi - lo;
+    const K span = hi - lo;
     unsigned int below_m = 0, below_a = 0, cm = 0, ca = 0;
     unsigned int km = 0, ka = 0;                           // bit i: coefficient i is kept (NV <= 32)
     bool nan = false;
     static_assert(NV <= 32, "keep masks are 32 bits");
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const float x = d[i];
+        const T x = d[i];
         nan |= x != x;
-        const uint32_t k = m1_key(x);
+        const K k = m1_key(x);
         below_m += k < lo ? 1u : 0u;
-        const bool keep_m = (uint32_t)(k - lo) <= span;
-        const float a = fabsf(x - mhat);
+        const bool keep_m = (K)(k - lo) <= span;
+        const T a = fabs(x - mhat);
         below_a += a < alo ? 1u : 0u;
         const bool keep_a = a >= alo && a <= ahi;
         km |= keep_m ? 1u << i : 0u;
@@ -509,8 +511,8 @@ __device__ __forceinline__ void gather_details(const float (&d)[NV], bool own, i
     if (ablate & 8192) return;                             // timing only
     // The kept keys leave through the wave's LDS stage (compacted there, then written as consecutive elements of the
     // list); a window with more of them than the stage holds writes them one by one.
-    auto emit = [&](unsigned int keep, unsigned int mine, unsigned int incl, unsigned int total, unsigned int base, float *stage,
-                    unsigned int stage_cap, float *dst, int64_t cap) {
+    auto emit = [&](unsigned int keep, unsigned int mine, unsigned int incl, unsigned int total, unsigned int base, T *stage,
+                    unsigned int stage_cap, T *dst, int64_t cap) {
         if (total == 0) return;
         unsigned int p = incl - mine;                       // the lane's first position among the window's kept keys
         if (total <= stage_cap) {
@@ -530,8 +532,8 @@ __device__ __forceinline__ void gather_details(const float (&d)[NV], bool own, i
                 }
         }
     };
-    if (!tie_m) emit(km, cm, both & 0xFFFFu, tm, base_m, stage_m, GSTAGE_M, gat.cand_m + b * gat.cap_m, gat.cap_m);
-    if (!tie_a) emit(ka, ca, both >> 16, ta, base_a, stage_a, GSTAGE_A, gat.cand_a + b * gat.cap_a, gat.cap_a);
+    if (!tie_m) emit(km, cm, both & 0xFFFFu, tm, base_m, stage_m, GSTAGE_M, cand_m + b * gat.cap_m, gat.cap_m);
+    if (!tie_a) emit(ka, ca, both >> 16, ta, base_a, stage_a, GSTAGE_A, cand_a + b * gat.cap_a, gat.cap_a);
 }
 
 // One window per wave, four waves per workgroup.  STATS: the finest-band details of the clean lanes to d1_out and,
@@ -592,10 +594,8 @@ __global__ __launch_bounds__(256) void k_wres(const T *__restrict__ x, T *__rest
             T d[C / 2];
 #pragma unroll
             for (int i = 0; i < C / 2; ++i) d[i] = K::at(s.dp[1], i);
-            if constexpr (sizeof(T) == 4) {
-                float *gs = stage + wave * (GSTAGE_M + GSTAGE_A);
-                gather_details(d, clean, b, start >> 1, gat, lane, gs, gs + GSTAGE_M, ablate);
-            }
+            T *gs = stage + wave * (GSTAGE_M + GSTAGE_A);
+            gather_details(d, clean, b, start >> 1, gat, lane, gs, gs + GSTAGE_M, ablate);
         }
         if (clean && top != nullptr) {
             T a[C >> TL];
@@ -716,8 +716,8 @@ static int tiles_t(Ctx *c, int F, int TL, int mode, const T *x, T *y, const Bloc
     return launch_f<T, 16, tiles::MODE_APPLY>(c, TL, x, y, g, max_frames, wavelet, thresh, thr_mode, zeroed, d1, d1_stride, top, top_stride, use_top, plan);
 }
 
-template <int F, int TL, int C>
-static int launch_gather(Ctx *c, const float *x, const BlockGeom &g, int64_t max_frames, int wavelet, WresGather gat, float *top,
+template <typename T, int F, int TL, int C>
+static int launch_gather(Ctx *c, const T *x, const BlockGeom &g, int64_t max_frames, int wavelet, WresGather gat, T *top,
                          int64_t top_stride, WresPlan *plan) {
     typedef WresGeom<F, TL, C> G;
     plan->window = G::W;
@@ -729,27 +729,37 @@ static int launch_gather(Ctx *c, const float *x, const BlockGeom &g, int64_t max
         return ADN_OK;
     }
     const int64_t windows = ceil_div(max_frames, G::A) + 1;
-    const TapsF<float, F> tp = tiles::make_taps_f<float, F>(wavelet);
+    const TapsF<T, F> tp = tiles::make_taps_f<T, F>(wavelet);
     const int64_t by = g.n_blocks < 32768 ? g.n_blocks : 32768;
-    ADN_LAUNCH_NAMED("k_wres<GATHER>", (k_wres<float, F, TL, C, MODE_GATHER>), dim3((unsigned)ceil_div(windows, 4), (unsigned)by, (unsigned)ceil_div(g.n_blocks, by)),
-                     dim3(256), 0, c->stream, x, (float *)nullptr, g, tp, (const double *)nullptr, 0, (int64_t *)nullptr, (float *)nullptr,
+    ADN_LAUNCH_NAMED("k_wres<GATHER>", (k_wres<T, F, TL, C, MODE_GATHER>), dim3((unsigned)ceil_div(windows, 4), (unsigned)by, (unsigned)ceil_div(g.n_blocks, by)),
+                     dim3(256), 0, c->stream, x, (T *)nullptr, g, tp, (const double *)nullptr, 0, (int64_t *)nullptr, (T *)nullptr,
                      (int64_t)0, top, top_stride, 0, c->ablate, gat);
     return ADN_OK;
+}
+
+// (a gather of one level alone, without the approximation, was measured against the direct gather k_d1_gather_direct on
+// 2560 blocks of 144 000 binary32 samples: 0.46 ms against 0.37 ms -- classifying costs both the same, and the direct
+// kernel's loads are the better coalesced; so only the four-level form is built, for the blocks that need `top` anyway)
+template <typename T>
+static int gather_t(Ctx *c, int F, int TL, const T *x, const BlockGeom &g, int64_t max_frames, int wavelet, WresGather gat, T *top,
+                    int64_t top_stride, WresPlan *plan) {
+    if (TL != 4) {
+        set_error("internal: the wave-resident gather is built for four levels");
+        return ADN_ERR_ARG;
+    }
+    if (F == 8) return launch_gather<T, 8, 4, RunOf<T, 8, 4>::C>(c, x, g, max_frames, wavelet, gat, top, top_stride, plan);
+    return launch_gather<T, 16, 4, RunOf<T, 16, 4>::C>(c, x, g, max_frames, wavelet, gat, top, top_stride, plan);
 }
 
 }  // namespace wres
 
 int wres_gather(Ctx *c, int F, int TL, const float *x, const BlockGeom &g, int64_t max_frames, int wavelet, WresGather gat,
                 float *top, int64_t top_stride, WresPlan *plan) {
-    // (a gather of one level alone, without the approximation, was measured against the direct gather k_d1_gather_direct on
-    // 2560 blocks of 144 000 samples: 0.46 ms against 0.37 ms -- classifying costs both the same, and the direct kernel's
-    // loads are the better coalesced; so only the four-level form is built, for the blocks that need `top` anyway)
-    if (TL != 4) {
-        set_error("internal: the wave-resident gather is built for four levels");
-        return ADN_ERR_ARG;
-    }
-    if (F == 8) return wres::launch_gather<8, 4, wres::RunOf<float, 8, 4>::C>(c, x, g, max_frames, wavelet, gat, top, top_stride, plan);
-    return wres::launch_gather<16, 4, wres::RunOf<float, 16, 4>::C>(c, x, g, max_frames, wavelet, gat, top, top_stride, plan);
+    return wres::gather_t<float>(c, F, TL, x, g, max_frames, wavelet, gat, top, top_stride, plan);
+}
+int wres_gather(Ctx *c, int F, int TL, const double *x, const BlockGeom &g, int64_t max_frames, int wavelet, WresGather gat,
+                double *top, int64_t top_stride, WresPlan *plan) {
+    return wres::gather_t<double>(c, F, TL, x, g, max_frames, wavelet, gat, top, top_stride, plan);
 }
 
 // Launches the wave-resident tiles of TL levels on every window that fits its block and reports, in *plan, how the
