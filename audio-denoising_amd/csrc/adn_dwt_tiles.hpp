@@ -447,6 +447,7 @@ __global__ __launch_bounds__(THREADS) void k_tile(const T *__restrict__ x, T *__
 // Levels TL+1 .. L of one block on the level-TL approximation (whole arrays in LDS, exact
 // modular indexing): analysis, shrink + zero count, synthesis back to level TL, in place in `top`.
 static constexpr int DEEP_THREADS = 1024;   // one workgroup per block and CU: all the waves a CU takes
+__host__ __device__ static inline int64_t deep_pad(int64_t n) { return (n + 3) & ~(int64_t)3; }
 template <typename T, int F>
 __global__ __launch_bounds__(DEEP_THREADS) void k_deep(T *__restrict__ top, int64_t top_stride, BlockGeom g,
                                               int TL, int L, TapsF<T, F> tp,
@@ -462,37 +463,92 @@ __global__ __launch_bounds__(DEEP_THREADS) void k_deep(T *__restrict__ top, int6
         for (int l = 0; l < TL; ++l) n = (n + 1) >> 1;
         // A_TL at 0, then A and D of level TL + 1.  A_TL is dead from the analysis of level TL + 2 until the last
         // synthesis step writes it again, and the arrays of all levels beyond TL + 1 together are no longer than it
-        // (unless the block is tiny): they take its place, so that two workgroups share a CU.
+        // (unless the block is tiny): they take its place, so that two workgroups share a CU.  Every array starts
+        // at a multiple of four elements (the 16-byte reads of the paths below).
         const int n1 = (n + 1) >> 1;
         int deeper = 0;
         for (int l = TL + 2, m = n1; l <= L; ++l) {
             m = (m + 1) >> 1;
-            deeper += 2 * m;
+            deeper += 2 * deep_pad(m);
         }
         NN[TL] = n;
         offA[TL] = 0;
         NN[TL + 1] = n1;
-        offA[TL + 1] = n;
-        offD[TL + 1] = n + n1;
-        int off = deeper <= n ? 0 : n + 2 * n1;
+        offA[TL + 1] = deep_pad(n);
+        offD[TL + 1] = deep_pad(n) + deep_pad(n1);
+        int off = deeper <= n ? 0 : deep_pad(n) + 2 * deep_pad(n1);
         for (int l = TL + 2, m = n1; l <= L; ++l) {
             m = (m + 1) >> 1;
             NN[l] = m;
             offA[l] = off;
-            off += m;
+            off += deep_pad(m);
             offD[l] = off;
-            off += m;
+            off += deep_pad(m);
         }
     }
     __syncthreads();
     T *tp_io = top + b * top_stride;
-    for (int i = tid; i < NN[TL]; i += NT) lds[offA[TL] + i] = tp_io[i];
+    // 16-byte pieces when the block's array is aligned
+    constexpr int VW = 16 / (int)sizeof(T);
+    typedef T V16 __attribute__((ext_vector_type(VW)));
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    const bool vec_io = (reinterpret_cast<uintptr_t>(tp_io) & 15) == 0;
+    if (vec_io) {
+        const int nv = NN[TL] / VW;
+#pragma unroll 4
+        for (int i = tid; i < nv; i += NT) reinterpret_cast<V16 *>(lds)[i] = reinterpret_cast<const V16 *>(tp_io)[i];
+        for (int i = nv * VW + tid; i < NN[TL]; i += NT) lds[i] = tp_io[i];
+    } else {
+        for (int i = tid; i < NN[TL]; i += NT) lds[i] = tp_io[i];
+    }
     __syncthreads();
+    // Away from the two ends of a level no window wraps or meets the repeated last sample, and a thread takes a
+    // group of neighbouring outputs whose windows it reads once, in aligned 16-byte (analysis) or two-element
+    // (synthesis) pieces: 20 elements for two analysis outputs of sixteen taps instead of 32, ten of each band for
+    // four synthesis outputs instead of 64.  Per output the products are added in the order of the exact path.
+    // The few outputs at the ends take the exact path, on the threads counted from the last one (those that the
+    // last round of groups leaves idle).
+    constexpr bool GROUPS = F % 8 == 0;
     for (int l = TL + 1; l <= L; ++l) {
         const T *src = lds + offA[l - 1];
         T *dA = lds + offA[l], *dD = lds + offD[l];
         const int Ns = NN[l - 1], Ms = Ns + (Ns & 1), K = NN[l];
-        for (int k = tid; k < K; k += NT) {
+        // group p: outputs 2p and 2p + 1, from src[4p - F/2 .. 4p + F/2 + 3]
+        int p_lo = F / 8, p_hi = min((Ns - F / 2 - 4) >> 2, (K - 2) >> 1);
+        if (!GROUPS || p_hi < p_lo) {
+            p_lo = 0;
+            p_hi = -1;
+        }
+        if constexpr (GROUPS) {
+            for (int p = p_lo + tid; p <= p_hi; p += NT) {
+                T w[F + 4];
+                const V16 *wv = reinterpret_cast<const V16 *>(src + 4 * p - F / 2);
+#pragma unroll
+                for (int i = 0; i < (F + 4) / VW; ++i) {
+                    const V16 v = wv[i];
+#pragma unroll
+                    for (int e = 0; e < VW; ++e) w[i * VW + e] = v[e];
+                }
+                T sa0 = 0, sd0 = 0, sa1 = 0, sd1 = 0;
+#pragma unroll
+                for (int j = 0; j < F; ++j) {
+                    sa0 = fma(tp.h[j], w[F - j], sa0);
+                    sd0 = fma(tp.g[j], w[F - j], sd0);
+                    sa1 = fma(tp.h[j], w[F + 2 - j], sa1);
+                    sd1 = fma(tp.g[j], w[F + 2 - j], sd1);
+                }
+                V2 oa, od;
+                oa[0] = sa0;
+                oa[1] = sa1;
+                od[0] = sd0;
+                od[1] = sd1;
+                *reinterpret_cast<V2 *>(dA + 2 * p) = oa;
+                *reinterpret_cast<V2 *>(dD + 2 * p) = od;
+            }
+        }
+        const int e_lo = 2 * p_lo, e_hi = 2 * (p_hi + 1);
+        for (int e = NT - 1 - tid; e < e_lo + K - e_hi; e += NT) {
+            const int k = e < e_lo ? e : e_hi + (e - e_lo);
             int idx = 2 * k + F / 2;
             while (idx >= Ms) idx -= Ms;
             T sa = 0, sd = 0;
@@ -527,7 +583,52 @@ __global__ __launch_bounds__(DEEP_THREADS) void k_deep(T *__restrict__ top, int6
         const T *ra = lds + offA[l], *rd = lds + offD[l];
         T *out = lds + offA[l - 1];
         const int K = NN[l], n_out = NN[l - 1];   // waverec drops the extra sample of an odd level
-        for (int nn = tid; nn < n_out; nn += NT) {
+        // group m: outputs 4m .. 4m + 3, from coefficients 2m - F/4 .. 2m + F/4 + 1 of either band (output 4m
+        // starts at coefficient 2m + F/4 - 1 with the odd taps, 4m + 1 and 4m + 2 at the next one with the even
+        // and the odd taps, 4m + 3 at the one after with the even taps)
+        int m_lo = F / 8, m_hi = min((K - 2 - F / 4) >> 1, (n_out - 4) >> 2);
+        if (!GROUPS || m_hi < m_lo) {
+            m_lo = 0;
+            m_hi = -1;
+        }
+        if constexpr (GROUPS) {
+            for (int m = m_lo + tid; m <= m_hi; m += NT) {
+                T a[F / 2 + 2], d[F / 2 + 2];
+                const V2 *pa = reinterpret_cast<const V2 *>(ra + 2 * m - F / 4);
+                const V2 *pd = reinterpret_cast<const V2 *>(rd + 2 * m - F / 4);
+#pragma unroll
+                for (int i = 0; i < F / 4 + 1; ++i) {
+                    const V2 va = pa[i], vd = pd[i];
+                    a[2 * i] = va[0];
+                    a[2 * i + 1] = va[1];
+                    d[2 * i] = vd[0];
+                    d[2 * i + 1] = vd[1];
+                }
+                T s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+                for (int q = 0; q < F / 2; ++q) {
+                    const int i0 = F / 2 - 1 - q;
+                    s0 = fma(tp.rl[2 * q + 1], a[i0], s0);
+                    s0 = fma(tp.rh[2 * q + 1], d[i0], s0);
+                    s1 = fma(tp.rl[2 * q], a[i0 + 1], s1);
+                    s1 = fma(tp.rh[2 * q], d[i0 + 1], s1);
+                    s2 = fma(tp.rl[2 * q + 1], a[i0 + 1], s2);
+                    s2 = fma(tp.rh[2 * q + 1], d[i0 + 1], s2);
+                    s3 = fma(tp.rl[2 * q], a[i0 + 2], s3);
+                    s3 = fma(tp.rh[2 * q], d[i0 + 2], s3);
+                }
+                V2 o0, o1;
+                o0[0] = s0;
+                o0[1] = s1;
+                o1[0] = s2;
+                o1[1] = s3;
+                reinterpret_cast<V2 *>(out + 4 * m)[0] = o0;
+                reinterpret_cast<V2 *>(out + 4 * m)[1] = o1;
+            }
+        }
+        const int e_lo = 4 * m_lo, e_hi = 4 * (m_hi + 1);
+        for (int e = NT - 1 - tid; e < e_lo + n_out - e_hi; e += NT) {
+            const int nn = e < e_lo ? e : e_hi + (e - e_lo);
             const int par = (nn + F / 2 - 1) & 1;
             int k = (nn + F / 2 - 1 - par) >> 1;
             while (k >= K) k -= K;
@@ -544,7 +645,14 @@ __global__ __launch_bounds__(DEEP_THREADS) void k_deep(T *__restrict__ top, int6
         }
         __syncthreads();
     }
-    for (int i = tid; i < NN[TL]; i += NT) tp_io[i] = lds[offA[TL] + i];
+    if (vec_io) {
+        const int nv = NN[TL] / VW;
+#pragma unroll 4
+        for (int i = tid; i < nv; i += NT) reinterpret_cast<V16 *>(tp_io)[i] = reinterpret_cast<const V16 *>(lds)[i];
+        for (int i = nv * VW + tid; i < NN[TL]; i += NT) tp_io[i] = lds[i];
+    } else {
+        for (int i = tid; i < NN[TL]; i += NT) tp_io[i] = lds[i];
+    }
 }
 
 // Samples and threads of a tile.  Up to two levels in the tile: one wave per tile of about 1024 (binary32) samples,
@@ -615,10 +723,11 @@ static size_t deep_lds_bytes(int64_t max_frames, int TL, int L) {
     int64_t deeper = 0;
     for (int64_t l = TL + 2, m = n1; l <= L; ++l) {
         m = (m + 1) / 2;
-        deeper += 2 * m;
+        deeper += 2 * deep_pad(m);
     }
-    size_t total = (size_t)(n + 2 * n1 + (deeper <= n ? 0 : deeper));
-    if (total < 512) total = 512;
+    size_t total = (size_t)(deep_pad(n) + 2 * deep_pad(n1) + (deeper <= n ? 0 : deeper));
+    // a block that does not fold has fewer than 16 (L - TL) + 2 elements at level TL and needs at most 3.5 times that
+    if (total < 2048) total = 2048;
     return total * sizeof(T) + 16;
 }
 
