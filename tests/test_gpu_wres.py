@@ -136,3 +136,32 @@ def test_wave_resident_tiles_many_blocks():
         want, s_or, _ = orc.denoise_block(xh[b * n:(b + 1) * n].astype(np.float64), "db4", 2, "soft")
         assert abs(st_w[0][b] - s_or) <= 1e-6 * max(1.0, abs(s_or))
         check32(y_w[b * n:(b + 1) * n], want)
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("wavelet,level", [("db4", 2), ("db8", 4), ("db8", 8), ("db4", 5)])
+def test_wave_resident_tiles_random_lengths(wavelet, level, dtype):
+    """400 blocks of random lengths in one batch (a third of them multiples of 16, 32 or 64, the lengths whose windows
+    go round the block; block starts at any element offset): samples and block statistics equal those of the LDS
+    tiles bit for bit."""
+    e = engine()
+    dt = torch.float32 if dtype == "f32" else torch.float64
+    ut = np.uint32 if dtype == "f32" else np.uint64
+    rng = np.random.default_rng(20 + level)
+    lens = rng.integers(1, 30000, size=400).astype(np.int64)
+    mult = rng.choice([16, 32, 64], size=400)
+    pick = rng.random(400) < 1.0 / 3.0
+    lens[pick] = np.maximum(mult[pick], lens[pick] // mult[pick] * mult[pick])
+    gap = rng.integers(0, 9, size=400)
+    off = np.concatenate([[0], np.cumsum(lens + (lens & 1) + gap)[:-1]]).astype(np.int64)
+    total = int(off[-1] + lens[-1] + 9)
+    gen = torch.Generator(device="cuda:0").manual_seed(31 + level)
+    x = torch.randn(total, dtype=dt, device="cuda:0", generator=gen) * 0.1
+    y_w, st_w = _run(e, x, off, lens, 0, wavelet=wavelet, level=level, thr_mode="soft")
+    y_l, st_l = _run(e, x, off, lens, 4096, wavelet=wavelet, level=level, thr_mode="soft")
+    bad = [int(n) for o, n in zip(off, lens) if not np.array_equal(y_w[o:o + n].view(ut), y_l[o:o + n].view(ut))]
+    assert not bad, bad[:20]
+    assert np.array_equal(y_w.view(ut), y_l.view(ut))
+    for a, b in zip(st_w, st_l):
+        assert np.array_equal(a, b, equal_nan=True)
