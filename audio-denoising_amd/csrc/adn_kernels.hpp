@@ -44,7 +44,11 @@ struct SelectArgs {
     // d_vals[(seg / blk_rows) * blk_sig_stride + (i / 4) * 4 * quad_stride + (seg % blk_rows) * 4 + i % 4];
     // quad_stride == 1: plain contiguous segments (the fields above)
     int64_t quad_stride = 1, blk_rows = 1, blk_sig_stride = 0;
+    // grouped rows long enough for the streaming route may take it: the caller has reserved
+    // select_rows_stream_ws_bytes of workspace for this call
+    bool rows_stream = false;
 };
+size_t select_rows_stream_ws_bytes(const Ctx *c, int64_t n_sig, int64_t rows_per_sig, int64_t max_len, size_t value_bytes);
 // longest row of the grouped layout launch_select takes (values of value_bytes bytes)
 int64_t select_grouped_limit(size_t value_bytes);
 // longest segment launch_select handles inside one workgroup (longer ones take the

@@ -1615,7 +1615,8 @@ void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_o
                                                      int64_t len_div, int64_t uniform_len, int64_t n_seg, int mode,
                                                      double q, const double *__restrict__ center,
                                                      double *__restrict__ out, MaskedMean mm, int max_bits,
-                                                     int64_t quad_stride, int64_t blk_rows, int64_t blk_sig_stride) {
+                                                     int64_t quad_stride, int64_t blk_rows, int64_t blk_sig_stride,
+                                                     const int *__restrict__ done) {
     typedef typename KeyT<T>::type K;
     typedef typename Quad4<T>::type Q4;
     constexpr K KEY_MAX = ~(K)0;
@@ -1639,6 +1640,7 @@ void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_o
     }
     const int wv = NW == 1 ? 0 : wave;                      // this wave's slice of the row
     if (seg >= n_seg) return;
+    if (done != nullptr && done[seg]) return;               // the row has its result already (rows_stream below)
     // exchange between the waves of a row (NW > 1).  Sums and minima: every wave adds to / lowers one LDS word, a
     // barrier, every wave reads the word; three words used in turn, the next one cleared by the call before, so that
     // one barrier per exchange is enough (a wave can be at most one exchange ahead of the slowest).
@@ -1970,6 +1972,241 @@ void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_o
     if (lane == 0 && wv == 0) out[seg] = select_result<T>(val_of((K)(k0 + kmin)), val_of((K)(k1 + kmin)), r0 == r1, frac, mode);
 }
 
+// ---------------------------------------------------------------- long rows of the grouped layout
+// A row of several ten thousand values fills the registers of all the waves a CU holds (k_select_wave with sixteen
+// waves per row: one row in flight per CU, so that no other row's search covers a row's load).  Such rows are
+// selected in three steps that stream instead:
+//  (1) the order statistics q -+ dq of every RS_STEP-th group of four values of the row (the grouped one-wave select
+//      on an RS_STEP times longer stride) bracket the wanted order statistic;
+//  (2) one pass over the rows (a lane per row, a wave per 64 neighbouring rows and a chunk of their groups: every
+//      load is 1 KB of consecutive bytes) counts the values below the bracket, appends those inside it to the row's
+//      candidate list and adds up the masked values of its chunk;
+//  (3) the exact order statistics of the candidates at the ranks that remain, and the masked mean from the chunks'
+//      sums in chunk order.
+// The bracket only has to be SOME pair of values: a row is done when both wanted ranks lie among its candidates and
+// the list did not overflow; any other row (bracket missed, NaN in the row, no values) is left to k_select_wave,
+// which skips the rows marked done.
+static constexpr int RS_STEP = 16;
+static constexpr int64_t RS_CAP = 8192;                 // candidates kept per row
+static constexpr int RS_BATCH = 4;                      // groups a lane has in flight
+static constexpr int RS_MAX_CHUNKS = 64;
+template <typename T> struct RowStreamMin;              // rows longer than this take the streaming route by themselves
+template <> struct RowStreamMin<float> { static constexpr int64_t value = 4 * 88 * 64; };
+template <> struct RowStreamMin<double> { static constexpr int64_t value = 4 * 96 * 64; };
+
+struct RowStream {
+    unsigned long long *below;   // [row] values below the bracket
+    unsigned long long *count;   // [row] candidates appended (beyond RS_CAP: not stored, the row is not done)
+    int *nan;                    // [row]
+    int *done;                   // [row]
+    double *psum;                // [chunk][row] masked sum of the chunk
+    int *pcnt;                   // [chunk][row]
+    int64_t n_rows;
+    int chunks;
+};
+
+static bool rows_stream_wanted(const Ctx *c, int64_t max_len, size_t value_bytes) {
+    if (c->force_generic || (c->ablate & 32768)) return false;
+    if (c->ablate & 16384) return max_len >= 4 * RS_STEP;
+    return max_len > (value_bytes == 8 ? RowStreamMin<double>::value : RowStreamMin<float>::value);
+}
+static int rows_stream_chunks(int64_t n_sig, int64_t rows_per_sig, int64_t max_len) {
+    const int64_t cols = n_sig * ceil_div(rows_per_sig, (int64_t)64);
+    int64_t ch = ceil_div((int64_t)4096, cols);
+    const int64_t most = ceil_div(ceil_div(max_len, (int64_t)4), (int64_t)(8 * RS_BATCH));    // at least 8 batches per chunk
+    ch = ch > most ? most : ch;
+    return (int)(ch < 1 ? 1 : (ch > RS_MAX_CHUNKS ? RS_MAX_CHUNKS : ch));
+}
+size_t select_rows_stream_ws_bytes(const Ctx *c, int64_t n_sig, int64_t rows_per_sig, int64_t max_len, size_t value_bytes) {
+    if (!rows_stream_wanted(c, max_len, value_bytes)) return 0;
+    const size_t n_rows = (size_t)(n_sig * rows_per_sig);
+    const size_t ch = (size_t)rows_stream_chunks(n_sig, rows_per_sig, max_len);
+    return ws_need(n_rows * RS_CAP, value_bytes) + 2 * ws_need(n_rows, 8) + ws_need((size_t)n_sig, 8) +
+           2 * ws_need(n_rows, 8) + 2 * ws_need(n_rows, 4) + ws_need(ch * n_rows, 8) + ws_need(ch * n_rows, 4);
+}
+
+__global__ void k_rowq_sample_len(const int64_t *__restrict__ seg_len, int64_t n_sig, int64_t *__restrict__ out) {
+    const int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (s >= n_sig) return;
+    const int64_t nq = seg_len[s] >> 2;                    // whole groups
+    out[s] = 4 * ((nq + RS_STEP - 1) / RS_STEP);
+}
+
+template <typename T, bool MASKED>
+__global__ __launch_bounds__(64) void k_rowq_classify(const T *__restrict__ vals, int64_t qs, int64_t rows_per_sig,
+                                                      int64_t sig_stride, const int64_t *__restrict__ seg_len,
+                                                      const double *__restrict__ lo_v, const double *__restrict__ hi_v,
+                                                      const unsigned char *__restrict__ mask, int64_t mask_stride,
+                                                      T *__restrict__ cand, RowStream rs, int64_t groups_per_chunk) {
+    typedef typename KeyT<T>::type K;
+    typedef typename Quad4<T>::type Q4;
+    const int lane = threadIdx.x;
+    const int64_t sig = blockIdx.z, chunk = blockIdx.x;
+    const int64_t bin = (int64_t)blockIdx.y * 64 + lane;
+    const bool act = bin < rows_per_sig;
+    const int64_t row = sig * rows_per_sig + (act ? bin : 0);
+    const int64_t n = seg_len[sig];
+    const int64_t groups = (n + 3) >> 2;                   // the last one may hold fewer than four values
+    const int64_t j0 = chunk * groups_per_chunk;
+    const int64_t j1 = j0 + groups_per_chunk < groups ? j0 + groups_per_chunk : groups;
+    if (j0 >= j1) return;                                  // (the chunk's sums were cleared)
+    const K klo = key_of((T)lo_v[row]), khi = key_of((T)hi_v[row]);
+    const bool ordered = klo <= khi;
+    const K base = ordered ? klo : ~(K)0, span = ordered ? (K)(khi - klo) : (K)0;
+    const Q4 *vv = reinterpret_cast<const Q4 *>(vals + sig * sig_stride) + (act ? bin : 0);
+    const uint32_t *mv = MASKED ? reinterpret_cast<const uint32_t *>(mask + sig * mask_stride) : nullptr;
+    T *list = cand + row * RS_CAP;
+    unsigned long long below = 0;
+    double msum = 0.0;
+    int mcnt = 0;
+    bool nan = false;
+    for (int64_t j = j0; j < j1; j += RS_BATCH) {
+        Q4 xq[RS_BATCH];
+        uint32_t mq[RS_BATCH];
+#pragma unroll
+        for (int i = 0; i < RS_BATCH; ++i) {
+            const int64_t jj = j + i < j1 ? j + i : j1 - 1;
+            xq[i] = vv[jj * qs];
+            mq[i] = MASKED ? mv[jj] : 0u;
+        }
+        T x[4 * RS_BATCH];
+        uint32_t in = 0;
+#pragma unroll
+        for (int i = 0; i < RS_BATCH; ++i) {
+            x[4 * i + 0] = xq[i].x;
+            x[4 * i + 1] = xq[i].y;
+            x[4 * i + 2] = xq[i].z;
+            x[4 * i + 3] = xq[i].w;
+            const int64_t left = n - 4 * (j + i);          // values of the group (<= 0: the batch ran past the chunk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool valid = j + i < j1 && e < left;
+                const T v = x[4 * i + e];
+                if (MASKED && valid && ((mq[i] >> (8 * e)) & 0xFFu)) {
+                    msum += (double)v;
+                    ++mcnt;
+                }
+                const bool is_nan = v != v;
+                nan |= valid && is_nan;
+                const K k = is_nan ? ~(K)0 : key_of(v);
+                below += valid && k < klo ? 1u : 0u;
+                in |= valid && (K)(k - base) <= span ? 1u << (4 * i + e) : 0u;
+            }
+        }
+        if (act && in) {
+            const unsigned long long at = atomicAdd(&rs.count[row], (unsigned long long)__popc(in));
+#pragma unroll
+            for (int i = 0; i < 4 * RS_BATCH; ++i) {
+                const unsigned long long p = at + (unsigned long long)__popc(in & ((1u << i) - 1u));
+                if ((in >> i & 1u) && p < (unsigned long long)RS_CAP) list[p] = x[i];
+            }
+        }
+    }
+    if (!act) return;
+    if (below) atomicAdd(&rs.below[row], below);
+    if (nan) rs.nan[row] = 1;
+    if (MASKED) {
+        rs.psum[chunk * rs.n_rows + row] = msum;
+        rs.pcnt[chunk * rs.n_rows + row] = mcnt;
+    }
+}
+
+template <bool MASKED>
+__global__ void k_rowq_check(const int64_t *__restrict__ seg_len, int64_t rows_per_sig, int mode, double q, RowStream rs,
+                             double *__restrict__ mean_out) {
+    const int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (row >= rs.n_rows) return;
+    const int64_t n = seg_len[row / rows_per_sig];
+    int ok = 0;
+    if (n > 0 && !rs.nan[row]) {
+        int64_t r0, r1;
+        double frac;
+        stat_ranks(n, mode, q, &r0, &r1, &frac);
+        const unsigned long long b = rs.below[row], cnt = rs.count[row];
+        ok = cnt <= (unsigned long long)RS_CAP && (unsigned long long)r0 >= b && (unsigned long long)r1 < b + cnt;
+    }
+    rs.done[row] = ok;
+    if (MASKED && ok) {
+        double sum = 0.0;
+        long long cnt = 0;
+        for (int ch = 0; ch < rs.chunks; ++ch) {
+            sum += rs.psum[ch * rs.n_rows + row];
+            cnt += rs.pcnt[ch * rs.n_rows + row];
+        }
+        mean_out[row] = sum / (double)(cnt > 1 ? cnt : 1);
+    }
+}
+
+template <typename T, int XF, bool MASKED>
+static int launch_select_wave(Ctx *c, const T *d_vals, const SelectArgs &a);
+
+// Steps (1) to (3) for every row of `a` (grouped layout, one length per signal); *done_out: the rows that have their
+// result (the caller runs k_select_wave on the others).
+template <typename T, bool MASKED>
+static int rows_stream(Ctx *c, const T *d_vals, const SelectArgs &a, const int **done_out) {
+    typedef typename KeyT<T>::type K;
+    const int64_t n_sig = a.n_seg / a.blk_rows, n_rows = a.n_seg;
+    const int chunks = rows_stream_chunks(n_sig, a.blk_rows, a.max_len);
+    T *cand = ws_take<T>(c, (size_t)n_rows * RS_CAP);
+    double *lo_v = ws_take<double>(c, n_rows), *hi_v = ws_take<double>(c, n_rows);
+    int64_t *slen = ws_take<int64_t>(c, n_sig);
+    RowStream rs;
+    rs.below = ws_take<unsigned long long>(c, n_rows);
+    rs.count = ws_take<unsigned long long>(c, n_rows);
+    rs.nan = ws_take<int>(c, n_rows);
+    rs.done = ws_take<int>(c, n_rows);
+    rs.psum = ws_take<double>(c, (size_t)chunks * n_rows);
+    rs.pcnt = ws_take<int>(c, (size_t)chunks * n_rows);
+    rs.n_rows = n_rows;
+    rs.chunks = chunks;
+    ADN_HIP(hipMemsetAsync(rs.below, 0, (size_t)n_rows * 8, c->stream));
+    ADN_HIP(hipMemsetAsync(rs.count, 0, (size_t)n_rows * 8, c->stream));
+    ADN_HIP(hipMemsetAsync(rs.nan, 0, (size_t)n_rows * 4, c->stream));
+    if (MASKED) {
+        ADN_HIP(hipMemsetAsync(rs.psum, 0, (size_t)chunks * n_rows * 8, c->stream));
+        ADN_HIP(hipMemsetAsync(rs.pcnt, 0, (size_t)chunks * n_rows * 4, c->stream));
+    }
+    // (1) the bracket: q -+ 4.5 standard deviations of the sample rank (and two ranks), for the longest row's sample
+    ADN_LAUNCH(k_rowq_sample_len, dim3((unsigned)ceil_div(n_sig, (int64_t)256)), dim3(256), 0, c->stream, a.d_seg_len, n_sig, slen);
+    const int64_t m_max = 4 * ceil_div(a.max_len >> 2, (int64_t)RS_STEP);
+    const double qq = a.mode == SEL_MEDIAN ? 50.0 : a.q, pr = qq / 100.0;
+    const double dr = 4.5 * sqrt((double)m_max * pr * (1.0 - pr)) + 2.0;
+    const double dq = 100.0 * dr / (double)(m_max > 1 ? m_max - 1 : 1);
+    SelectArgs sa = a;
+    sa.rows_stream = false;
+    sa.quad_stride = a.quad_stride * RS_STEP;
+    sa.d_seg_len = slen;
+    sa.max_len = m_max;
+    sa.mode = SEL_PERCENTILE;
+    sa.d_mask = nullptr;
+    sa.d_masked_mean = nullptr;
+    sa.q = qq - dq > 0.0 ? qq - dq : 0.0;
+    sa.d_out = lo_v;
+    ADN_TRY((launch_select_wave<T, XF_NONE, false>(c, d_vals, sa)));
+    sa.q = qq + dq < 100.0 ? qq + dq : 100.0;
+    sa.d_out = hi_v;
+    ADN_TRY((launch_select_wave<T, XF_NONE, false>(c, d_vals, sa)));
+    // (2)
+    int64_t gpc = ceil_div(ceil_div(a.max_len, (int64_t)4), (int64_t)chunks);
+    gpc = ceil_div(gpc, (int64_t)RS_BATCH) * RS_BATCH;
+    ADN_LAUNCH_NAMED("k_rowq_classify", (k_rowq_classify<T, MASKED>), dim3((unsigned)chunks, (unsigned)ceil_div(a.blk_rows, (int64_t)64), (unsigned)n_sig),
+                     dim3(64), 0, c->stream, d_vals, a.quad_stride, a.blk_rows, a.blk_sig_stride, a.d_seg_len, lo_v, hi_v,
+                     a.d_mask, a.mask_stride, cand, rs, gpc);
+    ADN_LAUNCH(k_rowq_check<MASKED>, dim3((unsigned)ceil_div(n_rows, (int64_t)256)), dim3(256), 0, c->stream, a.d_seg_len, a.blk_rows,
+               a.mode, a.q, rs, a.d_masked_mean);
+    // (3)
+    const size_t dyn = (size_t)RS_CAP * sizeof(K);
+    auto kern = k_select_lds<T, XF_NONE, false>;
+    ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
+    SubsetRanks sub{a.d_seg_len, a.blk_rows, 0, rs.below, rs.done, nullptr};
+    ADN_LAUNCH_NAMED("k_select_lds<rows, candidates>", kern, dim3((unsigned)n_rows), dim3(SEL_THREADS), dyn, c->stream, cand,
+                     (const int64_t *)nullptr, RS_CAP, reinterpret_cast<const int64_t *>(rs.count), (int64_t)1, (int64_t)0, a.mode, a.q,
+                     (const double *)nullptr, a.d_out, MaskedMean{nullptr, 1, 0, nullptr}, sub);
+    ADN_HIP(hipGetLastError());
+    *done_out = rs.done;
+    return ADN_OK;
+}
+
 static constexpr int64_t SEL_WAVE_MAX = 128 * 64;       // longest row ONE wave holds in registers
 
 // Rows of the grouped layout beyond that (binary32: beyond 88 keys per lane, the longest row four waves per SIMD hold):
@@ -1988,15 +2225,20 @@ static int launch_select_wave(Ctx *c, const T *d_vals, const SelectArgs &a) {
 #define ADN_SEL_WAVE(KPLV)                                                                                          \
     ADN_LAUNCH_NAMED("k_select_wave<" #KPLV ">", (k_select_wave<T, XF, MASKED, KPLV>), grid, block, 0, c->stream, d_vals,  \
                      a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len, a.n_seg, a.mode, a.q, a.d_center, \
-                     a.d_out, mm, (c->ablate & 32) ? 0 : 64, a.quad_stride, a.blk_rows, a.blk_sig_stride)
+                     a.d_out, mm, (c->ablate & 32) ? 0 : 64, a.quad_stride, a.blk_rows, a.blk_sig_stride, (const int *)nullptr)
 #define ADN_SEL_WG(NWV, KPLV)                                                                                        \
     ADN_LAUNCH_NAMED("k_select_wave<" #KPLV ", " #NWV " waves per row>", (k_select_wave<T, XF, MASKED, KPLV, NWV>),   \
                      dim3((unsigned)(ceil_div(a.n_seg, (int64_t)64) * 64)), dim3(NWV * 64), 0, c->stream, d_vals,   \
                      a.d_seg_off, a.seg_stride, a.d_seg_len, a.len_div, a.uniform_len, a.n_seg, a.mode, a.q, a.d_center, \
-                     a.d_out, mm, (c->ablate & 32) ? 0 : 64, a.quad_stride, a.blk_rows, a.blk_sig_stride)
+                     a.d_out, mm, (c->ablate & 32) ? 0 : 64, a.quad_stride, a.blk_rows, a.blk_sig_stride, done)
     // (diagnostic option bit 1024: rows that one wave could hold are shared by two waves all the same)
-    const bool share = a.quad_stride != 1 && (a.max_len > SelWg<T>::ONE_WAVE || (c->ablate & 1024));
+    const bool stream = XF == XF_NONE && a.quad_stride != 1 && a.rows_stream && rows_stream_wanted(c, a.max_len, sizeof(T)) &&
+                        a.d_seg_len != nullptr && a.len_div == a.blk_rows && a.n_seg % a.blk_rows == 0 &&
+                        (!MASKED || (a.mask_div == a.blk_rows && a.mask_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.d_mask) & 3) == 0));
+    const bool share = a.quad_stride != 1 && (a.max_len > SelWg<T>::ONE_WAVE || (c->ablate & 1024) || stream);
+    const int *done = nullptr;
     if constexpr (XF == XF_NONE) {
+        if (stream) ADN_TRY((rows_stream<T, MASKED>(c, d_vals, a, &done)));
         if (share) {
             const int64_t n = a.max_len;
             if constexpr (sizeof(T) == 4) {

@@ -1139,7 +1139,8 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     const size_t nS = (size_t)n_sig * sig_floats, nR = (size_t)n_sig * F;
     ADN_TRY(ws_reserve(c, ws_need(nS, sizeof(T)) + ws_need(n_sig, 8) + 2 * ws_need(nR, 8) + ws_need(nR, sizeof(T)) +
                               ws_need((size_t)n_sig * nv_max, 1) + ws_need((size_t)n_sig * Ts, 1) + ws_need(n_sig, 4) +
-                              2 * select_ws_bytes(n_sig * F, Tmax) + 2 * APPLY_WS_BYTES + ws_need((size_t)n_sig * nv_max, 8)));
+                              2 * select_ws_bytes(n_sig * F, Tmax) + 2 * APPLY_WS_BYTES + ws_need((size_t)n_sig * nv_max, 8) +
+                              2 * select_rows_stream_ws_bytes(c, n_sig, F, Tmax, sizeof(T))));
     T *S = ws_take<T>(c, nS);
     double *vad_e = ws_take<double>(c, (size_t)n_sig * nv_max);
     int64_t *Tn = ws_take<int64_t>(c, n_sig);
@@ -1174,6 +1175,7 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
         sa.quad_stride = ROWS_GROUP_STRIDE;
         sa.blk_rows = F;
         sa.blk_sig_stride = sig_floats;
+        sa.rows_stream = true;
     } else {
         ADN_TRY(rows_dispatch<T>(c, d_x, sg, tb, n_sig, Ts, 1, S, nullptr));
     }

@@ -91,7 +91,9 @@ int adn_synchronize(adn_ctx *ctx);
  *   threshold statistics in two passes (finest band written to memory, two selections on it) instead of one pass
  *   over the samples; 1024 every grouped row is shared by two waves of the row select (what rows longer than
  *   8192 frames get by themselves); 2048 the single-pass statistics print the state of blocks that fell back to
- *   stderr; 4096 binary32 mono blocks run on the LDS tile kernels alone (no wave-resident tiles).
+ *   stderr; 4096 binary32 mono blocks run on the LDS tile kernels alone (no wave-resident tiles); 16384 power rows of
+ *   any length take the streaming row select of the Wiener stage (sample bracket, one gathering pass, exact select on
+ *   the candidates: what rows of more than 22 528 frames, binary64 24 576, take by themselves); 32768 no row does.
  * ADN_OPT_KERNEL_TIMING: record a HIP event pair on the context's stream around every kernel
  *   launch; adn_kernel_times() reports them.  Switching it off drops unreported records. */
 enum { ADN_OPT_FORCE_GENERIC = 1, ADN_OPT_ABLATE = 2, ADN_OPT_FORCE_FALLBACK = 3, ADN_OPT_KERNEL_TIMING = 4 };

@@ -1,0 +1,96 @@
+"""GPU parity of the streaming select of long power rows (Wiener stage, files of more than about eight minutes: every
+16th group of four frames brackets the order statistic, one pass over the rows gathers the candidates inside the
+bracket, the exact select runs on them; rows whose bracket misses are left to the register-resident select).
+Diagnostic option bit 16384 sends rows of any length this way, bit 32768 none.  The order statistics are the same
+keys on either route (gain rows bit for bit when no voice-activity mean is involved); the voice-activity mean adds
+its terms in another order (binary32: 2e-6, binary64: 1e-12)."""
+import numpy as np
+import pytest
+import torch
+
+import adn_oracle as orc
+import synth
+from gpu_util import engine, dev, host, check32, check64
+
+pytestmark = pytest.mark.gpu
+SR = 48000
+
+
+def _wiener(e, bits, *a, **kw):
+    e._check(e.lib.adn_set_option(e._h, 2, bits))
+    try:
+        e.kernel_timing(True)
+        y, l, g = e.wiener(*a, want_gain=True, **kw)
+        torch.cuda.synchronize()
+        names = list(e.kernel_times())
+        return y, g, names
+    finally:
+        e.kernel_timing(False)
+        e._check(e.lib.adn_set_option(e._h, 2, 0))
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n_ch", [1, 2])
+def test_streaming_row_select_equals_register_select(dt, n_ch):
+    """A ragged batch through both routes: speech in noise (30 s), a pure tone (most rows hold a few distinct tiny
+    values), digital silence (every key equal: the whole row is its own candidate list), noise quantised to 16-bit
+    steps (ties), a signal with one NaN sample (NaN rows: left to the register-resident select), a signal one window
+    long (one frame: no sample to take a bracket from), one of 3 s, and noise in bursts that only the sampled frames see."""
+    e = engine()
+    npdt = np.float64 if dt == torch.float64 else np.float32
+    rng = np.random.default_rng(77)
+    lens = [30 * SR + 123, 20 * SR, 12 * SR + 5, 25 * SR, 9 * SR, 2048, 3 * SR, 40 * SR]
+    t = np.arange(lens[1]) / SR
+    sigs = [synth.noisy_speech(lens[0], SR, 42, 501),
+            0.5 * np.sin(2 * np.pi * 1000.0 * t),
+            np.zeros(lens[2]),
+            np.round(rng.standard_normal(lens[3]) * 40.0) / 32768.0,
+            synth.noisy_speech(lens[4], SR, 42, 502),
+            rng.standard_normal(lens[5]) * 0.1,
+            synth.noisy_speech(lens[6], SR, 42, 503),
+            rng.standard_normal(lens[7]) * 0.1]
+    # bursts at the period of the sample (every 16th group of four frames = 64 hops): the sampled frames are all loud,
+    # nine tenths of the others quiet, so that the brackets miss and the rows go back to the register-resident select
+    pos = np.arange(lens[7]) % (64 * 512)
+    sigs[7] *= np.where(pos < 2048 + 3 * 512, 1.0, 0.01)
+    sigs[4][4 * SR + 17] = np.nan
+    if n_ch == 2:
+        sigs = [np.stack([s, 0.7 * s + 0.01 * rng.standard_normal(len(s)) * (np.abs(s).max() > 0)], axis=1).reshape(-1) for s in sigs]
+    xs = dev(np.concatenate(sigs).astype(npdt), dt)
+    for vad in (True, False):
+        y0, g0, k0 = _wiener(e, 32768, xs, lens, SR, n_ch=n_ch, vad_guided=vad)
+        y1, g1, k1 = _wiener(e, 16384, xs, lens, SR, n_ch=n_ch, vad_guided=vad)
+        assert not any("k_rowq_classify" in k for k in k0) and any("k_rowq_classify" in k for k in k1)
+        g0h, g1h, y0h, y1h = host(g0), host(g1), host(y0), host(y1)
+        assert np.array_equal(np.isnan(g0h), np.isnan(g1h)) and np.array_equal(np.isnan(y0h), np.isnan(y1h))
+        if vad:
+            tol = 1e-12 if dt == torch.float64 else 2e-6
+            assert np.nanmax(np.abs(g0h - g1h)) <= tol
+            assert np.nanmax(np.abs(y0h - y1h)) <= tol
+        else:
+            assert np.array_equal(g0h, g1h, equal_nan=True)
+            assert np.array_equal(y0h, y1h, equal_nan=True)
+
+
+@pytest.mark.timeout(600)
+def test_streaming_row_select_ten_minute_file_against_oracle():
+    """One mono file of 600 s at 48 kHz (56 247 frames per row: the streaming route by itself) through the Wiener
+    stage, with and without voice-activity guidance: against the oracle (binary32 tolerance) and against the
+    register-resident select of the same rows."""
+    e = engine()
+    n = 600 * SR
+    x = np.concatenate([synth.noisy_speech(60 * SR, SR, 42, 600 + i) * (0.5 + 0.1 * i) for i in range(10)]).astype(np.float32)
+    xd = dev(x, torch.float32)
+    for vad in (True, False):
+        y1, g1, k1 = _wiener(e, 0, xd, [n], SR, vad_guided=vad)
+        assert any("k_rowq_classify" in k for k in k1)
+        y0, g0, k0 = _wiener(e, 32768, xd, [n], SR, vad_guided=vad)
+        assert not any("k_rowq_classify" in k for k in k0)
+        if vad:
+            assert float((g0 - g1).abs().max()) <= 2e-6 and float((y0 - y1).abs().max()) <= 2e-6
+        else:
+            assert torch.equal(g0, g1) and torch.equal(y0, y1)
+        want, gain_or = orc.wiener(x.astype(np.float64), SR, vad_guided=vad)
+        check32(host(y1), want)
+        assert np.max(np.abs(host(g1)[0] - gain_or)) <= 2e-5
