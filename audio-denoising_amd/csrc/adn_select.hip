@@ -2022,7 +2022,7 @@ size_t select_rows_stream_ws_bytes(const Ctx *c, int64_t n_sig, int64_t rows_per
     const size_t n_rows = (size_t)(n_sig * rows_per_sig);
     const size_t ch = (size_t)rows_stream_chunks(n_sig, rows_per_sig, max_len);
     return ws_need(n_rows * RS_CAP, value_bytes) + 2 * ws_need(n_rows, 8) + ws_need((size_t)n_sig, 8) +
-           2 * ws_need(n_rows, 8) + 2 * ws_need(n_rows, 4) + ws_need(ch * n_rows, 8) + ws_need(ch * n_rows, 4);
+           ws_need(2 * n_rows + (n_rows + 1) / 2, 8) + ws_need(n_rows, 4) + ws_need(ch * n_rows, 8) + ws_need(ch * n_rows, 4);
 }
 
 __global__ void k_rowq_sample_len(const int64_t *__restrict__ seg_len, int64_t n_sig, int64_t *__restrict__ out) {
@@ -2049,7 +2049,13 @@ __global__ __launch_bounds__(64) void k_rowq_classify(const T *__restrict__ vals
     const int64_t groups = (n + 3) >> 2;                   // the last one may hold fewer than four values
     const int64_t j0 = chunk * groups_per_chunk;
     const int64_t j1 = j0 + groups_per_chunk < groups ? j0 + groups_per_chunk : groups;
-    if (j0 >= j1) return;                                  // (the chunk's sums were cleared)
+    if (j0 >= j1) {                                        // no frames in this chunk
+        if (MASKED && act) {
+            rs.psum[chunk * rs.n_rows + row] = 0.0;
+            rs.pcnt[chunk * rs.n_rows + row] = 0;
+        }
+        return;
+    }
     const K klo = key_of((T)lo_v[row]), khi = key_of((T)hi_v[row]);
     const bool ordered = klo <= khi;
     const K base = ordered ? klo : ~(K)0, span = ordered ? (K)(khi - klo) : (K)0;
@@ -2151,21 +2157,17 @@ static int rows_stream(Ctx *c, const T *d_vals, const SelectArgs &a, const int *
     double *lo_v = ws_take<double>(c, n_rows), *hi_v = ws_take<double>(c, n_rows);
     int64_t *slen = ws_take<int64_t>(c, n_sig);
     RowStream rs;
-    rs.below = ws_take<unsigned long long>(c, n_rows);
-    rs.count = ws_take<unsigned long long>(c, n_rows);
-    rs.nan = ws_take<int>(c, n_rows);
+    // (the three arrays that start at zero lie side by side: one fill)
+    unsigned long long *zeroed = ws_take<unsigned long long>(c, 2 * (size_t)n_rows + ((size_t)n_rows + 1) / 2);
+    rs.below = zeroed;
+    rs.count = zeroed + n_rows;
+    rs.nan = reinterpret_cast<int *>(zeroed + 2 * n_rows);
     rs.done = ws_take<int>(c, n_rows);
     rs.psum = ws_take<double>(c, (size_t)chunks * n_rows);
     rs.pcnt = ws_take<int>(c, (size_t)chunks * n_rows);
     rs.n_rows = n_rows;
     rs.chunks = chunks;
-    ADN_HIP(hipMemsetAsync(rs.below, 0, (size_t)n_rows * 8, c->stream));
-    ADN_HIP(hipMemsetAsync(rs.count, 0, (size_t)n_rows * 8, c->stream));
-    ADN_HIP(hipMemsetAsync(rs.nan, 0, (size_t)n_rows * 4, c->stream));
-    if (MASKED) {
-        ADN_HIP(hipMemsetAsync(rs.psum, 0, (size_t)chunks * n_rows * 8, c->stream));
-        ADN_HIP(hipMemsetAsync(rs.pcnt, 0, (size_t)chunks * n_rows * 4, c->stream));
-    }
+    ADN_HIP(hipMemsetAsync(zeroed, 0, (size_t)n_rows * 20, c->stream));
     // (1) the bracket: q -+ 4.5 standard deviations of the sample rank (and two ranks), for the longest row's sample
     ADN_LAUNCH(k_rowq_sample_len, dim3((unsigned)ceil_div(n_sig, (int64_t)256)), dim3(256), 0, c->stream, a.d_seg_len, n_sig, slen);
     const int64_t m_max = 4 * ceil_div(a.max_len >> 2, (int64_t)RS_STEP);
