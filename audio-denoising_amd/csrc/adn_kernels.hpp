@@ -20,7 +20,10 @@ __host__ __device__ inline long long sample_run_start(long long n, int nrun, int
 }
 
 // ------------------------------------------------ segmented order statistics
-enum { SEL_MEDIAN = 0, SEL_PERCENTILE = 1, SEL_PERCENTILE_DB20 = 2 };
+enum { SEL_MEDIAN = 0, SEL_PERCENTILE = 1, SEL_PERCENTILE_DB20 = 2,
+       // internal (brackets taken from a sample of n values): the order statistic at rank (n - 1) q / 100 minus / plus
+       // 4.5 standard deviations of that rank in a sample of n (and two ranks), clamped to the sample
+       SEL_BRACKET_LO = 3, SEL_BRACKET_HI = 4 };
 enum { XF_NONE = 0, XF_ABSDEV = 1 };
 
 struct SelectArgs {

@@ -54,6 +54,15 @@ __host__ __device__ inline void stat_ranks(int64_t n, int mode, double q, int64_
         *frac = 0.5;
         return;
     }
+    if (mode == SEL_BRACKET_LO || mode == SEL_BRACKET_HI) {
+        const double p = q / 100.0, d = 4.5 * sqrt((double)n * p * (1.0 - p)) + 2.0;
+        double at = (double)(n - 1) * p + (mode == SEL_BRACKET_LO ? -d : d);
+        at = mode == SEL_BRACKET_LO ? floor(at) : ceil(at);
+        at = at < 0.0 ? 0.0 : (at > (double)(n - 1) ? (double)(n - 1) : at);
+        *r0 = *r1 = (int64_t)at;
+        *frac = 0.0;
+        return;
+    }
     const double pos = (double)(n - 1) * (q / 100.0);
     int64_t lo = (int64_t)floor(pos);
     if (lo > n - 1) lo = n - 1;
@@ -1976,8 +1985,8 @@ void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_o
 // A row of several ten thousand values fills the registers of all the waves a CU holds (k_select_wave with sixteen
 // waves per row: one row in flight per CU, so that no other row's search covers a row's load).  Such rows are
 // selected in three steps that stream instead:
-//  (1) the order statistics q -+ dq of every RS_STEP-th group of four values of the row (the grouped one-wave select
-//      on an RS_STEP times longer stride) bracket the wanted order statistic;
+//  (1) two order statistics of every RS_STEP-th group of four values of the row (the grouped one-wave select on an
+//      RS_STEP times longer stride; modes SEL_BRACKET_LO / _HI) bracket the wanted order statistic;
 //  (2) one pass over the rows (a lane per row, a wave per 64 neighbouring rows and a chunk of their groups: every
 //      load is 1 KB of consecutive bytes) counts the values below the bracket, appends those inside it to the row's
 //      candidate list and adds up the masked values of its chunk;
@@ -2168,24 +2177,22 @@ static int rows_stream(Ctx *c, const T *d_vals, const SelectArgs &a, const int *
     rs.n_rows = n_rows;
     rs.chunks = chunks;
     ADN_HIP(hipMemsetAsync(zeroed, 0, (size_t)n_rows * 20, c->stream));
-    // (1) the bracket: q -+ 4.5 standard deviations of the sample rank (and two ranks), for the longest row's sample
+    // (1) the bracket: the sample's order statistics 4.5 standard deviations of the rank (and two ranks) to either side
+    // of the wanted one, for every row by the length of its own sample
     ADN_LAUNCH(k_rowq_sample_len, dim3((unsigned)ceil_div(n_sig, (int64_t)256)), dim3(256), 0, c->stream, a.d_seg_len, n_sig, slen);
     const int64_t m_max = 4 * ceil_div(a.max_len >> 2, (int64_t)RS_STEP);
-    const double qq = a.mode == SEL_MEDIAN ? 50.0 : a.q, pr = qq / 100.0;
-    const double dr = 4.5 * sqrt((double)m_max * pr * (1.0 - pr)) + 2.0;
-    const double dq = 100.0 * dr / (double)(m_max > 1 ? m_max - 1 : 1);
     SelectArgs sa = a;
     sa.rows_stream = false;
     sa.quad_stride = a.quad_stride * RS_STEP;
     sa.d_seg_len = slen;
     sa.max_len = m_max;
-    sa.mode = SEL_PERCENTILE;
+    sa.q = a.mode == SEL_MEDIAN ? 50.0 : a.q;
     sa.d_mask = nullptr;
     sa.d_masked_mean = nullptr;
-    sa.q = qq - dq > 0.0 ? qq - dq : 0.0;
+    sa.mode = SEL_BRACKET_LO;
     sa.d_out = lo_v;
     ADN_TRY((launch_select_wave<T, XF_NONE, false>(c, d_vals, sa)));
-    sa.q = qq + dq < 100.0 ? qq + dq : 100.0;
+    sa.mode = SEL_BRACKET_HI;
     sa.d_out = hi_v;
     ADN_TRY((launch_select_wave<T, XF_NONE, false>(c, d_vals, sa)));
     // (2)
