@@ -148,9 +148,22 @@ template <> struct CxOf<double> { typedef z2 type; };
 template <> struct QuadOf<float> { typedef f4v type; };
 template <> struct QuadOf<double> { typedef z4 type; };
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ double fast_sqrt(double x) { return sqrt(x); }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
-__device__ __forceinline__ double fast_rsq(double x) { return 1.0 / sqrt(x); }
+// binary64: the hardware's reciprocal square root (about 26 good bits) and two Newton steps, eight instructions where
+// the library's sqrt followed by a division takes some forty; the result is within two units in the last place for
+// every positive finite argument (squared magnitudes here: no overflow of x * y * y near the ends of the range
+// matters, x y y stays about 1).  Zero gives NaN (0 * inf): the callers select around it.
+__device__ __forceinline__ double fast_rsq(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    y = y * fma(-(h * y), y, 1.5);
+    y = y * fma(-(h * y), y, 1.5);
+    return y;
+}
+__device__ __forceinline__ double fast_sqrt(double x) {
+    const double r = x * fast_rsq(x);
+    return (x > 0.0 && x < __builtin_inf()) ? r : x;       // sqrt(+-0) = +-0, sqrt(inf) = inf, sqrt(NaN) = NaN
+}
 
 // v * W16^M (forward) or its conjugate (inverse)
 template <int M, bool INV, typename C>
