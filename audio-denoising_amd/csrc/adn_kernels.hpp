@@ -52,6 +52,9 @@ struct SelectArgs {
     bool rows_stream = false;
 };
 size_t select_rows_stream_ws_bytes(const Ctx *c, int64_t n_sig, int64_t rows_per_sig, int64_t max_len, size_t value_bytes);
+// longest row of the grouped layout when the caller sets rows_stream (the streaming route has its own exact fallback,
+// so it reaches beyond the register-resident select)
+int64_t select_grouped_limit_stream(const Ctx *c, size_t value_bytes);
 // longest row of the grouped layout launch_select takes (values of value_bytes bytes)
 int64_t select_grouped_limit(size_t value_bytes);
 // longest segment launch_select handles inside one workgroup (longer ones take the

@@ -1996,21 +1996,27 @@ void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_o
 // the list did not overflow; any other row (bracket missed, NaN in the row, no values) is left to k_select_wave,
 // which skips the rows marked done.
 static constexpr int RS_STEP = 16;
-static constexpr int64_t RS_CAP = 8192;                 // candidates kept per row
+// candidates kept per row: the bracket of a median holds about 9 sqrt(RS_STEP n / 4) values
+__host__ __device__ static inline int64_t rows_stream_cap(int64_t max_len, size_t value_bytes) {
+    return value_bytes == 4 && max_len > 131072 ? 16384 : 8192;
+}
+// longest row of the grouped layout with the streaming route (the candidate lists of longer rows outgrow LDS)
+static constexpr int64_t RS_LIMIT_F32 = 262144, RS_LIMIT_F64 = 98304;
 static constexpr int RS_BATCH = 4;                      // groups a lane has in flight
-static constexpr int RS_MAX_CHUNKS = 64;
+static constexpr int RS_MAX_CHUNKS = 256;
 template <typename T> struct RowStreamMin;              // rows longer than this take the streaming route by themselves
 template <> struct RowStreamMin<float> { static constexpr int64_t value = 4 * 88 * 64; };
 template <> struct RowStreamMin<double> { static constexpr int64_t value = 4 * 96 * 64; };
 
 struct RowStream {
     unsigned long long *below;   // [row] values below the bracket
-    unsigned long long *count;   // [row] candidates appended (beyond RS_CAP: not stored, the row is not done)
+    unsigned long long *count;   // [row] candidates appended (beyond cap: not stored, the row is not done)
     int *nan;                    // [row]
     int *done;                   // [row]
     double *psum;                // [chunk][row] masked sum of the chunk
     int *pcnt;                   // [chunk][row]
     int64_t n_rows;
+    int64_t cap;                 // places of a row's candidate list
     int chunks;
 };
 
@@ -2030,7 +2036,7 @@ size_t select_rows_stream_ws_bytes(const Ctx *c, int64_t n_sig, int64_t rows_per
     if (!rows_stream_wanted(c, max_len, value_bytes)) return 0;
     const size_t n_rows = (size_t)(n_sig * rows_per_sig);
     const size_t ch = (size_t)rows_stream_chunks(n_sig, rows_per_sig, max_len);
-    return ws_need(n_rows * RS_CAP, value_bytes) + 2 * ws_need(n_rows, 8) + ws_need((size_t)n_sig, 8) +
+    return ws_need(n_rows * (size_t)rows_stream_cap(max_len, value_bytes), value_bytes) + 2 * ws_need(n_rows, 8) + ws_need((size_t)n_sig, 8) +
            ws_need(2 * n_rows + (n_rows + 1) / 2, 8) + ws_need(n_rows, 4) + ws_need(ch * n_rows, 8) + ws_need(ch * n_rows, 4);
 }
 
@@ -2070,7 +2076,7 @@ __global__ __launch_bounds__(64) void k_rowq_classify(const T *__restrict__ vals
     const K base = ordered ? klo : ~(K)0, span = ordered ? (K)(khi - klo) : (K)0;
     const Q4 *vv = reinterpret_cast<const Q4 *>(vals + sig * sig_stride) + (act ? bin : 0);
     const uint32_t *mv = MASKED ? reinterpret_cast<const uint32_t *>(mask + sig * mask_stride) : nullptr;
-    T *list = cand + row * RS_CAP;
+    T *list = cand + row * rs.cap;
     unsigned long long below = 0;
     double msum = 0.0;
     int mcnt = 0;
@@ -2113,7 +2119,7 @@ __global__ __launch_bounds__(64) void k_rowq_classify(const T *__restrict__ vals
 #pragma unroll
             for (int i = 0; i < 4 * RS_BATCH; ++i) {
                 const unsigned long long p = at + (unsigned long long)__popc(in & ((1u << i) - 1u));
-                if ((in >> i & 1u) && p < (unsigned long long)RS_CAP) list[p] = x[i];
+                if ((in >> i & 1u) && p < (unsigned long long)rs.cap) list[p] = x[i];
             }
         }
     }
@@ -2138,7 +2144,7 @@ __global__ void k_rowq_check(const int64_t *__restrict__ seg_len, int64_t rows_p
         double frac;
         stat_ranks(n, mode, q, &r0, &r1, &frac);
         const unsigned long long b = rs.below[row], cnt = rs.count[row];
-        ok = cnt <= (unsigned long long)RS_CAP && (unsigned long long)r0 >= b && (unsigned long long)r1 < b + cnt;
+        ok = cnt <= (unsigned long long)rs.cap && (unsigned long long)r0 >= b && (unsigned long long)r1 < b + cnt;
     }
     rs.done[row] = ok;
     if (MASKED && ok) {
@@ -2152,6 +2158,154 @@ __global__ void k_rowq_check(const int64_t *__restrict__ seg_len, int64_t rows_p
     }
 }
 
+// The rows the streaming route left, whatever their length (rows beyond the register-resident select's reach have no
+// other exact route): radix selection, eight key bits per pass over the row, one workgroup per row, early exit for the
+// rows that are done.  The masked mean adds per-thread sums in thread order.  Few rows come here (a bracket misses
+// about one row in 10^5), unless the data has NaN or the sample misleads: then this is slow and exact.
+template <typename T, bool MASKED>
+__global__ __launch_bounds__(256) void k_rowq_exact(const T *__restrict__ vals, int64_t qs, int64_t rows_per_sig,
+                                                    int64_t sig_stride, const int64_t *__restrict__ seg_len,
+                                                    const unsigned char *__restrict__ mask, int64_t mask_stride,
+                                                    const int *__restrict__ done, int mode, double q,
+                                                    double *__restrict__ out, double *__restrict__ mean_out) {
+    typedef typename KeyT<T>::type K;
+    typedef typename Quad4<T>::type Q4;
+    constexpr int BITS = KeyT<T>::bits;
+    const int64_t row = blockIdx.x;
+    if (done[row]) return;
+    const int tid = threadIdx.x;
+    const int64_t sig = row / rows_per_sig, bin = row % rows_per_sig;
+    const int64_t n = seg_len[sig];
+    if (n <= 0) {
+        if (tid == 0) {
+            out[row] = __longlong_as_double(0x7FF8000000000000ll);
+            if (MASKED) mean_out[row] = 0.0;
+        }
+        return;
+    }
+    int64_t r0, r1;
+    double frac;
+    stat_ranks(n, mode, q, &r0, &r1, &frac);
+    const Q4 *vv = reinterpret_cast<const Q4 *>(vals + sig * sig_stride) + bin;
+    const uint32_t *mv = MASKED ? reinterpret_cast<const uint32_t *>(mask + sig * mask_stride) : nullptr;
+    const int64_t groups = (n + 3) >> 2;
+    __shared__ uint32_t hist[256];
+    __shared__ unsigned long long s_rank;
+    __shared__ K s_prefix;
+    __shared__ int s_nan;
+    __shared__ double s_sum[256];
+    __shared__ int s_cnt[256];
+    __shared__ K s_above[256];
+    __shared__ uint32_t s_le[256];
+    // one sweep over the row: f(value, key, mask byte) for every value of the row, four groups per thread in flight
+    auto sweep = [&](bool with_mask, auto &&f) {
+        for (int64_t j = tid; j < groups; j += 4 * 256) {
+            Q4 xq[4];
+            uint32_t mq[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t jj = j + i * 256 < groups ? j + i * 256 : j;
+                xq[i] = vv[jj * qs];
+                mq[i] = MASKED && with_mask ? mv[jj] : 0u;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t jj = j + i * 256;
+                if (jj >= groups) break;
+                const int64_t left = n - 4 * jj;
+                const T x[4] = {xq[i].x, xq[i].y, xq[i].z, xq[i].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (e < left) {
+                        const bool is_nan = x[e] != x[e];
+                        f(x[e], is_nan ? ~(K)0 : key_of(x[e]), (mq[i] >> (8 * e)) & 0xFFu);
+                    }
+            }
+        }
+    };
+    K prefix = 0;
+    unsigned long long rank = (unsigned long long)r0;
+    double msum = 0.0;
+    int mcnt = 0;
+    bool nan = false;
+    for (int pass = 0; pass < BITS / 8; ++pass) {
+        const int shift = BITS - 8 * (pass + 1);
+        hist[tid] = 0;
+        if (tid == 0 && pass == 0) s_nan = 0;
+        __syncthreads();
+        if (pass == 0) {
+            sweep(true, [&](T v, K k, uint32_t m) {
+                if (MASKED && m) {
+                    msum += (double)v;
+                    ++mcnt;
+                }
+                nan |= k == ~(K)0;
+                atomicAdd(&hist[(uint32_t)(k >> shift) & 255u], 1u);
+            });
+            if (nan) s_nan = 1;
+            if (MASKED) {
+                s_sum[tid] = msum;
+                s_cnt[tid] = mcnt;
+            }
+        } else {
+            sweep(false, [&](T, K k, uint32_t) {
+                if ((K)(k >> (shift + 8)) == prefix) atomicAdd(&hist[(uint32_t)(k >> shift) & 255u], 1u);
+            });
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (pass == 0 && MASKED) {
+                double sum = 0.0;
+                long long cnt = 0;
+                for (int i = 0; i < 256; ++i) {
+                    sum += s_sum[i];
+                    cnt += s_cnt[i];
+                }
+                mean_out[row] = sum / (double)(cnt > 1 ? cnt : 1);
+            }
+            unsigned long long before = 0;
+            int d = 0;
+            for (; d < 255; ++d) {
+                if (before + hist[d] > rank) break;
+                before += hist[d];
+            }
+            s_rank = rank - before;
+            s_prefix = (K)((prefix << 8) | (K)d);
+        }
+        __syncthreads();
+        if (s_nan) {                                           // a NaN in the row: the statistic is NaN
+            if (tid == 0) out[row] = __longlong_as_double(0x7FF8000000000000ll);
+            return;
+        }
+        rank = s_rank;
+        prefix = s_prefix;
+    }
+    const K k0 = prefix;
+    K k1 = k0;
+    if (r1 != r0) {
+        // the next order statistic: k0 again if it occurs often enough, else the smallest key above it
+        uint32_t le = 0;
+        K above = ~(K)0;
+        sweep(false, [&](T, K k, uint32_t) {
+            le += k <= k0 ? 1u : 0u;
+            above = (k > k0 && k < above) ? k : above;
+        });
+        s_le[tid] = le;
+        s_above[tid] = above;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long tot = 0;
+            K mn = ~(K)0;
+            for (int i = 0; i < 256; ++i) {
+                tot += s_le[i];
+                mn = s_above[i] < mn ? s_above[i] : mn;
+            }
+            k1 = tot > (unsigned long long)r1 ? k0 : mn;
+        }
+    }
+    if (tid == 0) out[row] = select_result<T>(val_of(k0), val_of(k1), r0 == r1, frac, mode);
+}
+
 template <typename T, int XF, bool MASKED>
 static int launch_select_wave(Ctx *c, const T *d_vals, const SelectArgs &a);
 
@@ -2162,7 +2316,8 @@ static int rows_stream(Ctx *c, const T *d_vals, const SelectArgs &a, const int *
     typedef typename KeyT<T>::type K;
     const int64_t n_sig = a.n_seg / a.blk_rows, n_rows = a.n_seg;
     const int chunks = rows_stream_chunks(n_sig, a.blk_rows, a.max_len);
-    T *cand = ws_take<T>(c, (size_t)n_rows * RS_CAP);
+    const int64_t cap = rows_stream_cap(a.max_len, sizeof(T));
+    T *cand = ws_take<T>(c, (size_t)n_rows * cap);
     double *lo_v = ws_take<double>(c, n_rows), *hi_v = ws_take<double>(c, n_rows);
     int64_t *slen = ws_take<int64_t>(c, n_sig);
     RowStream rs;
@@ -2175,6 +2330,7 @@ static int rows_stream(Ctx *c, const T *d_vals, const SelectArgs &a, const int *
     rs.psum = ws_take<double>(c, (size_t)chunks * n_rows);
     rs.pcnt = ws_take<int>(c, (size_t)chunks * n_rows);
     rs.n_rows = n_rows;
+    rs.cap = cap;
     rs.chunks = chunks;
     ADN_HIP(hipMemsetAsync(zeroed, 0, (size_t)n_rows * 20, c->stream));
     // (1) the bracket: the sample's order statistics 4.5 standard deviations of the rank (and two ranks) to either side
@@ -2204,12 +2360,12 @@ static int rows_stream(Ctx *c, const T *d_vals, const SelectArgs &a, const int *
     ADN_LAUNCH(k_rowq_check<MASKED>, dim3((unsigned)ceil_div(n_rows, (int64_t)256)), dim3(256), 0, c->stream, a.d_seg_len, a.blk_rows,
                a.mode, a.q, rs, a.d_masked_mean);
     // (3)
-    const size_t dyn = (size_t)RS_CAP * sizeof(K);
+    const size_t dyn = (size_t)cap * sizeof(K);
     auto kern = k_select_lds<T, XF_NONE, false>;
     ADN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn));
     SubsetRanks sub{a.d_seg_len, a.blk_rows, 0, rs.below, rs.done, nullptr};
     ADN_LAUNCH_NAMED("k_select_lds<rows, candidates>", kern, dim3((unsigned)n_rows), dim3(SEL_THREADS), dyn, c->stream, cand,
-                     (const int64_t *)nullptr, RS_CAP, reinterpret_cast<const int64_t *>(rs.count), (int64_t)1, (int64_t)0, a.mode, a.q,
+                     (const int64_t *)nullptr, cap, reinterpret_cast<const int64_t *>(rs.count), (int64_t)1, (int64_t)0, a.mode, a.q,
                      (const double *)nullptr, a.d_out, MaskedMean{nullptr, 1, 0, nullptr}, sub);
     ADN_HIP(hipGetLastError());
     *done_out = rs.done;
@@ -2247,7 +2403,19 @@ static int launch_select_wave(Ctx *c, const T *d_vals, const SelectArgs &a) {
     const bool share = a.quad_stride != 1 && (a.max_len > SelWg<T>::ONE_WAVE || (c->ablate & 1024) || stream);
     const int *done = nullptr;
     if constexpr (XF == XF_NONE) {
+        const bool beyond = a.quad_stride != 1 && a.max_len > SelWg<T>::LIMIT;     // no register kernel holds such a row
+        if (beyond && !stream) {
+            set_error("internal: grouped rows of %lld values need the streaming row select", (long long)a.max_len);
+            return ADN_ERR_UNSUPPORTED;
+        }
         if (stream) ADN_TRY((rows_stream<T, MASKED>(c, d_vals, a, &done)));
+        if (stream && (beyond || (c->ablate & 65536))) {
+            ADN_LAUNCH_NAMED("k_rowq_exact", (k_rowq_exact<T, MASKED>), dim3((unsigned)a.n_seg), dim3(256), 0, c->stream, d_vals,
+                             a.quad_stride, a.blk_rows, a.blk_sig_stride, a.d_seg_len, a.d_mask, a.mask_stride, done, a.mode,
+                             a.q, a.d_out, a.d_masked_mean);
+            ADN_HIP(hipGetLastError());
+            return ADN_OK;
+        }
         if (share) {
             const int64_t n = a.max_len;
             if constexpr (sizeof(T) == 4) {
@@ -2281,16 +2449,21 @@ static int launch_select_wave(Ctx *c, const T *d_vals, const SelectArgs &a) {
 }
 
 int64_t select_grouped_limit(size_t value_bytes) { return value_bytes == 8 ? SelWg<double>::LIMIT : SelWg<float>::LIMIT; }
+int64_t select_grouped_limit_stream(const Ctx *c, size_t value_bytes) {
+    const int64_t lim = value_bytes == 8 ? RS_LIMIT_F64 : RS_LIMIT_F32;
+    return rows_stream_wanted(c, lim, value_bytes) ? lim : select_grouped_limit(value_bytes);
+}
 
 template <typename T>
 int launch_select(Ctx *c, const T *d_vals, const SelectArgs &a) {
     if (a.n_seg <= 0) return ADN_OK;
     using K = typename KeyT<T>::type;
     if (a.quad_stride != 1) {
-        ADN_REQUIRE(a.max_len > 0 && a.max_len <= select_grouped_limit(sizeof(T)) && a.xform == XF_NONE &&
+        const int64_t longest = a.rows_stream ? select_grouped_limit_stream(c, sizeof(T)) : select_grouped_limit(sizeof(T));
+        ADN_REQUIRE(a.max_len > 0 && a.max_len <= longest && a.xform == XF_NONE &&
                         a.mode != SEL_PERCENTILE_DB20 && (reinterpret_cast<uintptr_t>(d_vals) & 31) == 0 &&
                         a.blk_sig_stride % 4 == 0 && (a.quad_stride * (a.max_len / 4 + 1)) < (int64_t(1) << 28),
-                    "internal: grouped rows are rows of at most %lld values", (long long)select_grouped_limit(sizeof(T)));
+                    "internal: grouped rows are rows of at most %lld values", (long long)longest);
     }
     if (a.max_len > BIG_THRESHOLD && a.quad_stride == 1) {
         if (a.d_masked_mean) {

@@ -1154,7 +1154,7 @@ int wiener(Ctx *c, const T *d_x, int64_t n_sig, const int64_t *d_off, const int6
     // rows of up to a few thousand frames: power rows in groups of four frames, written by waves that
     // work alone and read by the register-resident row select; the rows kernel adds up the voice-activity
     // frames' energies on the way when those frames are at least a hop long
-    const bool grouped = !c->force_generic && (c->ablate & 64) == 0 && rows_wave_ok(sg, n_fft) && Tmax <= select_grouped_limit(sizeof(T));
+    const bool grouped = !c->force_generic && (c->ablate & 64) == 0 && rows_wave_ok(sg, n_fft) && Tmax <= select_grouped_limit_stream(c, sizeof(T));
     const bool vad_in_rows = grouped && vad_guided && (c->ablate & 128) == 0 && frame_len >= hop &&
                              frame_len <= rows_wave_vad_max_frame();
     if (vad_guided && !vad_in_rows) {

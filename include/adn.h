@@ -93,7 +93,9 @@ int adn_synchronize(adn_ctx *ctx);
  *   8192 frames get by themselves); 2048 the single-pass statistics print the state of blocks that fell back to
  *   stderr; 4096 binary32 mono blocks run on the LDS tile kernels alone (no wave-resident tiles); 16384 power rows of
  *   any length take the streaming row select of the Wiener stage (sample bracket, one gathering pass, exact select on
- *   the candidates: what rows of more than 22 528 frames, binary64 24 576, take by themselves); 32768 no row does.
+ *   the candidates: what rows of more than 22 528 frames, binary64 24 576, take by themselves); 32768 no row does;
+ *   65536 the rows the streaming select's brackets miss go to its radix selection (what rows of more than 90 112
+ *   frames, binary64 49 152, get by themselves) instead of the register-resident select.
  * ADN_OPT_KERNEL_TIMING: record a HIP event pair on the context's stream around every kernel
  *   launch; adn_kernel_times() reports them.  Switching it off drops unreported records. */
 enum { ADN_OPT_FORCE_GENERIC = 1, ADN_OPT_ABLATE = 2, ADN_OPT_FORCE_FALLBACK = 3, ADN_OPT_KERNEL_TIMING = 4 };

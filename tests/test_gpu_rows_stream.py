@@ -1,7 +1,9 @@
 """GPU parity of the streaming select of long power rows (Wiener stage, files of more than about eight minutes: every
 16th group of four frames brackets the order statistic, one pass over the rows gathers the candidates inside the
 bracket, the exact select runs on them; rows whose bracket misses are left to the register-resident select).
-Diagnostic option bit 16384 sends rows of any length this way, bit 32768 none.  The order statistics are the same
+Diagnostic option bit 16384 sends rows of any length this way, bit 32768 none; bit 65536 gives the rows the brackets
+miss to the radix selection that serves rows beyond the register-resident select's reach (90 112 frames in binary32,
+49 152 in binary64) instead of the register-resident select.  The order statistics are the same
 keys on either route (gain rows bit for bit when no voice-activity mean is involved); the voice-activity mean adds
 its terms in another order (binary32: 2e-6, binary64: 1e-12)."""
 import numpy as np
@@ -60,17 +62,20 @@ def test_streaming_row_select_equals_register_select(dt, n_ch):
     xs = dev(np.concatenate(sigs).astype(npdt), dt)
     for vad in (True, False):
         y0, g0, k0 = _wiener(e, 32768, xs, lens, SR, n_ch=n_ch, vad_guided=vad)
-        y1, g1, k1 = _wiener(e, 16384, xs, lens, SR, n_ch=n_ch, vad_guided=vad)
-        assert not any("k_rowq_classify" in k for k in k0) and any("k_rowq_classify" in k for k in k1)
-        g0h, g1h, y0h, y1h = host(g0), host(g1), host(y0), host(y1)
-        assert np.array_equal(np.isnan(g0h), np.isnan(g1h)) and np.array_equal(np.isnan(y0h), np.isnan(y1h))
-        if vad:
-            tol = 1e-12 if dt == torch.float64 else 2e-6
-            assert np.nanmax(np.abs(g0h - g1h)) <= tol
-            assert np.nanmax(np.abs(y0h - y1h)) <= tol
-        else:
-            assert np.array_equal(g0h, g1h, equal_nan=True)
-            assert np.array_equal(y0h, y1h, equal_nan=True)
+        assert not any("k_rowq" in k for k in k0)
+        g0h, y0h = host(g0), host(y0)
+        for bits, last in ((16384, "waves per row"), (16384 | 65536, "k_rowq_exact")):
+            y1, g1, k1 = _wiener(e, bits, xs, lens, SR, n_ch=n_ch, vad_guided=vad)
+            assert any("k_rowq_classify" in k for k in k1) and any(last in k for k in k1)
+            g1h, y1h = host(g1), host(y1)
+            assert np.array_equal(np.isnan(g0h), np.isnan(g1h)) and np.array_equal(np.isnan(y0h), np.isnan(y1h))
+            if vad:
+                tol = 1e-12 if dt == torch.float64 else 2e-6
+                assert np.nanmax(np.abs(g0h - g1h)) <= tol
+                assert np.nanmax(np.abs(y0h - y1h)) <= tol
+            else:
+                assert np.array_equal(g0h, g1h, equal_nan=True)
+                assert np.array_equal(y0h, y1h, equal_nan=True)
 
 
 @pytest.mark.timeout(600)
@@ -95,6 +100,39 @@ def test_streaming_row_select_long_file_against_oracle(dt, seconds):
             assert float((g0 - g1).abs().max()) <= tol and float((y0 - y1).abs().max()) <= tol
         else:
             assert torch.equal(g0, g1) and torch.equal(y0, y1)
+        want, gain_or = orc.wiener(x.astype(np.float64), SR, vad_guided=vad)
+        if f64:
+            check64(host(y1), want)
+            check64(host(g1)[0], gain_or, 1e-12)
+        else:
+            check32(host(y1), want)
+            assert np.max(np.abs(host(g1)[0] - gain_or)) <= 2e-5
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("dt,seconds", [(torch.float32, 1200), (torch.float64, 660)])
+def test_rows_beyond_the_register_select_against_oracle(dt, seconds):
+    """One mono file of 20 minutes in binary32 (112 497 frames per row) and one of 11 minutes in binary64 (61 872
+    frames): rows no register-resident select holds.  They stay in the grouped layout, selected by the streaming
+    route with the radix selection behind it.  Against the oracle, and against the transposed rows with the
+    long-segment select (diagnostic option bit 64; the route of such files before, and of files beyond 262 144 /
+    98 304 frames still)."""
+    e = engine()
+    f64 = dt == torch.float64
+    n = seconds * SR
+    x = np.concatenate([synth.noisy_speech(60 * SR, SR, 42, 700 + i) * (0.4 + 0.05 * (i % 9)) for i in range(seconds // 60)])
+    x = x.astype(np.float64 if f64 else np.float32)
+    xd = dev(x, dt)
+    tol = 1e-12 if f64 else 2e-6
+    for vad in (True, False):
+        y1, g1, k1 = _wiener(e, 0, xd, [n], SR, vad_guided=vad)
+        assert any("k_rowq_classify" in k for k in k1) and any("k_rowq_exact" in k for k in k1)
+        assert not any("k_rows_fast" in k or "k_stft_rows" in k or "k_big" in k for k in k1)
+        y0, g0, k0 = _wiener(e, 64, xd, [n], SR, vad_guided=vad)
+        assert not any("k_rowq" in k for k in k0)
+        assert float((g0 - g1).abs().max()) <= tol and float((y0 - y1).abs().max()) <= tol
+        if not vad and not f64:
+            assert torch.equal(g0, g1)                      # the same keys on both routes
         want, gain_or = orc.wiener(x.astype(np.float64), SR, vad_guided=vad)
         if f64:
             check64(host(y1), want)
