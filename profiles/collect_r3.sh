@@ -5,7 +5,7 @@
 #   3./4. PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass) reduced by pmc_traffic.py,
 #   5. a PMC pass of eight SQ counters reduced by pmc_sq.py,
 #   6. the mono wavelet shape at BASELINE config 3's full size (1024 x 30 s, db8 level 8): its own line and kernel stats,
-#   7. the shape sweep (clip lengths 10 ... 600 s at the same audio per step).
+#   7. the shape sweep (clip lengths 10 ... 1900 s at the same audio per step).
 set -e
 export ADN_COMMIT=${1:-unknown}      # commit of the tree the files were collected from (the GPU box has no .git)
 OUT=$PWD/gpurun_out/r3
@@ -21,5 +21,5 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c
 cd $OLDPWD
 python3 profiles/pmc_sq.py $OUT/sq/s_counter_collection.csv $OUT/pmc_sq.json > /dev/null
 python3 profiles/pmc_traffic.py $OUT/fetch/f_counter_collection.csv $OUT/write/w_counter_collection.csv 64 $OUT/pmc_traffic.json > /dev/null
-timeout -k 10 300 python3 profiles/shape_sweep.py 10 20 30 45 60 61.3 70 85 90 120 180 240 360 480 600 > $OUT/shape_sweep.txt 2>/dev/null
+timeout -k 10 300 python3 profiles/shape_sweep.py 10 20 30 45 60 61.3 70 85 90 120 180 240 360 480 600 900 1200 1900 > $OUT/shape_sweep.txt 2>/dev/null
 echo collected
