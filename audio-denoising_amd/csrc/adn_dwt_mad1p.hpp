@@ -512,8 +512,7 @@ __device__ __forceinline__ void m1_gather_finish(const T (&d)[BATCH], const bool
         if (saw_nan) st[b].has_nan = 1;
         if (tid == 0) {
             const unsigned int cnt = (unsigned int)(n - f0 < M1_TILE ? n - f0 : M1_TILE);
-            atomicAdd(&st[b].n_m, cnt);
-            atomicAdd(&st[b].n_a, cnt);
+            atomicAdd(m1_counts(&st[b]), (unsigned long long)cnt | ((unsigned long long)cnt << 32));
         }
         return;
     }
@@ -536,8 +535,12 @@ __device__ __forceinline__ void m1_gather_finish(const T (&d)[BATCH], const bool
     if (tid == 0) {
         if ((!tie_m && *s_fill_m > M1_STAGE_M) || (!tie_a && *s_fill_a > M1_STAGE_A)) st[b].spill = 1;
         const unsigned int add_m = tie_m ? *s_fill_m : cm, add_a = tie_a ? *s_fill_a : ca;
-        *s_base_m = add_m ? atomicAdd(&st[b].n_m, add_m) : 0u;
-        *s_base_a = add_a ? atomicAdd(&st[b].n_a, add_a) : 0u;
+        // both list lengths in one returning atomic (n_m and n_a share an aligned 64-bit word; neither reaches 2^32):
+        // the tiles of a block queue up on the block's state, and it is the returning atomics they wait for
+        unsigned long long was = 0;
+        if (add_m | add_a) was = atomicAdd(m1_counts(&st[b]), (unsigned long long)add_m | ((unsigned long long)add_a << 32));
+        *s_base_m = (unsigned int)was;
+        *s_base_a = (unsigned int)(was >> 32);
         if (*s_below_m) atomicAdd(&st[b].below_m, *s_below_m);
         if (*s_below_a) atomicAdd(&st[b].below_a, *s_below_a);
         if (*s_nan) st[b].has_nan = 1;

@@ -1,6 +1,7 @@
 // Definitions shared by the wavelet translation units (adn_dwt.hip and adn_dwt_wres.hip): block geometry,
 // pywt.threshold, filter taps in the operand forms of the two-wide multiply-adds.
 #pragma once
+#include <cstddef>
 #include "adn_kernels.hpp"
 
 namespace adn {
@@ -49,6 +50,11 @@ struct M1State {                  // per block
     int spill;                        // a tile held more bracket keys than its LDS stage: lists incomplete
     int tie_m, tie_a;                 // lo_m == hi_m (alo == ahi): the keys equal to it are counted, not gathered
 };
+
+static_assert(offsetof(M1State, n_m) % 8 == 0 && offsetof(M1State, n_a) == offsetof(M1State, n_m) + 4 && sizeof(M1State) % 8 == 0,
+              "n_m and n_a form one aligned 64-bit word");
+// the two list lengths as one word: n_m in the low half, n_a in the high half
+__device__ __forceinline__ unsigned long long *m1_counts(M1State *st) { return reinterpret_cast<unsigned long long *>(&st->n_m); }
 
 template <typename T>
 __device__ __forceinline__ typename KeyT<T>::type m1_key(T x) {

@@ -455,8 +455,7 @@ __device__ __forceinline__ void gather_details(const T (&d)[NV], bool own, int64
         if (nan) st->has_nan = 1;
         if (lane == 0) {
             const unsigned int cnt = (unsigned int)__popcll(owners) * NV;
-            atomicAdd(&st->n_m, cnt);
-            atomicAdd(&st->n_a, cnt);
+            atomicAdd(m1_counts(st), (unsigned long long)cnt | ((unsigned long long)cnt << 32));
         }
         return;
     }
@@ -493,9 +492,11 @@ __device__ __forceinline__ void gather_details(const T (&d)[NV], bool own, int64
     const unsigned int tot = __shfl(both, 63);
     const unsigned int tm = tot & 0xFFFFu, ta = tot >> 16;
     unsigned int base_m = 0, base_a = 0;
-    if (lane == 0) {
-        if (tm) base_m = atomicAdd(&st->n_m, tm);
-        if (ta) base_a = atomicAdd(&st->n_a, ta);
+    if (lane == 0 && (tm | ta)) {
+        // both list lengths in one returning atomic (they share an aligned 64-bit word)
+        const unsigned long long was = atomicAdd(m1_counts(st), (unsigned long long)tm | ((unsigned long long)ta << 32));
+        base_m = (unsigned int)was;
+        base_a = (unsigned int)(was >> 32);
     }
     base_m = __shfl(base_m, 0);
     base_a = __shfl(base_a, 0);
