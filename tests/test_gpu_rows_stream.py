@@ -1,4 +1,4 @@
-"""GPU parity of the streaming select of long power rows (Wiener stage, files of more than about eight minutes: every
+"""GPU parity of the streaming select of long power rows (Wiener stage, files of more than about four minutes: every
 16th group of four frames brackets the order statistic, one pass over the rows gathers the candidates inside the
 bracket, the exact select runs on them; rows whose bracket misses are left to the register-resident select).
 Diagnostic option bit 16384 sends rows of any length this way, bit 32768 none; bit 65536 gives the rows the brackets
