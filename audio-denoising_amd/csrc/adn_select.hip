@@ -1997,11 +1997,14 @@ void k_select_wave(const T *__restrict__ vals, const int64_t *__restrict__ seg_o
 // which skips the rows marked done.
 static constexpr int RS_STEP = 16;
 // candidates kept per row: the bracket of a median holds about 9 sqrt(RS_STEP n / 4) values
+// (8192 up to 131 072 values, 16 384 up to 524 288, 32 768 beyond; binary64 lists fill LDS at 16 384)
 __host__ __device__ static inline int64_t rows_stream_cap(int64_t max_len, size_t value_bytes) {
-    return value_bytes == 4 && max_len > 131072 ? 16384 : 8192;
+    const int64_t short_rows = value_bytes == 8 ? 98304 : 131072;
+    return max_len <= short_rows ? 8192 : (max_len <= 524288 ? 16384 : 32768);
 }
-// longest row of the grouped layout with the streaming route (the candidate lists of longer rows outgrow LDS)
-static constexpr int64_t RS_LIMIT_F32 = 262144, RS_LIMIT_F64 = 98304;
+// longest row of the grouped layout with the streaming route: the candidate lists of longer rows outgrow LDS, and
+// the register-resident select of the sample addresses a row's groups with 32-bit byte offsets
+static constexpr int64_t RS_LIMIT_F32 = 786432, RS_LIMIT_F64 = 393216;
 static constexpr int RS_BATCH = 4;                      // groups a lane has in flight
 static constexpr int RS_MAX_CHUNKS = 256;
 template <typename T> struct RowStreamMin;              // rows longer than this take the streaming route by themselves

@@ -115,8 +115,8 @@ def test_rows_beyond_the_register_select_against_oracle(dt, seconds):
     """One mono file of 20 minutes in binary32 (112 497 frames per row) and one of 11 minutes in binary64 (61 872
     frames): rows no register-resident select holds.  They stay in the grouped layout, selected by the streaming
     route with the radix selection behind it.  Against the oracle, and against the transposed rows with the
-    long-segment select (diagnostic option bit 64; the route of such files before, and of files beyond 262 144 /
-    98 304 frames still)."""
+    long-segment select (diagnostic option bit 64; the route of such files before, and of files beyond 786 432 /
+    393 216 frames still)."""
     e = engine()
     f64 = dt == torch.float64
     n = seconds * SR
@@ -140,3 +140,27 @@ def test_rows_beyond_the_register_select_against_oracle(dt, seconds):
         else:
             check32(host(y1), want)
             assert np.max(np.abs(host(g1)[0] - gain_or)) <= 2e-5
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("seconds", [3000, 6000])
+def test_rows_of_hours_equal_transposed_route(seconds):
+    """One mono binary32 file of 50 minutes (281 247 frames per row: candidate lists of 16 384) and one of 100 minutes
+    (562 497 frames: lists of 32 768) through the Wiener stage on the grouped rows with the streaming select, against
+    the transposed rows with the long-segment select (diagnostic option bit 64), which the oracle tests pin at
+    shorter lengths: the same order statistics (gain rows bit for bit without voice-activity guidance)."""
+    e = engine()
+    n = seconds * SR
+    gen = torch.Generator(device="cuda:0").manual_seed(seconds)
+    t = torch.arange(n, device="cuda:0", dtype=torch.float32) / SR
+    x = torch.randn(n, device="cuda:0", dtype=torch.float32, generator=gen) * (0.02 + 0.3 * torch.sin(2 * np.pi * t / 97.0).abs())
+    del t
+    for vad in (True, False):
+        y1, g1, k1 = _wiener(e, 0, x, [n], SR, vad_guided=vad)
+        assert any("k_rowq_classify" in k for k in k1) and not any("k_rows_fast" in k or "k_big" in k for k in k1)
+        y0, g0, k0 = _wiener(e, 64, x, [n], SR, vad_guided=vad)
+        assert not any("k_rowq" in k for k in k0)
+        if vad:
+            assert float((g0 - g1).abs().max()) <= 2e-6 and float((y0 - y1).abs().max()) <= 2e-6
+        else:
+            assert torch.equal(g0, g1) and torch.equal(y0, y1)
