@@ -21,5 +21,5 @@ timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c
 cd $OLDPWD
 python3 profiles/pmc_sq.py $OUT/sq/s_counter_collection.csv $OUT/pmc_sq.json > /dev/null
 python3 profiles/pmc_traffic.py $OUT/fetch/f_counter_collection.csv $OUT/write/w_counter_collection.csv 64 $OUT/pmc_traffic.json > /dev/null
-timeout -k 10 300 python3 profiles/shape_sweep.py 10 20 30 45 60 61.3 70 85 90 120 180 240 360 480 600 900 1200 1900 > $OUT/shape_sweep.txt 2>/dev/null
+timeout -k 10 600 python3 profiles/shape_sweep.py 10 20 30 45 60 61.3 70 85 90 120 180 240 360 480 600 900 1200 1900 > $OUT/shape_sweep.txt 2>/dev/null
 echo collected
