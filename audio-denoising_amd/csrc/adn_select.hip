@@ -2440,7 +2440,9 @@ static int launch_select_wave(Ctx *c, const T *d_vals, const SelectArgs &a) {
         }
     }
     if (a.max_len <= 8 * 64) ADN_SEL_WAVE(8);
+    else if (a.max_len <= 16 * 64) ADN_SEL_WAVE(16);       // (clips of 10 s: 938 frames)
     else if (a.max_len <= 24 * 64) ADN_SEL_WAVE(24);
+    else if (a.max_len <= 32 * 64) ADN_SEL_WAVE(32);       // (20 s: 1875 frames)
     else if (a.max_len <= 48 * 64) ADN_SEL_WAVE(48);
     else if (a.max_len <= 88 * 64 && sizeof(T) == 4) ADN_SEL_WAVE(88);     // binary32: four waves per SIMD still
     else if (a.max_len <= 96 * 64) ADN_SEL_WAVE(96);
